@@ -1,0 +1,265 @@
+"""ORACLE (test infrastructure, NOT product code) -- ctypes loader for oracle/liboracle.so
+(the C restatement in oracle_rhs.c) plus problem builders that run the reference's driver
+set-up (oracle/ref_setup.py) for the BASELINE configurations.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import ref_physics as ph
+from . import ref_setup as rs
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+
+
+def build(force=False):
+    """Compile oracle/liboracle.so with gcc (idempotent)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "oracle_rhs.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+class _CnsT(C.Structure):
+    _fields_ = ([("K", C.c_int), ("Np", C.c_int), ("Nq", C.c_int), ("Nfq", C.c_int)]
+                + [(n, _dp) for n in ("Vq", "Pq", "Vf", "LIFT", "Dr", "Ds", "VhP", "Ph", "Qrh", "Qsh",
+                                      "rxJ", "sxJ", "ryJ", "syJ", "J", "wJq", "nxJ", "nyJ", "sJ")]
+                + [("mapP", _lp), ("Nb", C.c_int), ("mapB", _lp), ("bkind", _ip), ("BCTYPE", C.c_int),
+                   ("Re", C.c_double), ("lambda_", C.c_double), ("mu", C.c_double), ("Pr", C.c_double),
+                   ("inviscid_dissp", C.c_int), ("viscous_dissp", C.c_int)])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.oracle_logmean.restype = C.c_double
+        L.oracle_logmean.argtypes = [C.c_double] * 4
+        L.oracle_euler_fluxes_2d.argtypes = [_dp] * 6
+        L.oracle_v_ufun.argtypes = [_dp, _dp]
+        L.oracle_u_vfun.argtypes = [_dp, _dp]
+        L.oracle_betafun.restype = C.c_double
+        L.oracle_betafun.argtypes = [_dp]
+        L.oracle_wavespeed.restype = C.c_double
+        L.oracle_wavespeed.argtypes = [C.c_double] * 3
+        L.oracle_euler_rhs.restype = C.c_double
+        L.oracle_euler_rhs.argtypes = ([C.c_int] * 3 + [_dp] * 4 + [_ip, _ip] + [_dp] * 11 + [_lp, C.c_double, C.c_int, _dp])
+        L.oracle_cns_rhs_inviscid.argtypes = [C.POINTER(_CnsT), _dp, _dp]
+        L.oracle_cns_rhs_viscous.restype = C.c_double
+        L.oracle_cns_rhs_viscous.argtypes = [C.POINTER(_CnsT), _dp, _dp]
+        L.oracle_cns_rhsRK.argtypes = [C.POINTER(_CnsT), _dp, _dp, C.c_int, _dp]
+        L.oracle_set_threads.argtypes = [C.c_int]
+        L.oracle_get_max_threads.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def ek(x):
+    """(n x K) Julia-layout matrix -> C array [K][n]."""
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64).T)
+
+
+def stack(Q):
+    """list of 4 (n x K) matrices -> [4][K][n]."""
+    return np.ascontiguousarray(np.stack([np.asarray(q, dtype=np.float64).T for q in Q]))
+
+
+def unstack(A):
+    """[4][K][n] -> list of 4 (n x K) Fortran matrices."""
+    return [np.asfortranarray(A[f].T) for f in range(A.shape[0])]
+
+
+# ---------------------------------------------------------------------------------------
+# pointwise wrappers
+# ---------------------------------------------------------------------------------------
+def logmean(aL, aR, logL=None, logR=None):
+    if logL is None:
+        logL, logR = np.log(aL), np.log(aR)
+    return lib().oracle_logmean(float(aL), float(aR), float(logL), float(logR))
+
+
+def euler_fluxes_2d(UL, UR):
+    UL = np.array(UL, dtype=float)
+    UR = np.array(UR, dtype=float)
+    lL = np.log(UL[[0, 3]])
+    lR = np.log(UR[[0, 3]])
+    Fx, Fy = np.zeros(4), np.zeros(4)
+    lib().oracle_euler_fluxes_2d(_d(UL), _d(UR), _d(lL), _d(lR), _d(Fx), _d(Fy))
+    return Fx, Fy
+
+
+def v_ufun(U):
+    U = np.array(U, dtype=float)
+    V = np.zeros(4)
+    lib().oracle_v_ufun(_d(U), _d(V))
+    return V
+
+
+def u_vfun(V):
+    V = np.array(V, dtype=float)
+    U = np.zeros(4)
+    lib().oracle_u_vfun(_d(V), _d(U))
+    return U
+
+
+# ---------------------------------------------------------------------------------------
+# problem builders (the reference drivers' set-up sections)
+# ---------------------------------------------------------------------------------------
+class Problem:
+    pass
+
+
+def build_euler_problem(N, Kx, Ky):
+    """examples/dg2D_euler_quad.jl:21-91: periodic vortex box [0,15]x[-5,5], Gauss collocation."""
+    p = Problem()
+    VX, VY, EToV = rs.uniform_quad_mesh(Kx, Ky)
+    VX = 15 * (1 + VX) / 2
+    VY = 5 * VY
+    rd = rs.init_reference_quad(N, rs.gauss_quad(0, 0, N))
+    md = rs.init_mesh_2D(VX, VY, EToV, rd)
+    rs.make_periodic_2D(md, rd, VX, VY)
+    ops = rs.euler_quad_ops(rd)
+    for n in ("rxJ", "sxJ", "ryJ", "syJ"):                       # :86-88
+        setattr(md, n, np.asfortranarray(ops["Vh"] @ getattr(md, n)))
+    rho, u, v, pr = ph.vortex(md.xq, md.yq, 0)                     # :81-83
+    p.Q = [np.asfortranarray(q) for q in ph.primitive_to_conservative(rho, u, v, pr)]
+    p.rd, p.md, p.ops, p.VX, p.VY, p.EToV, p.N = rd, md, ops, VX, VY, EToV, N
+    return p
+
+
+def build_cns_problem(N, Kx, Ky, bc="periodic", BCTYPE=1, Re=1000.0, Pr=.71):
+    """Modal-ESDG CNS set-up of examples/CompressibleNS/dg2D_CNS_cavity_optimized.jl:21-90 fed
+    with the reference *quad* element (SURVEY.md section 8 config mapping).
+      bc="periodic": vortex box [0,15]x[-5,5], mapB emptied after the periodic patch;
+      bc="cavity"  : [-1,1]^2 lid-driven cavity walls with BCTYPE 1/2/3."""
+    p = Problem()
+    VX, VY, EToV = rs.uniform_quad_mesh(Kx, Ky)
+    if bc == "periodic":
+        VX = 15 * (1 + VX) / 2
+        VY = 5 * VY
+    rd = rs.init_reference_quad(N)
+    md = rs.init_mesh_2D(VX, VY, EToV, rd)
+    if bc == "periodic":
+        rs.make_periodic_2D(md, rd, VX, VY)
+        md.mapB = np.zeros(0, dtype=np.int64)
+    ops = rs.cns_ops(rd)
+    for n in ("rxJ", "sxJ", "ryJ", "syJ"):                       # :85-87
+        setattr(md, n, np.asfortranarray(ops["Vh"] @ getattr(md, n)))
+    p.mu = 1 / Re
+    p.lam = -2 / 3 * p.mu                                          # :33-36
+    p.Re, p.Pr, p.BCTYPE, p.bc = Re, Pr, BCTYPE, bc
+    if bc == "periodic":
+        rho, u, v, pr = ph.vortex(md.x, md.y, 0)
+    else:                                                          # smooth non-trivial cavity state
+        x, y = md.x, md.y
+        rho = 1.0 + .2 * np.exp(-10 * (x ** 2 + y ** 2))
+        u = .1 * np.sin(np.pi * x) * np.cos(np.pi * y)
+        v = -.1 * np.cos(np.pi * x) * np.sin(np.pi * y)
+        pr = (1 / (.3 ** 2 * ph.GAMMA)) * rho ** ph.GAMMA
+    p.Q = [np.asfortranarray(q) for q in ph.primitive_to_conservative(rho, u, v, pr)]
+    p.rd, p.md, p.ops, p.VX, p.VY, p.EToV, p.N = rd, md, ops, VX, VY, EToV, N
+    return p
+
+
+# ---------------------------------------------------------------------------------------
+# C RHS wrappers
+# ---------------------------------------------------------------------------------------
+class EulerOracle:
+    """C restatement of `rhs` (examples/dg2D_euler_quad.jl:141-194) bound to one problem."""
+
+    def __init__(self, p):
+        md, ops = p.md, p.ops
+        self.K, self.Nq, self.Nfq = md.K, ops["Ph"].shape[0], ops["Lf"].shape[1]
+        rowptr = [0]
+        col = []
+        for ids in ops["Qrsids"]:
+            col += [c - 1 for c in ids]
+            rowptr.append(len(col))
+        self.rowptr = np.array(rowptr, dtype=np.int32)
+        self.col = np.array(col, dtype=np.int32)
+        c = np.ascontiguousarray
+        self.a = dict(Ef=c(ops["Ef"]), Qr=c(ops["Qrh_sparse"]), Qs=c(ops["Qsh_sparse"]), Ph=c(ops["Ph"]), Lf=c(ops["Lf"]),
+                      rxJ=ek(md.rxJ), sxJ=ek(md.sxJ), ryJ=ek(md.ryJ), syJ=ek(md.syJ), J=ek(md.J), wJq=ek(md.wJq),
+                      nxJ=ek(md.nxJ), nyJ=ek(md.nyJ), sJ=ek(md.sJ))
+        self.mapP = np.ascontiguousarray(md.mapP.T.astype(np.int64))
+
+    def rhs_stacked(self, Qs, lf_scale=.5, compute_rhstest=False):
+        out = np.zeros_like(Qs)
+        a = self.a
+        rt = lib().oracle_euler_rhs(self.K, self.Nq, self.Nfq, _d(Qs), _d(a["Ef"]), _d(a["Qr"]), _d(a["Qs"]),
+                                    self.rowptr.ctypes.data_as(_ip), self.col.ctypes.data_as(_ip), _d(a["Ph"]),
+                                    _d(a["Lf"]), _d(a["rxJ"]), _d(a["sxJ"]), _d(a["ryJ"]), _d(a["syJ"]), _d(a["J"]),
+                                    _d(a["wJq"]), _d(a["nxJ"]), _d(a["nyJ"]), _d(a["sJ"]),
+                                    self.mapP.ctypes.data_as(_lp), float(lf_scale), int(compute_rhstest), _d(out))
+        return out, rt
+
+    def rhs(self, Q, lf_scale=.5, compute_rhstest=False):
+        out, rt = self.rhs_stacked(stack(Q), lf_scale, compute_rhstest)
+        return unstack(out), rt
+
+
+class CnsOracle:
+    """C restatement of rhs_inviscid!/rhs_viscous!/rhsRK! (dg2D_CNS_cavity_optimized.jl) bound to one problem."""
+
+    def __init__(self, p, inviscid_dissp=True, viscous_dissp=True):
+        md, rd, ops = p.md, p.rd, p.ops
+        c = np.ascontiguousarray
+        self.K = md.K
+        self.Np = rd.Pq.shape[0]
+        self.keep = dict(Vq=c(rd.Vq), Pq=c(rd.Pq), Vf=c(rd.Vf), LIFT=c(rd.LIFT), Dr=c(rd.Dr), Ds=c(rd.Ds), VhP=c(ops["VhP"]),
+                         Ph=c(ops["Ph"]), Qrh=c(ops["Qrhskew"]), Qsh=c(ops["Qshskew"]), rxJ=ek(md.rxJ), sxJ=ek(md.sxJ),
+                         ryJ=ek(md.ryJ), syJ=ek(md.syJ), J=ek(md.J), wJq=ek(md.wJq), nxJ=ek(md.nxJ), nyJ=ek(md.nyJ),
+                         sJ=ek(md.sJ))
+        self.mapP = np.ascontiguousarray(md.mapP.T.astype(np.int64))
+        mapB = np.asarray(md.mapB, dtype=np.int64)
+        yb = md.yf.flatten(order="F")[mapB - 1] if mapB.size else np.zeros(0)
+        self.mapB = np.ascontiguousarray(mapB)
+        self.bkind = np.ascontiguousarray((np.abs(yb - 1) < 1e-12).astype(np.int32))   # lid test, :139
+        t = _CnsT()
+        t.K, t.Np, t.Nq, t.Nfq = md.K, self.Np, rd.Vq.shape[0], rd.Vf.shape[0]
+        for k, v in self.keep.items():
+            setattr(t, k, _d(v))
+        t.mapP = self.mapP.ctypes.data_as(_lp)
+        t.Nb = int(mapB.size)
+        t.mapB = self.mapB.ctypes.data_as(_lp)
+        t.bkind = self.bkind.ctypes.data_as(_ip)
+        t.BCTYPE = int(p.BCTYPE)
+        t.Re, t.lambda_, t.mu, t.Pr = float(p.Re), float(p.lam), float(p.mu), float(p.Pr)
+        t.inviscid_dissp, t.viscous_dissp = int(inviscid_dissp), int(viscous_dissp)
+        self.t = t
+
+    def rhs_inviscid(self, Q):
+        Qs = stack(Q)
+        out = np.zeros_like(Qs)
+        lib().oracle_cns_rhs_inviscid(C.byref(self.t), _d(Qs), _d(out))
+        return unstack(out)
+
+    def rhs_viscous(self, Q):
+        Qs = stack(Q)
+        out = np.zeros_like(Qs)
+        rt = lib().oracle_cns_rhs_viscous(C.byref(self.t), _d(Qs), _d(out))
+        return unstack(out), rt
+
+    def rhsRK_stacked(self, Qs, compute_diag=False):
+        out = np.zeros_like(Qs)
+        diag = np.zeros(2)
+        lib().oracle_cns_rhsRK(C.byref(self.t), _d(Qs), _d(out), int(compute_diag), _d(diag))
+        return out, diag
+
+    def rhsRK(self, Q, compute_diag=True):
+        out, diag = self.rhsRK_stacked(stack(Q), compute_diag)
+        return unstack(out), diag[0], diag[1]
