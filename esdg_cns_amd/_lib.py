@@ -1,0 +1,98 @@
+"""ctypes binding of libesdg_hip.so (C ABI: include/esdg_hip.h).  There is no fallback: if the HIP
+extension is missing or no GPU is present, the product path raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libesdg_hip.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int64_p = C.POINTER(C.c_int64)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class esdg_ops_t(C.Structure):
+    _fields_ = [("N", C.c_int32), ("Np", C.c_int32), ("Nq", C.c_int32), ("Nfq", C.c_int32)] + [
+        (n, c_double_p) for n in ("Qrhskew", "Qshskew", "Ph", "wq", "wf", "Ef", "Lf", "Vq", "Pq", "VhP", "LIFT", "Vf", "Dr", "Ds")]
+
+
+class esdg_mesh_t(C.Structure):
+    _fields_ = [("K", C.c_int64), ("geo_ld", C.c_int32),
+                ("rxJ", c_double_p), ("sxJ", c_double_p), ("ryJ", c_double_p), ("syJ", c_double_p),
+                ("J", c_double_p), ("wJq", c_double_p), ("nxJ", c_double_p), ("nyJ", c_double_p), ("sJ", c_double_p),
+                ("mapP", c_int64_p), ("mapB", c_int64_p), ("NmapB", C.c_int64), ("bkind", c_uint8_p),
+                ("elem_offset", C.c_int64), ("Kglobal", C.c_int64), ("nranks", C.c_int32), ("rank", C.c_int32),
+                ("rank_offsets", c_int64_p)]
+
+
+class esdg_phys_t(C.Structure):
+    _fields_ = [("formulation", C.c_int32), ("lf_scale", C.c_double), ("inviscid_dissp", C.c_int32),
+                ("viscous_dissp", C.c_int32), ("BCTYPE", C.c_int32), ("Re", C.c_double), ("mu", C.c_double),
+                ("lambda_", C.c_double), ("Pr", C.c_double)]
+
+
+# every symbol include/esdg_hip.h declares: (restype, argtypes)
+_vp = C.c_void_p
+_szp = C.POINTER(C.c_size_t)
+_i32p = C.POINTER(C.c_int32)
+SYMBOLS = {
+    "esdg_create": (C.c_int, [C.POINTER(esdg_ops_t), C.POINTER(esdg_mesh_t), C.POINTER(esdg_phys_t), C.POINTER(_vp)]),
+    "esdg_destroy": (C.c_int, [_vp]),
+    "esdg_last_error": (C.c_char_p, []),
+    "esdg_version": (C.c_char_p, []),
+    "esdg_workspace_bytes": (C.c_size_t, [_vp]),
+    "esdg_bind_workspace": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "esdg_num_phases": (C.c_int, [_vp]),
+    "esdg_rhs_phase": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "esdg_rhs": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "esdg_rhstest": (C.c_int, [_vp, _vp, _vp, c_double_p, _vp]),
+    "esdg_rhs_host": (C.c_int, [_vp, C.POINTER(c_double_p), C.POINTER(c_double_p)]),
+    "esdg_halo_num_neighbors": (C.c_int, [_vp]),
+    "esdg_num_exchanges": (C.c_int, [_vp]),
+    "esdg_exchange_info": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p]),
+    "esdg_halo_segment": (C.c_int, [_vp, C.c_int, C.c_int, _i32p, _szp, _szp, _szp, _szp]),
+    "esdg_halo_plan_create": (C.c_int, [c_int64_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, c_int64_p, C.POINTER(_vp)]),
+    "esdg_halo_plan_destroy": (C.c_int, [_vp]),
+    "esdg_halo_plan_num_neighbors": (C.c_int, [_vp]),
+    "esdg_halo_plan_num_ghosts": (C.c_int64, [_vp]),
+    "esdg_halo_plan_num_sends": (C.c_int64, [_vp]),
+    "esdg_halo_plan_neighbor": (C.c_int, [_vp, C.c_int, _i32p, c_int64_p, c_int64_p, c_int64_p, c_int64_p]),
+    "esdg_halo_plan_mapP": (_i32p, [_vp]),
+    "esdg_halo_plan_sendlist": (_i32p, [_vp]),
+    "esdg_lsrk_update": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_int64, _vp]),
+    "esdg_axpy_stages": (C.c_int, [_vp, _vp, C.POINTER(_vp), c_double_p, C.c_int, C.c_double, C.c_int64, _vp]),
+    "esdg_dopri_error": (C.c_int, [_vp, C.POINTER(_vp), c_double_p, C.c_int, C.c_double, C.c_int64, c_double_p, _vp]),
+    "esdg_dmalloc": (_vp, [C.c_size_t]),
+    "esdg_dfree": (C.c_int, [_vp]),
+    "esdg_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "esdg_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "esdg_device_synchronize": (C.c_int, []),
+    "esdg_device_count": (C.c_int, []),
+}
+
+_LIB = None
+
+
+class EsdgError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libesdg_hip.so; raise loudly when the HIP extension has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise EsdgError(f"{LIB_PATH} not found: the HIP extension is not built "
+                            "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)      # AttributeError if the ABI and the header drifted apart
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise EsdgError(f"libesdg_hip error {rc}: {lib().esdg_last_error().decode()}")

@@ -1,0 +1,30 @@
+"""Build libesdg_hip.so in-tree with hipcc for gfx950 (MI355X)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["csrc/esdg_kernels.hip", "csrc/esdg_api.hip"]
+HEADERS = ["csrc/esdg_dev.hpp", "../include/esdg_hip.h"]
+OUT = os.path.join(HERE, "libesdg_hip.so")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    if not (force or needs_build()):
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", OUT] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=HERE)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force=True, verbose=True)

@@ -1,0 +1,664 @@
+// esdg_api.hip -- host side of libesdg_hip.so: the C ABI declared in include/esdg_hip.h.
+//
+// esdg_create() takes exactly the arrays a reference driver holds when it calls its `rhs`
+// (rd::RefElemData / md::MeshData fields and the `ops` tuple, all column-major, 1-based maps),
+// derives the sparse collocated operators the kernels use, checks the structural assumptions
+// (tensor-product sparsity, skew-symmetry, affine elements) and builds the halo plan for
+// element-index sharding.  There is no CPU compute path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/esdg_hip.h"
+#include "esdg_dev.hpp"
+
+using namespace esdg;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) return fail(ESDG_ERR_NO_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+constexpr double DROPTOL = 1e-12;  // same threshold as the reference's droptol! calls (euler_quad.jl:62-63,76-78)
+
+// dense row-major matrix helper
+struct Mat {
+  int r = 0, c = 0;
+  std::vector<double> a;
+  Mat() {}
+  Mat(int r_, int c_) : r(r_), c(c_), a((size_t)r_ * c_, 0.0) {}
+  double& operator()(int i, int j) { return a[(size_t)i * c + j]; }
+  double operator()(int i, int j) const { return a[(size_t)i * c + j]; }
+};
+
+Mat from_colmajor(const double* p, int r, int c) {
+  Mat m(r, c);
+  for (int j = 0; j < c; ++j)
+    for (int i = 0; i < r; ++i) m(i, j) = p[(size_t)j * r + i];
+  return m;
+}
+
+Mat matmul(const Mat& A, const Mat& B) {
+  Mat C(A.r, B.c);
+  for (int i = 0; i < A.r; ++i)
+    for (int k = 0; k < A.c; ++k) {
+      const double a = A(i, k);
+      if (a == 0.0) continue;
+      for (int j = 0; j < B.c; ++j) C(i, j) += a * B(k, j);
+    }
+  return C;
+}
+
+struct Ell {
+  int rows = 0, w = 0;
+  std::vector<uint8_t> idx;
+  std::vector<double> val;
+};
+
+// sparsify with the reference's drop tolerance; returns false if a row exceeds wmax
+bool to_ell(const Mat& A, int wmax, Ell& out) {
+  int w = 0;
+  for (int i = 0; i < A.r; ++i) {
+    int n = 0;
+    for (int j = 0; j < A.c; ++j) n += std::fabs(A(i, j)) > DROPTOL;
+    w = std::max(w, n);
+  }
+  if (w > wmax || A.c > 255) return false;
+  if (w == 0) w = 1;
+  out.rows = A.r;
+  out.w = w;
+  out.idx.assign((size_t)A.r * w, 0);
+  out.val.assign((size_t)A.r * w, 0.0);
+  for (int i = 0; i < A.r; ++i) {
+    int t = 0;
+    for (int j = 0; j < A.c; ++j)
+      if (std::fabs(A(i, j)) > DROPTOL) {
+        out.idx[(size_t)i * w + t] = (uint8_t)j;
+        out.val[(size_t)i * w + t] = A(i, j);
+        ++t;
+      }
+  }
+  return true;
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  template <typename T>
+  int upload(const std::vector<T>& v) {
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    HIP_TRY(hipMalloc(&p, bytes));
+    if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+  }
+  int alloc(size_t bytes) {
+    HIP_TRY(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+    return 0;
+  }
+  template <typename T>
+  const T* as() const { return static_cast<const T*>(p); }
+};
+
+struct Exchange {
+  int after_phase, before_phase, ncomp;
+  size_t buf_off;   // byte offset of the trace buffer in the workspace
+  size_t send_off;  // byte offset of the packed send buffer in the workspace
+};
+
+}  // namespace
+
+// Halo plan for element-index sharding: pure host logic, no device needed.
+struct esdg_halo_plan {
+  int64_t K = 0, nghost = 0, nsend = 0;
+  int Nfq = 0;
+  std::vector<int32_t> mapP;      // local face-node index, or ghost slot K*Nfq + g
+  std::vector<int32_t> sendlist;  // local face nodes to pack, grouped by neighbour
+  std::vector<int32_t> nbr_rank;
+  std::vector<int64_t> nbr_send_off, nbr_send_cnt, nbr_recv_off, nbr_recv_cnt;  // in face nodes
+};
+
+namespace {
+
+// mapP: (Nfq x K) 1-based GLOBAL linear indices of the local elements [elem_offset, elem_offset+K).
+// Ghost slots of one neighbour rank are contiguous and ordered by the global node id; the send list
+// towards a neighbour is ordered by the global id of the local node.  On a conforming mesh (mapP an
+// involution) both sides therefore agree on the order without communicating.
+int build_halo_plan(const int64_t* mapP_g, int64_t K, int Nfq, int64_t e_lo, int64_t Kg, int nranks,
+                    const int64_t* rank_offsets, esdg_halo_plan& pl) {
+  if (K < 0 || Nfq <= 0 || !mapP_g) return fail(ESDG_ERR_ARG, "bad halo plan arguments");
+  if ((int64_t)K * Nfq > (int64_t)2000000000) return fail(ESDG_ERR_ARG, "too many local face nodes for int32 maps");
+  if (nranks > 1 && !rank_offsets) return fail(ESDG_ERR_ARG, "rank_offsets required when nranks>1");
+  if (Kg <= 0) Kg = K;
+  auto owner = [&](int64_t ge) -> int {
+    if (nranks <= 1) return 0;
+    int r = (int)(std::upper_bound(rank_offsets, rank_offsets + nranks + 1, ge) - rank_offsets) - 1;
+    return std::min(std::max(r, 0), nranks - 1);
+  };
+  pl.K = K; pl.Nfq = Nfq;
+  pl.mapP.assign((size_t)K * Nfq, 0);
+  std::map<int, std::vector<int64_t>> ghosts, sends;
+  for (int64_t n = 0; n < K * Nfq; ++n) {
+    const int64_t g = mapP_g[n] - 1;
+    if (g < 0 || g >= Kg * Nfq) return fail(ESDG_ERR_ARG, "mapP[%lld]=%lld out of range", (long long)n, (long long)(g + 1));
+    const int64_t ge = g / Nfq;
+    if (ge >= e_lo && ge < e_lo + K) {
+      pl.mapP[n] = (int32_t)(g - e_lo * Nfq);
+    } else {
+      const int r = owner(ge);
+      ghosts[r].push_back(g);
+      sends[r].push_back(e_lo * Nfq + n);
+      pl.mapP[n] = -1;
+    }
+  }
+  int64_t goff = 0, soff = 0;
+  std::map<int, std::map<int64_t, int32_t>> ghost_slot;
+  for (auto& kv : ghosts) {
+    auto& v = kv.second;
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    auto& sv = sends[kv.first];
+    std::sort(sv.begin(), sv.end());
+    sv.erase(std::unique(sv.begin(), sv.end()), sv.end());
+    pl.nbr_rank.push_back(kv.first);
+    pl.nbr_recv_off.push_back(goff);
+    pl.nbr_recv_cnt.push_back((int64_t)v.size());
+    pl.nbr_send_off.push_back(soff);
+    pl.nbr_send_cnt.push_back((int64_t)sv.size());
+    auto& slot = ghost_slot[kv.first];
+    for (size_t i = 0; i < v.size(); ++i) slot[v[i]] = (int32_t)(K * Nfq + goff + (int64_t)i);
+    for (int64_t gs : sv) pl.sendlist.push_back((int32_t)(gs - e_lo * Nfq));
+    goff += (int64_t)v.size();
+    soff += (int64_t)sv.size();
+  }
+  pl.nghost = goff;
+  pl.nsend = soff;
+  for (int64_t n = 0; n < K * Nfq; ++n)
+    if (pl.mapP[n] < 0) {
+      const int64_t g = mapP_g[n] - 1;
+      pl.mapP[n] = ghost_slot[owner(g / Nfq)][g];
+    }
+  return 0;
+}
+
+}  // namespace
+
+struct esdg_ctx {
+  Tables T{};
+  MeshDev M{};
+  Phys ph{};
+  int nphases = 2;
+  int64_t K = 0, nghost = 0, nsend = 0;
+  int Np = 0, Nq = 0, Nfq = 0;
+  // device storage
+  DevBuf d_pair_ij, d_pair_c, d_inc_ptr, d_inc, d_Ef_i, d_Ef_v, d_Ph_i, d_Ph_v, d_Lf_i, d_Lf_v, d_Dr_i, d_Dr_v, d_Ds_i,
+      d_Ds_v, d_Vq, d_Pq, d_geo, d_mapP, d_bc, d_wJq, d_sendlist, d_partial;
+  // halo plan
+  std::vector<int32_t> nbr_rank;
+  std::vector<int64_t> nbr_send_off, nbr_send_cnt, nbr_recv_off, nbr_recv_cnt;  // in face nodes
+  std::vector<Exchange> xch;
+  // workspace
+  size_t ws_bytes = 0;
+  char* ws = nullptr;
+  size_t off_AU = 0, off_Av = 0, off_B = 0;
+  static constexpr int NPARTIAL = 1024;
+};
+
+extern "C" {
+
+const char* esdg_last_error(void) { return g_err.c_str(); }
+const char* esdg_version(void) { return "esdg_hip 0.1 (gfx950)"; }
+
+int esdg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_t* phys, esdg_ctx** out) {
+  if (!ops || !mesh || !phys || !out) return fail(ESDG_ERR_ARG, "null argument");
+  *out = nullptr;
+  const int N1 = ops->N + 1, Nq = ops->Nq, Nfq = ops->Nfq, Np = ops->Np, Nh = Nq + Nfq;
+  if (!supported_degree(N1)) return fail(ESDG_ERR_ARG, "unsupported degree N=%d (need 1..7)", ops->N);
+  if (Nq != N1 * N1 || Np != N1 * N1 || Nfq != 4 * N1)
+    return fail(ESDG_ERR_STRUCTURE, "need tensor quad sizes Np=Nq=(N+1)^2, Nfq=4(N+1); got Np=%d Nq=%d Nfq=%d", Np, Nq,
+                Nfq);
+  const int form = phys->formulation;
+  if (form < 0 || form > 2) return fail(ESDG_ERR_ARG, "bad formulation %d", form);
+  const bool modal = form != ESDG_EULER_COLLOCATED, visc = form == ESDG_CNS_MODAL;
+  if (!ops->Qrhskew || !ops->Qshskew || !ops->Ph) return fail(ESDG_ERR_ARG, "Qrhskew/Qshskew/Ph required");
+  if (!modal && (!ops->Ef || !ops->Lf)) return fail(ESDG_ERR_ARG, "collocated formulation needs Ef and Lf");
+  if (modal && (!ops->Vq || !ops->Pq || !ops->VhP || !ops->LIFT)) return fail(ESDG_ERR_ARG, "modal formulation needs Vq,Pq,VhP,LIFT");
+  if (visc && (!ops->Dr || !ops->Ds)) return fail(ESDG_ERR_ARG, "CNS formulation needs Dr and Ds");
+  if (mesh->K < 0 || !mesh->rxJ || !mesh->sxJ || !mesh->ryJ || !mesh->syJ || !mesh->J || !mesh->nxJ || !mesh->nyJ ||
+      !mesh->sJ || !mesh->mapP)
+    return fail(ESDG_ERR_ARG, "mesh arrays missing");
+  if (mesh->NmapB > 0) return fail(ESDG_ERR_ARG, "wall boundary conditions are not implemented yet (NmapB=%lld)", (long long)mesh->NmapB);
+  if ((int64_t)mesh->K * Nfq > (int64_t)2000000000) return fail(ESDG_ERR_ARG, "too many local face nodes for int32 maps");
+  if (esdg_device_count() < 1) return fail(ESDG_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+
+  esdg_ctx* c = new esdg_ctx();
+  struct Guard {
+    esdg_ctx* c;
+    ~Guard() { delete c; }
+  } guard{c};
+
+  c->Np = Np; c->Nq = Nq; c->Nfq = Nfq; c->K = mesh->K;
+  c->ph.formulation = form;
+  c->ph.lf_scale = phys->lf_scale;
+  c->ph.inviscid_dissp = phys->inviscid_dissp;
+  c->ph.viscous_dissp = phys->viscous_dissp;
+  c->ph.BCTYPE = phys->BCTYPE;
+  c->ph.Re = phys->Re; c->ph.mu = phys->mu; c->ph.lambda = phys->lambda; c->ph.Pr = phys->Pr;
+  c->nphases = visc ? 3 : 2;
+
+  // ---- collocated sparse operators -------------------------------------------------------
+  Mat EfD, PhC, LfC, DrC, DsC, Vq, Pq;
+  if (!modal) {
+    EfD = from_colmajor(ops->Ef, Nfq, Nq);
+    PhC = from_colmajor(ops->Ph, Nq, Nh);
+    LfC = from_colmajor(ops->Lf, Nq, Nfq);
+  } else {
+    Vq = from_colmajor(ops->Vq, Nq, Np);
+    Pq = from_colmajor(ops->Pq, Np, Nq);
+    Mat VhP = from_colmajor(ops->VhP, Nh, Nq);
+    EfD = Mat(Nfq, Nq);
+    for (int i = 0; i < Nfq; ++i)
+      for (int j = 0; j < Nq; ++j) EfD(i, j) = VhP(Nq + i, j);
+    // the volume block of VhP must be the identity (Vq*Pq = I on tensor quads)
+    for (int i = 0; i < Nq; ++i)
+      for (int j = 0; j < Nq; ++j)
+        if (std::fabs(VhP(i, j) - (i == j ? 1.0 : 0.0)) > 1e-10)
+          return fail(ESDG_ERR_STRUCTURE, "VhP volume block is not the identity (|VhP[%d,%d]-delta|=%g): not a Gauss tensor element", i, j,
+                      std::fabs(VhP(i, j) - (i == j ? 1.0 : 0.0)));
+    PhC = matmul(Vq, from_colmajor(ops->Ph, Np, Nh));
+    LfC = matmul(Vq, from_colmajor(ops->LIFT, Np, Nfq));
+    if (visc) {
+      DrC = matmul(matmul(Vq, from_colmajor(ops->Dr, Np, Np)), Pq);
+      DsC = matmul(matmul(Vq, from_colmajor(ops->Ds, Np, Np)), Pq);
+    }
+  }
+  Ell eEf, ePh, eLf, eDr, eDs;
+  if (!to_ell(EfD, N1, eEf)) return fail(ESDG_ERR_STRUCTURE, "Ef has more than N+1 non-zeros per row");
+  if (!to_ell(PhC, 5, ePh)) return fail(ESDG_ERR_STRUCTURE, "collocated Ph has more than 5 non-zeros per row");
+  if (!to_ell(LfC, 4, eLf)) return fail(ESDG_ERR_STRUCTURE, "collocated Lf has more than 4 non-zeros per row");
+  if (visc) {
+    if (!to_ell(DrC, N1, eDr) || !to_ell(DsC, N1, eDs)) return fail(ESDG_ERR_STRUCTURE, "collocated Dr/Ds not tensor-sparse");
+    if (eDr.w != eDs.w) {  // equalise widths
+      const int w = std::max(eDr.w, eDs.w);
+      auto widen = [&](Ell& e) {
+        Ell n;
+        n.rows = e.rows; n.w = w;
+        n.idx.assign((size_t)e.rows * w, 0);
+        n.val.assign((size_t)e.rows * w, 0.0);
+        for (int i = 0; i < e.rows; ++i)
+          for (int t = 0; t < e.w; ++t) { n.idx[(size_t)i * w + t] = e.idx[(size_t)i * e.w + t]; n.val[(size_t)i * w + t] = e.val[(size_t)i * e.w + t]; }
+        e = n;
+      };
+      widen(eDr); widen(eDs);
+    }
+  }
+
+  // ---- flux-differencing pair list ---------------------------------------------------------
+  Mat Qr = from_colmajor(ops->Qrhskew, Nh, Nh), Qs = from_colmajor(ops->Qshskew, Nh, Nh);
+  std::vector<uint8_t> pair_ij;
+  std::vector<double> pair_c;
+  std::vector<std::vector<uint16_t>> rows(Nh);
+  for (int i = 0; i < Nh; ++i)
+    for (int j = i; j < Nh; ++j) {
+      if (std::fabs(Qr(i, j) + Qr(j, i)) > 1e-10 || std::fabs(Qs(i, j) + Qs(j, i)) > 1e-10)
+        return fail(ESDG_ERR_STRUCTURE, "Qrhskew/Qshskew not skew-symmetric at (%d,%d)", i, j);
+      const bool nz = std::fabs(Qr(i, j)) > DROPTOL || std::fabs(Qs(i, j)) > DROPTOL;
+      if (!nz || i == j) continue;
+      if (i >= Nq && j >= Nq) return fail(ESDG_ERR_STRUCTURE, "non-zero face-face SBP weight at (%d,%d)", i, j);
+      const int p = (int)pair_c.size() / 2;
+      pair_ij.push_back((uint8_t)i);
+      pair_ij.push_back((uint8_t)j);
+      pair_c.push_back(Qr(i, j));
+      pair_c.push_back(Qs(i, j));
+      rows[i].push_back((uint16_t)p);
+      rows[j].push_back((uint16_t)(p | 0x8000));
+    }
+  const int P = (int)pair_c.size() / 2;
+  if (P > N1 * N1 * (N1 + 3))
+    return fail(ESDG_ERR_STRUCTURE, "%d non-zero flux pairs, tensor-product Gauss elements have %d", P, N1 * N1 * (N1 + 3));
+  std::vector<uint16_t> inc_ptr(Nh + 1, 0), inc;
+  for (int i = 0; i < Nh; ++i) {
+    inc_ptr[i + 1] = (uint16_t)(inc_ptr[i] + rows[i].size());
+    inc.insert(inc.end(), rows[i].begin(), rows[i].end());
+  }
+
+  // ---- geometry: affine check + per-element records ---------------------------------------
+  const int64_t K = mesh->K;
+  const int ld = mesh->geo_ld > 0 ? mesh->geo_ld : Nh;
+  std::vector<double> geo((size_t)K * GEO_STRIDE);
+  for (int64_t e = 0; e < K; ++e) {
+    const double* src[4] = {mesh->rxJ + e * ld, mesh->sxJ + e * ld, mesh->ryJ + e * ld, mesh->syJ + e * ld};
+    double scale = 0;
+    for (int m = 0; m < 4; ++m) scale = std::max(scale, std::fabs(src[m][0]));
+    for (int m = 0; m < 4; ++m) {
+      for (int i = 1; i < ld; ++i)
+        if (std::fabs(src[m][i] - src[m][0]) > 1e-10 * scale)
+          return fail(ESDG_ERR_STRUCTURE, "element %lld is not affine (metric term %d varies)", (long long)e, m);
+      geo[(size_t)e * GEO_STRIDE + m] = src[m][0];
+    }
+    const double* J = mesh->J + e * Np;
+    for (int i = 1; i < Np; ++i)
+      if (std::fabs(J[i] - J[0]) > 1e-10 * std::fabs(J[0])) return fail(ESDG_ERR_STRUCTURE, "element %lld is not affine (J varies)", (long long)e);
+    geo[(size_t)e * GEO_STRIDE + 4] = J[0];
+    for (int f = 0; f < 4; ++f) {
+      const size_t o = (size_t)e * Nfq + (size_t)f * N1;
+      for (int i = 1; i < N1; ++i)
+        if (std::fabs(mesh->nxJ[o + i] - mesh->nxJ[o]) > 1e-10 * mesh->sJ[o] || std::fabs(mesh->nyJ[o + i] - mesh->nyJ[o]) > 1e-10 * mesh->sJ[o])
+          return fail(ESDG_ERR_STRUCTURE, "element %lld face %d is curved", (long long)e, f);
+      geo[(size_t)e * GEO_STRIDE + 5 + 3 * f + 0] = mesh->nxJ[o];
+      geo[(size_t)e * GEO_STRIDE + 5 + 3 * f + 1] = mesh->nyJ[o];
+      geo[(size_t)e * GEO_STRIDE + 5 + 3 * f + 2] = mesh->sJ[o];
+    }
+  }
+
+  // ---- mapP -> local int32 with ghost slots; halo plan ------------------------------------
+  esdg_halo_plan pl;
+  {
+    int prc = build_halo_plan(mesh->mapP, K, Nfq, mesh->elem_offset, mesh->Kglobal > 0 ? mesh->Kglobal : K,
+                              std::max(1, mesh->nranks), mesh->rank_offsets, pl);
+    if (prc) return prc;
+  }
+  c->nghost = pl.nghost;
+  c->nsend = pl.nsend;
+  c->nbr_rank = pl.nbr_rank;
+  c->nbr_send_off = pl.nbr_send_off; c->nbr_send_cnt = pl.nbr_send_cnt;
+  c->nbr_recv_off = pl.nbr_recv_off; c->nbr_recv_cnt = pl.nbr_recv_cnt;
+  const std::vector<int32_t>& mapP = pl.mapP;
+  const std::vector<int32_t>& sendlist = pl.sendlist;
+
+  // ---- upload ------------------------------------------------------------------------------
+  int rc;
+#define UP(buf, vec) if ((rc = c->buf.upload(vec)) != 0) return rc
+  UP(d_pair_ij, pair_ij); UP(d_pair_c, pair_c); UP(d_inc_ptr, inc_ptr); UP(d_inc, inc);
+  UP(d_Ef_i, eEf.idx); UP(d_Ef_v, eEf.val); UP(d_Ph_i, ePh.idx); UP(d_Ph_v, ePh.val);
+  UP(d_Lf_i, eLf.idx); UP(d_Lf_v, eLf.val);
+  UP(d_Dr_i, eDr.idx); UP(d_Dr_v, eDr.val); UP(d_Ds_i, eDs.idx); UP(d_Ds_v, eDs.val);
+  UP(d_Vq, Vq.a); UP(d_Pq, Pq.a);
+  UP(d_geo, geo); UP(d_mapP, mapP); UP(d_sendlist, sendlist);
+  if (mesh->wJq) {
+    std::vector<double> w(mesh->wJq, mesh->wJq + (size_t)K * Nq);
+    UP(d_wJq, w);
+  }
+#undef UP
+  if ((rc = c->d_partial.alloc(sizeof(double) * esdg_ctx::NPARTIAL)) != 0) return rc;
+
+  Tables& T = c->T;
+  T.N1 = N1; T.Np = Np; T.Nq = Nq; T.Nfq = Nfq; T.Nh = Nh; T.P = P;
+  T.pair_ij = c->d_pair_ij.as<uint8_t>(); T.pair_c = c->d_pair_c.as<double>();
+  T.inc_ptr = c->d_inc_ptr.as<uint16_t>(); T.inc = c->d_inc.as<uint16_t>();
+  T.Ef_idx = c->d_Ef_i.as<uint8_t>(); T.Ef_val = c->d_Ef_v.as<double>(); T.wEf = eEf.w;
+  T.Ph_idx = c->d_Ph_i.as<uint8_t>(); T.Ph_val = c->d_Ph_v.as<double>(); T.wPh = ePh.w;
+  T.Lf_idx = c->d_Lf_i.as<uint8_t>(); T.Lf_val = c->d_Lf_v.as<double>(); T.wLf = eLf.w;
+  T.Dr_idx = c->d_Dr_i.as<uint8_t>(); T.Dr_val = c->d_Dr_v.as<double>();
+  T.Ds_idx = c->d_Ds_i.as<uint8_t>(); T.Ds_val = c->d_Ds_v.as<double>(); T.wD = visc ? eDr.w : 0;
+  T.Vq = c->d_Vq.as<double>(); T.Pq = c->d_Pq.as<double>();
+  c->M.K = K; c->M.geo = c->d_geo.as<double>(); c->M.mapP = c->d_mapP.as<int32_t>(); c->M.bc = nullptr;
+  c->M.wJq = mesh->wJq ? c->d_wJq.as<double>() : nullptr;
+
+  // ---- workspace layout ---------------------------------------------------------------------
+  auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t nodes = (size_t)(K * Nfq + c->nghost);
+  size_t off = 0;
+  c->off_AU = off; off = align(off + nodes * AU_NC * sizeof(double));
+  if (visc) {
+    c->off_Av = off; off = align(off + nodes * AV_NC * sizeof(double));
+    c->off_B = off; off = align(off + nodes * B_NC * sizeof(double));
+  }
+  Exchange x0{0, c->nphases - 1, AU_NC, c->off_AU, off};
+  off = align(off + (size_t)c->nsend * AU_NC * sizeof(double));
+  c->xch.push_back(x0);
+  if (visc) {
+    Exchange x1{0, 1, AV_NC, c->off_Av, off};
+    off = align(off + (size_t)c->nsend * AV_NC * sizeof(double));
+    Exchange x2{1, 2, B_NC, c->off_B, off};
+    off = align(off + (size_t)c->nsend * B_NC * sizeof(double));
+    c->xch.push_back(x1);
+    c->xch.push_back(x2);
+  }
+  c->ws_bytes = off;
+  guard.c = nullptr;
+  *out = c;
+  return ESDG_OK;
+}
+
+int esdg_destroy(esdg_ctx* ctx) {
+  delete ctx;
+  return ESDG_OK;
+}
+
+size_t esdg_workspace_bytes(const esdg_ctx* ctx) { return ctx ? ctx->ws_bytes : 0; }
+
+int esdg_bind_workspace(esdg_ctx* ctx, void* dev_ptr, size_t bytes) {
+  if (!ctx || !dev_ptr) return fail(ESDG_ERR_ARG, "null argument");
+  if (bytes < ctx->ws_bytes) return fail(ESDG_ERR_ARG, "workspace too small: %zu < %zu", bytes, ctx->ws_bytes);
+  if (((uintptr_t)dev_ptr & 15) != 0) return fail(ESDG_ERR_ARG, "workspace must be 16-byte aligned");
+  ctx->ws = static_cast<char*>(dev_ptr);
+  return ESDG_OK;
+}
+
+int esdg_num_phases(const esdg_ctx* ctx) { return ctx ? ctx->nphases : 0; }
+
+int esdg_rhs_phase(esdg_ctx* ctx, int phase, const double* Q, double* rhs, void* stream) {
+  if (!ctx || !Q) return fail(ESDG_ERR_ARG, "null argument");
+  if (!ctx->ws) return fail(ESDG_ERR_STATE, "workspace not bound (esdg_bind_workspace)");
+  if (phase < 0 || phase >= ctx->nphases) return fail(ESDG_ERR_ARG, "bad phase %d", phase);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  double* A_U = reinterpret_cast<double*>(ctx->ws + ctx->off_AU);
+  const bool visc = ctx->nphases == 3;
+  double* A_v = visc ? reinterpret_cast<double*>(ctx->ws + ctx->off_Av) : nullptr;
+  double* B = visc ? reinterpret_cast<double*>(ctx->ws + ctx->off_B) : nullptr;
+  int rc = 0;
+  const int32_t* sl = ctx->d_sendlist.as<int32_t>();
+  if (phase == 0) {
+    rc = launch_project(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, s);
+    if (!rc && ctx->nsend) {
+      rc = launch_pack(A_U, AU_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[0].send_off), s);
+      if (!rc && visc) rc = launch_pack(A_v, AV_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[1].send_off), s);
+    }
+  } else if (visc && phase == 1) {
+    rc = launch_sigma(ctx->T, ctx->M, ctx->ph, Q, A_v, B, s);
+    if (!rc && ctx->nsend) rc = launch_pack(B, B_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[2].send_off), s);
+  } else {
+    if (!rhs) return fail(ESDG_ERR_ARG, "rhs output is null");
+    rc = launch_rhs(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, B, rhs, s);
+  }
+  if (rc) return fail(ESDG_ERR_NO_DEVICE, "kernel launch failed in phase %d: %s", phase, hipGetErrorString((hipError_t)rc));
+  return ESDG_OK;
+}
+
+int esdg_rhs(esdg_ctx* ctx, const double* Q, double* rhs, void* stream) {
+  if (!ctx) return fail(ESDG_ERR_ARG, "null ctx");
+  if (ctx->nghost) return fail(ESDG_ERR_STATE, "mesh is sharded: drive esdg_rhs_phase + halo exchange from the host");
+  for (int p = 0; p < ctx->nphases; ++p) {
+    int rc = esdg_rhs_phase(ctx, p, Q, rhs, stream);
+    if (rc) return rc;
+  }
+  return ESDG_OK;
+}
+
+int esdg_rhstest(esdg_ctx* ctx, const double* Q, const double* rhs, double* diag, void* stream) {
+  if (!ctx || !Q || !rhs || !diag) return fail(ESDG_ERR_ARG, "null argument");
+  if (!ctx->M.wJq) return fail(ESDG_ERR_STATE, "wJq was not supplied at esdg_create");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  double* partial = static_cast<double*>(ctx->d_partial.p);
+  int rc = launch_rhstest(ctx->T, ctx->M, ctx->ph, Q, rhs, partial, esdg_ctx::NPARTIAL, s);
+  if (rc) return fail(ESDG_ERR_NO_DEVICE, "rhstest launch: %s", hipGetErrorString((hipError_t)rc));
+  std::vector<double> h(esdg_ctx::NPARTIAL);
+  HIP_TRY(hipMemcpyAsync(h.data(), partial, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  double t = 0.0;
+  for (double v : h) t += v;
+  diag[0] = t;
+  diag[1] = 0.0;
+  return ESDG_OK;
+}
+
+int esdg_rhs_host(esdg_ctx* ctx, const double* const Q[4], double* const rhs[4]) {
+  if (!ctx || !Q || !rhs) return fail(ESDG_ERR_ARG, "null argument");
+  if (ctx->nghost) return fail(ESDG_ERR_STATE, "esdg_rhs_host needs an unsharded mesh");
+  const size_t n = (size_t)ctx->K * ctx->Np, bytes = n * sizeof(double);
+  DevBuf dQ, dR, dW;
+  int rc;
+  if ((rc = dQ.alloc(4 * bytes)) || (rc = dR.alloc(4 * bytes))) return rc;
+  void* old_ws = ctx->ws;
+  if (!ctx->ws) {
+    if ((rc = dW.alloc(ctx->ws_bytes))) return rc;
+    ctx->ws = static_cast<char*>(dW.p);
+  }
+  for (int f = 0; f < 4; ++f) HIP_TRY(hipMemcpy(static_cast<char*>(dQ.p) + f * bytes, Q[f], bytes, hipMemcpyHostToDevice));
+  rc = esdg_rhs(ctx, static_cast<const double*>(dQ.p), static_cast<double*>(dR.p), nullptr);
+  if (!rc) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) rc = fail(ESDG_ERR_NO_DEVICE, "kernel execution failed: %s", hipGetErrorString(e));
+  }
+  ctx->ws = static_cast<char*>(old_ws);
+  if (rc) return rc;
+  for (int f = 0; f < 4; ++f) HIP_TRY(hipMemcpy(rhs[f], static_cast<char*>(dR.p) + f * bytes, bytes, hipMemcpyDeviceToHost));
+  return ESDG_OK;
+}
+
+// ---- halo plan -------------------------------------------------------------------------------
+int esdg_halo_num_neighbors(const esdg_ctx* ctx) { return ctx ? (int)ctx->nbr_rank.size() : 0; }
+int esdg_num_exchanges(const esdg_ctx* ctx) { return ctx ? (int)ctx->xch.size() : 0; }
+
+int esdg_exchange_info(const esdg_ctx* ctx, int xch, int32_t* after_phase, int32_t* before_phase, int32_t* ncomp) {
+  if (!ctx || xch < 0 || xch >= (int)ctx->xch.size()) return fail(ESDG_ERR_ARG, "bad exchange id");
+  if (after_phase) *after_phase = ctx->xch[xch].after_phase;
+  if (before_phase) *before_phase = ctx->xch[xch].before_phase;
+  if (ncomp) *ncomp = ctx->xch[xch].ncomp;
+  return ESDG_OK;
+}
+
+int esdg_halo_segment(const esdg_ctx* ctx, int xch, int nbr, int32_t* peer, size_t* send_off, size_t* send_bytes,
+                      size_t* recv_off, size_t* recv_bytes) {
+  if (!ctx || xch < 0 || xch >= (int)ctx->xch.size() || nbr < 0 || nbr >= (int)ctx->nbr_rank.size())
+    return fail(ESDG_ERR_ARG, "bad exchange/neighbour id");
+  const Exchange& x = ctx->xch[xch];
+  const size_t rec = (size_t)x.ncomp * sizeof(double);
+  if (peer) *peer = ctx->nbr_rank[nbr];
+  if (send_off) *send_off = x.send_off + (size_t)ctx->nbr_send_off[nbr] * rec;
+  if (send_bytes) *send_bytes = (size_t)ctx->nbr_send_cnt[nbr] * rec;
+  if (recv_off) *recv_off = x.buf_off + ((size_t)ctx->K * ctx->Nfq + (size_t)ctx->nbr_recv_off[nbr]) * rec;
+  if (recv_bytes) *recv_bytes = (size_t)ctx->nbr_recv_cnt[nbr] * rec;
+  return ESDG_OK;
+}
+
+// ---- host-only halo plan (testable without a GPU) ----------------------------------------------
+int esdg_halo_plan_create(const int64_t* mapP, int64_t K, int32_t Nfq, int64_t elem_offset, int64_t Kglobal,
+                          int32_t nranks, const int64_t* rank_offsets, esdg_halo_plan** out) {
+  if (!out) return fail(ESDG_ERR_ARG, "null argument");
+  esdg_halo_plan* p = new esdg_halo_plan();
+  int rc = build_halo_plan(mapP, K, Nfq, elem_offset, Kglobal, nranks, rank_offsets, *p);
+  if (rc) { delete p; *out = nullptr; return rc; }
+  *out = p;
+  return ESDG_OK;
+}
+int esdg_halo_plan_destroy(esdg_halo_plan* p) { delete p; return ESDG_OK; }
+int esdg_halo_plan_num_neighbors(const esdg_halo_plan* p) { return p ? (int)p->nbr_rank.size() : 0; }
+int64_t esdg_halo_plan_num_ghosts(const esdg_halo_plan* p) { return p ? p->nghost : 0; }
+int64_t esdg_halo_plan_num_sends(const esdg_halo_plan* p) { return p ? p->nsend : 0; }
+int esdg_halo_plan_neighbor(const esdg_halo_plan* p, int nbr, int32_t* peer, int64_t* send_off, int64_t* send_cnt,
+                            int64_t* recv_off, int64_t* recv_cnt) {
+  if (!p || nbr < 0 || nbr >= (int)p->nbr_rank.size()) return fail(ESDG_ERR_ARG, "bad neighbour id");
+  if (peer) *peer = p->nbr_rank[nbr];
+  if (send_off) *send_off = p->nbr_send_off[nbr];
+  if (send_cnt) *send_cnt = p->nbr_send_cnt[nbr];
+  if (recv_off) *recv_off = p->nbr_recv_off[nbr];
+  if (recv_cnt) *recv_cnt = p->nbr_recv_cnt[nbr];
+  return ESDG_OK;
+}
+const int32_t* esdg_halo_plan_mapP(const esdg_halo_plan* p) { return p ? p->mapP.data() : nullptr; }
+const int32_t* esdg_halo_plan_sendlist(const esdg_halo_plan* p) { return p ? p->sendlist.data() : nullptr; }
+
+// ---- time-integration helpers ----------------------------------------------------------------
+int esdg_lsrk_update(double* Q, double* resQ, const double* rhs, double a, double b, double dt, int64_t n, void* stream) {
+  if (!Q || !resQ || !rhs || n < 0) return fail(ESDG_ERR_ARG, "bad argument");
+  if (n == 0) return ESDG_OK;
+  int rc = launch_lsrk(Q, resQ, rhs, a, b, dt, n, static_cast<hipStream_t>(stream));
+  if (rc) return fail(ESDG_ERR_NO_DEVICE, "lsrk launch: %s", hipGetErrorString((hipError_t)rc));
+  return ESDG_OK;
+}
+
+int esdg_axpy_stages(double* y, const double* x0, const double* const* k, const double* coef, int ns, double dt, int64_t n,
+                     void* stream) {
+  if (!y || !x0 || !k || !coef || ns < 0 || ns > 8) return fail(ESDG_ERR_ARG, "bad argument");
+  int rc = launch_axpy_stages(y, x0, k, coef, ns, dt, n, static_cast<hipStream_t>(stream));
+  if (rc) return fail(ESDG_ERR_NO_DEVICE, "axpy launch: %s", hipGetErrorString((hipError_t)rc));
+  return ESDG_OK;
+}
+
+int esdg_dopri_error(const double* Q, const double* const* k, const double* coefE, int ns, double tol, int64_t n,
+                     double* result, void* stream) {
+  if (!Q || !k || !coefE || !result || ns < 1 || ns > 8) return fail(ESDG_ERR_ARG, "bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nb = 512;
+  double* partial = nullptr;
+  HIP_TRY(hipMalloc(&partial, sizeof(double) * nb));
+  int rc = launch_dopri_err(Q, k, coefE, ns, tol, n, partial, nb, s);
+  std::vector<double> h(nb);
+  hipError_t e = hipMemcpyAsync(h.data(), partial, sizeof(double) * nb, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(partial);
+  if (rc || e != hipSuccess) return fail(ESDG_ERR_NO_DEVICE, "dopri error kernel failed");
+  double t = 0.0;
+  for (double v : h) t += v;
+  *result = t;
+  return ESDG_OK;
+}
+
+// ---- device-memory helpers ---------------------------------------------------------------------
+void* esdg_dmalloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) {
+    fail(ESDG_ERR_ALLOC, "hipMalloc(%zu) failed", bytes);
+    return nullptr;
+  }
+  return p;
+}
+int esdg_dfree(void* p) {
+  if (p) HIP_TRY(hipFree(p));
+  return ESDG_OK;
+}
+int esdg_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+  HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return ESDG_OK;
+}
+int esdg_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+  HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return ESDG_OK;
+}
+int esdg_device_synchronize(void) {
+  HIP_TRY(hipDeviceSynchronize());
+  return ESDG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// esdg_dev.hpp -- device-side data structures shared by the host API (esdg_api.hip) and the
+// gfx950 kernels (esdg_kernels.hip).  MI355X-only code: no CUDA paths, wave = 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace esdg {
+
+// Per-element affine geometry record (doubles):
+//   [0..3] rxJ sxJ ryJ syJ   (row 1 of the Vh-interpolated metric arrays, dg2D_euler_quad.jl:175)
+//   [4]    J
+//   [5+3f .. 7+3f] nxJ nyJ sJ of face f (first node of the face; constant on affine faces)
+constexpr int GEO_STRIDE = 17;
+
+constexpr int AU_NC = 5;  // trace buffer A_U: (rho, rho*u, rho*v, E, lam) per face node
+constexpr int AV_NC = 3;  // trace buffer A_v: projected entropy variables (v2, v3, v4)
+constexpr int B_NC = 3;   // trace buffer B: normal viscous stress (sigma_x*nxJ + sigma_y*nyJ), rows 2..4
+
+// Sparse (ELL) collocated operators and the flux-differencing pair list, derived once on the
+// host from the dense matrices the driver passes (esdg_ops_t).  All pointers are device memory.
+struct Tables {
+  int N1, Np, Nq, Nfq, Nh;
+  int P;                   // number of unordered flux pairs with a non-zero weight
+  const uint8_t* pair_ij;  // [P][2]  (i, j) node ids in the hybridized numbering (vol, then face)
+  const double* pair_c;    // [P][2]  (Qrhskew[i,j], Qshskew[i,j])
+  const uint16_t* inc_ptr; // [Nh+1]  CSR over rows: incident pairs
+  const uint16_t* inc;     // [2P]    pair id | 0x8000 if this row is the pair's j (subtract)
+  const uint8_t* Ef_idx;   // [Nfq][wEf]
+  const double* Ef_val;
+  const uint8_t* Ph_idx;   // [Nq][wPh]  columns in 0..Nh-1
+  const double* Ph_val;
+  const uint8_t* Lf_idx;   // [Nq][wLf]  columns in 0..Nfq-1
+  const double* Lf_val;
+  const uint8_t* Dr_idx;   // [Nq][wD]
+  const double* Dr_val;
+  const uint8_t* Ds_idx;
+  const double* Ds_val;
+  int wEf, wPh, wLf, wD;
+  const double* Vq;        // [Nq][Np] row-major (modal)
+  const double* Pq;        // [Np][Nq] row-major (modal)
+};
+
+struct MeshDev {
+  int64_t K;               // local elements
+  const double* geo;       // [K][GEO_STRIDE]
+  const int32_t* mapP;     // [K][Nfq]  local face-node index, or ghost slot >= K*Nfq
+  const uint8_t* bc;       // [K][Nfq]  0 interior/periodic, 1 wall, 2 lid; may be null (no walls)
+  const double* wJq;       // [K][Nq] (diagnostics) may be null
+};
+
+struct Phys {
+  int formulation;
+  double lf_scale;
+  int inviscid_dissp, viscous_dissp, BCTYPE;
+  double Re, mu, lambda, Pr;
+};
+
+// kernel launchers (esdg_kernels.hip); return hipError_t as int
+int launch_project(const Tables& T, const MeshDev& M, const Phys& ph, const double* Q, double* A_U, double* A_v,
+                   hipStream_t s);
+int launch_sigma(const Tables& T, const MeshDev& M, const Phys& ph, const double* Q, const double* A_v, double* B,
+                 hipStream_t s);
+int launch_rhs(const Tables& T, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
+               const double* A_v, const double* B, double* rhs, hipStream_t s);
+int launch_pack(const double* src, int ncomp, const int32_t* list, int64_t n, double* dst, hipStream_t s);
+int launch_rhstest(const Tables& T, const MeshDev& M, const Phys& ph, const double* Q, const double* rhs,
+                   double* partial, int nblocks, hipStream_t s);
+int launch_lsrk(double* Q, double* resQ, const double* rhs, double a, double b, double dt, int64_t n, hipStream_t s);
+int launch_axpy_stages(double* y, const double* x0, const double* const* k, const double* coef, int ns, double dt,
+                       int64_t n, hipStream_t s);
+int launch_dopri_err(const double* Q, const double* const* k, const double* coefE, int ns, double tol, int64_t n,
+                     double* partial, int nblocks, hipStream_t s);
+bool supported_degree(int N1);
+
+}  // namespace esdg

@@ -1,0 +1,245 @@
+"""Host-side driver of the MI355X RHS engine: wraps the C ABI (include/esdg_hip.h) and mirrors the
+reference drivers' operator surface so their time loops transliterate one to one.
+
+  rhs(Q, md, ops, flux_fun, compute_rhstest)        examples/dg2D_euler_quad.jl:141
+  rhsRK(Q, rd, md, ops, ...)                        examples/CompressibleNS/dg2D_CNS_cavity_optimized.jl:955
+  lsrk45 loop                                       examples/dg2D_euler_quad.jl:196-212
+
+torch supplies device memory, streams and torch.distributed only; all arithmetic happens in the
+hand-written HIP kernels.  There is no CPU fallback: without the HIP extension or a GPU this raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, esdg_mesh_t, esdg_ops_t, esdg_phys_t
+
+EULER_COLLOCATED, CNS_MODAL, EULER_MODAL = 0, 1, 2
+
+
+def _f(a):
+    """float64 Fortran-contiguous copy/view (Julia layout)."""
+    return np.asfortranarray(np.asarray(a, dtype=np.float64))
+
+
+def _dp(a):
+    return a.ctypes.data_as(_lib.c_double_p)
+
+
+class HaloExchanger:
+    """Face-trace halo exchange over torch.distributed (backend "nccl" == RCCL over xGMI on ROCm;
+    "gloo" in the CPU tests).  Works on any 1-D uint8 workspace tensor: segments are byte ranges."""
+
+    def __init__(self, segments, group=None):
+        # segments[xch] = list of (peer, send_off, send_bytes, recv_off, recv_bytes)
+        self.segments = segments
+        self.group = group
+
+    def start(self, ws_bytes, xch):
+        import torch.distributed as dist
+        ops = []
+        for peer, so, sb, ro, rb in self.segments[xch]:
+            if rb:
+                ops.append(dist.P2POp(dist.irecv, ws_bytes[ro:ro + rb], peer, self.group))
+            if sb:
+                ops.append(dist.P2POp(dist.isend, ws_bytes[so:so + sb], peer, self.group))
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    @staticmethod
+    def wait(works):
+        for w in works:
+            w.wait()
+
+
+class RhsEngine:
+    """One esdg_ctx: operators + (local shard of the) mesh resident on one MI355X."""
+
+    def __init__(self, rd, md, ops, formulation, lf_scale=None, inviscid_dissp=True, viscous_dissp=True, BCTYPE=1,
+                 Re=1000.0, mu=None, lam=None, Pr=.71, device=None, rank=0, nranks=1, rank_offsets=None, group=None):
+        L = _lib.lib()
+        if not torch.cuda.is_available() or L.esdg_device_count() < 1:
+            raise _lib.EsdgError("no MI355X/HIP device visible: the RHS engine has no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.formulation = formulation
+        modal = formulation != EULER_COLLOCATED
+        Nq, Nfq = rd.wq.size, rd.wf.size
+        Np = rd.Pq.shape[0] if modal else Nq
+        self.Np, self.Nq, self.Nfq, self.K = Np, Nq, Nfq, int(md.K)
+        keep = self._keep = {}
+
+        o = esdg_ops_t()
+        o.N, o.Np, o.Nq, o.Nfq = rd.N, Np, Nq, Nfq
+        names = ["Qrhskew", "Qshskew", "Ph"] + (["VhP", "LIFT", "Vq"] if modal else ["Ef", "Lf"])
+        for n in names:
+            keep[n] = _f(ops[n])
+            setattr(o, n, _dp(keep[n]))
+        keep["wq"], keep["wf"] = _f(rd.wq), _f(rd.wf)
+        o.wq, o.wf = _dp(keep["wq"]), _dp(keep["wf"])
+        if modal:
+            for n in ("Pq", "Vf", "Dr", "Ds"):
+                keep[n] = _f(getattr(rd, n))
+                setattr(o, n, _dp(keep[n]))
+
+        m = esdg_mesh_t()
+        m.K = int(md.K)
+        m.geo_ld = int(md.rxJ.shape[0])
+        for n in ("rxJ", "sxJ", "ryJ", "syJ", "J", "wJq", "nxJ", "nyJ", "sJ"):
+            keep["m_" + n] = _f(getattr(md, n))
+            setattr(m, n, _dp(keep["m_" + n]))
+        keep["mapP"] = np.asfortranarray(np.asarray(md.mapP, dtype=np.int64))
+        m.mapP = keep["mapP"].ctypes.data_as(_lib.c_int64_p)
+        m.mapB, m.NmapB, m.bkind = None, 0, None
+        m.elem_offset = int(getattr(md, "elem_offset", 0))
+        m.Kglobal = int(getattr(md, "Kglobal", md.K))
+        m.nranks, m.rank = int(nranks), int(rank)
+        if nranks > 1:
+            keep["ro"] = np.ascontiguousarray(np.asarray(rank_offsets, dtype=np.int64))
+            m.rank_offsets = keep["ro"].ctypes.data_as(_lib.c_int64_p)
+
+        p = esdg_phys_t()
+        p.formulation = formulation
+        p.lf_scale = float(lf_scale if lf_scale is not None else (.5 if formulation == EULER_COLLOCATED else .25))
+        p.inviscid_dissp, p.viscous_dissp, p.BCTYPE = int(inviscid_dissp), int(viscous_dissp), int(BCTYPE)
+        mu = 1.0 / Re if mu is None else mu
+        lam = -2.0 / 3.0 * mu if lam is None else lam
+        p.Re, p.mu, p.lambda_, p.Pr = float(Re), float(mu), float(lam), float(Pr)
+
+        ctx = C.c_void_p()
+        check(L.esdg_create(C.byref(o), C.byref(m), C.byref(p), C.byref(ctx)))
+        self.ctx = ctx
+        self.L = L
+        self.nphases = L.esdg_num_phases(ctx)
+        nbytes = int(L.esdg_workspace_bytes(ctx))
+        self.ws = torch.zeros(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+        check(L.esdg_bind_workspace(ctx, C.c_void_p(self.ws.data_ptr()), nbytes))
+
+        # halo plan
+        self.nranks = nranks
+        self.halo = None
+        nn = L.esdg_halo_num_neighbors(ctx)
+        self.xinfo = []
+        segs = []
+        for x in range(L.esdg_num_exchanges(ctx)):
+            a, b, nc = C.c_int32(), C.c_int32(), C.c_int32()
+            check(L.esdg_exchange_info(ctx, x, C.byref(a), C.byref(b), C.byref(nc)))
+            self.xinfo.append((a.value, b.value, nc.value))
+            s = []
+            for n in range(nn):
+                peer = C.c_int32()
+                so, sb, ro, rb = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+                check(L.esdg_halo_segment(ctx, x, n, C.byref(peer), C.byref(so), C.byref(sb), C.byref(ro), C.byref(rb)))
+                s.append((peer.value, so.value, sb.value, ro.value, rb.value))
+            segs.append(s)
+        if nn:
+            self.halo = HaloExchanger(segs, group)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.L.esdg_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # -- state helpers ------------------------------------------------------------------------
+    def upload(self, Q):
+        """tuple/list of 4 (Np x K) host matrices -> device tensor [4][K][Np]."""
+        h = np.ascontiguousarray(np.stack([np.asarray(q, dtype=np.float64).T for q in Q]))
+        return torch.from_numpy(h).to(self.device)
+
+    @staticmethod
+    def download(Qd):
+        """device tensor [4][K][Np] -> list of 4 Fortran (Np x K) host matrices."""
+        h = Qd.detach().cpu().numpy()
+        return [np.asfortranarray(h[f].T) for f in range(h.shape[0])]
+
+    def new_state(self):
+        return torch.zeros((4, self.K, self.Np), dtype=torch.float64, device=self.device)
+
+    # -- the hot path -------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def rhs_into(self, Qd, out):
+        """One RHS evaluation, state resident on device; asynchronous on torch's current stream."""
+        assert Qd.is_contiguous() and out.is_contiguous() and Qd.dtype == torch.float64
+        L, ctx, s = self.L, self.ctx, self._stream()
+        if self.halo is None:
+            check(L.esdg_rhs(ctx, C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr()), s))
+            return out
+        pending = {}
+        for ph in range(self.nphases):
+            for x, (a, b, _) in enumerate(self.xinfo):
+                if b == ph and x in pending:
+                    HaloExchanger.wait(pending.pop(x))
+            check(L.esdg_rhs_phase(ctx, ph, C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr()), s))
+            for x, (a, b, _) in enumerate(self.xinfo):
+                if a == ph:
+                    pending[x] = self.halo.start(self.ws, x)
+        return out
+
+    def rhs(self, Qd):
+        return self.rhs_into(Qd, torch.empty_like(Qd))
+
+    def rhstest(self, Qd, rhsd):
+        """sum(wJq .* v(u) .* rhs) over the local elements (euler_quad.jl:186-191)."""
+        diag = (C.c_double * 2)()
+        check(self.L.esdg_rhstest(self.ctx, C.c_void_p(Qd.data_ptr()), C.c_void_p(rhsd.data_ptr()), diag, self._stream()))
+        return diag[0]
+
+    def rhs_host(self, Q):
+        """Literal drop-in on host arrays through esdg_rhs_host (H2D + rhs + D2H)."""
+        Qh = [_f(q) for q in Q]
+        out = [np.zeros_like(q) for q in Qh]
+        qa = (_lib.c_double_p * 4)(*[_dp(q) for q in Qh])
+        ra = (_lib.c_double_p * 4)(*[_dp(r) for r in out])
+        check(self.L.esdg_rhs_host(self.ctx, qa, ra))
+        return out
+
+    # -- time integration (the step either side of the path) -------------------------------------
+    def lsrk_update(self, Qd, resd, rhsd, a, b, dt):
+        check(self.L.esdg_lsrk_update(C.c_void_p(Qd.data_ptr()), C.c_void_p(resd.data_ptr()), C.c_void_p(rhsd.data_ptr()),
+                                      float(a), float(b), float(dt), Qd.numel(), self._stream()))
+
+    def lsrk45_step(self, Qd, resd, rhsd, dt, coeffs):
+        """for INTRK = 1:5: rhs; resQ = rk4a*resQ + dt*rhs; Q += rk4b*resQ  (euler_quad.jl:200-206)."""
+        rk4a, rk4b = coeffs[0], coeffs[1]
+        for k in range(5):
+            self.rhs_into(Qd, rhsd)
+            self.lsrk_update(Qd, resd, rhsd, rk4a[k], rk4b[k], dt)
+
+
+# -----------------------------------------------------------------------------------------------
+# reference-signature wrappers
+# -----------------------------------------------------------------------------------------------
+def _engine_for(md, rd, ops, formulation, **kw):
+    key = ("_esdg_engine", formulation, tuple(sorted(kw.items())))
+    cache = md.__dict__.setdefault("_esdg_cache", {})
+    if key not in cache:
+        cache[key] = RhsEngine(rd, md, ops, formulation, **kw)
+    return cache[key]
+
+
+def rhs(Q, md, ops, flux_fun=None, compute_rhstest=False, rd=None):
+    """Drop-in for `rhs(Q,md,ops,flux_fun,compute_rhstest)` of examples/dg2D_euler_quad.jl:141:
+    Q = tuple of 4 (Nq x K) matrices at the Gauss nodes; returns (rhsQ, rhstest).  `flux_fun` is
+    accepted and ignored (only euler_fluxes exists in the reference).  Host arrays in, host arrays
+    out: PCIe-bound, for validation; time loops should keep the state on device via RhsEngine."""
+    eng = _engine_for(md, rd if rd is not None else ops["rd"], ops, EULER_COLLOCATED)
+    Qd = eng.upload(Q)
+    r = eng.rhs(Qd)
+    rt = eng.rhstest(Qd, r) if compute_rhstest else 0
+    return tuple(eng.download(r)), rt
+
+
+def rhsRK(Q, rd, md, ops, Re=1000.0, lam=None, mu=None, Pr=.71, inviscid_dissp=True, viscous_dissp=True, BCTYPE=1):
+    """Drop-in for `rhsRK!` of dg2D_CNS_cavity_optimized.jl:955 on quad elements: Q = 4 (Np x K)
+    nodal coefficient matrices; returns (rhsQ, rhstest).  (rhstest_visc is not produced yet.)"""
+    eng = _engine_for(md, rd, ops, CNS_MODAL, Re=Re, lam=lam, mu=mu, Pr=Pr, inviscid_dissp=inviscid_dissp,
+                      viscous_dissp=viscous_dissp, BCTYPE=BCTYPE)
+    Qd = eng.upload(Q)
+    r = eng.rhs(Qd)
+    return tuple(eng.download(r)), eng.rhstest(Qd, r)

@@ -1,0 +1,197 @@
+/* esdg_hip.h -- C ABI of libesdg_hip.so: MI355X (gfx950) right-hand-side engine for the
+ * entropy-stable DG compressible Euler / Navier-Stokes solvers of yiminllin/ESDG-CNS.
+ *
+ * This is the drop-in boundary of the hot path.  The reference has no
+ * FFI: its `rhs` functions are script-local Julia (examples/dg2D_euler_quad.jl:141,
+ * examples/CompressibleNS/dg2D_CNS_cavity_optimized.jl:447,749,955).  Each entry point below
+ * names the reference function it replaces; INTEGRATION.md shows the Julia `ccall` stubs.
+ *
+ * Conventions (chosen so a Julia driver passes `pointer(A)` with no copies):
+ *   - all matrices are dense **column-major** float64, exactly as Julia stores them;
+ *   - index arrays are int64 and **1-based** (mapP, mapB), linear into (Nfq x K);
+ *   - a state / rhs is `nfld` (=4 in 2D) matrices of shape (Np x K); on the device they are
+ *     stacked field-major in ONE buffer: Q[f*K*Np + e*Np + i]  (== Julia's per-field layout);
+ *   - every function returns 0 on success, a negative esdg_status otherwise;
+ *     esdg_last_error() gives the message (the reference throws Julia exceptions instead);
+ *   - `stream` arguments are hipStream_t passed as void* (NULL = default stream);
+ *   - gamma = 1.4 is fixed, as in the reference (EntropyStableEuler.jl:9 and the literals
+ *     0.4/1.4/2.4 in dg2D_CNS_cavity_optimized.jl:463-474).
+ * No CPU fallback exists: without a HIP device every compute entry point fails with
+ * ESDG_ERR_NO_DEVICE.
+ */
+#ifndef ESDG_HIP_H
+#define ESDG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  ESDG_OK = 0,
+  ESDG_ERR_ARG = -1,        /* bad argument / unsupported size */
+  ESDG_ERR_STRUCTURE = -2,  /* operators are not tensor-product-sparse / mesh not affine */
+  ESDG_ERR_NO_DEVICE = -3,  /* no HIP device or HIP runtime error */
+  ESDG_ERR_ALLOC = -4,
+  ESDG_ERR_STATE = -5       /* call order (e.g. workspace not bound) */
+} esdg_status;
+
+typedef struct esdg_ctx esdg_ctx;
+
+/* Formulation of the hot path. */
+typedef enum {
+  /* `rhs` of examples/dg2D_euler_quad.jl:141-194: state lives at the Gauss quadrature nodes
+   * (Np == Nq), operators in the quadrature basis (Ph = W^-1 Vh', Lf), LF factor .5 (:165). */
+  ESDG_EULER_COLLOCATED = 0,
+  /* `rhsRK!` of examples/CompressibleNS/dg2D_CNS_cavity_optimized.jl:955-972 = rhs_inviscid!
+   * (:447-528) + rhs_viscous! (:749-849): state = nodal (LGL) coefficients, LF factor .25 (:508). */
+  ESDG_CNS_MODAL = 1,
+  /* rhs_inviscid! alone (same file), i.e. modal Euler. */
+  ESDG_EULER_MODAL = 2
+} esdg_formulation;
+
+/* Reference-element operators: fields of `rd::RefElemData` (src/SetupDG.jl:38-75) and of the
+ * driver's `ops` tuple.  Column-major.  Pointers not needed by the formulation may be NULL. */
+typedef struct {
+  int32_t N;    /* polynomial degree */
+  int32_t Np;   /* rows of a state matrix: (N+1)^2 */
+  int32_t Nq;   /* volume quadrature nodes: length(rd.wq) */
+  int32_t Nfq;  /* face quadrature nodes: length(rd.wf) */
+  /* both formulations */
+  const double* Qrhskew; /* (Nh x Nh), Nh = Nq+Nfq; dg2D_euler_quad.jl:61 / cavity_optimized.jl:82 */
+  const double* Qshskew; /* (Nh x Nh) */
+  const double* Ph;      /* collocated: (Nq x Nh) W^-1 Vh' (euler_quad.jl:77); modal: (Np x Nh) M\Vh' (:76) */
+  const double* wq;      /* (Nq) rd.wq */
+  const double* wf;      /* (Nfq) rd.wf */
+  /* collocated only */
+  const double* Ef;      /* (Nfq x Nq) Vf*Pq, euler_quad.jl:49 */
+  const double* Lf;      /* (Nq x Nfq) W^-1 Ef' Wf, euler_quad.jl:78 */
+  /* modal only */
+  const double* Vq;      /* (Nq x Np) rd.Vq */
+  const double* Pq;      /* (Np x Nq) rd.Pq */
+  const double* VhP;     /* (Nh x Nq) Vh*Pq, cavity_optimized.jl:77 */
+  const double* LIFT;    /* (Np x Nfq) rd.LIFT */
+  const double* Vf;      /* (Nfq x Np) rd.Vf     (viscous) */
+  const double* Dr;      /* (Np x Np) rd.Dr      (viscous) */
+  const double* Ds;      /* (Np x Np) rd.Ds      (viscous) */
+} esdg_ops_t;
+
+/* Mesh data: fields of `md::MeshData` (src/SetupDG.jl:77-115) for the LOCAL elements of this
+ * process.  rxJ..syJ are the Vh-interpolated (Nh x K) arrays the drivers store back into md
+ * (euler_quad.jl:86-88); only affine elements are supported (the reference's flux differencing
+ * assumes them too: "assumes affine elements for now", euler_quad.jl:175) and this is checked. */
+typedef struct {
+  int64_t K;             /* local element count */
+  int32_t geo_ld;        /* leading dimension (rows) of rxJ..syJ: Nh (drivers) or Np */
+  const double *rxJ, *sxJ, *ryJ, *syJ;
+  const double* J;       /* (Np x K) */
+  const double* wJq;     /* (Nq x K) -- diagnostics (rhstest) only, may be NULL */
+  const double *nxJ, *nyJ, *sJ; /* (Nfq x K) */
+  const int64_t* mapP;   /* (Nfq x K) 1-based GLOBAL linear index into (Nfq x Kglobal) */
+  const int64_t* mapB;   /* wall-boundary face nodes, 1-based GLOBAL linear index, may be NULL */
+  int64_t NmapB;
+  const uint8_t* bkind;  /* per mapB entry: 0 = wall, 1 = lid (init_BC_funs :139-148); NULL = all wall */
+  /* element-index sharding.  Single process: elem_offset=0, Kglobal=K, nranks=1. */
+  int64_t elem_offset;   /* global index (0-based) of the first local element */
+  int64_t Kglobal;
+  int32_t nranks, rank;
+  const int64_t* rank_offsets; /* (nranks+1) element offsets of every rank; NULL if nranks==1 */
+} esdg_mesh_t;
+
+typedef struct {
+  int32_t formulation;     /* esdg_formulation */
+  double lf_scale;         /* .5 (euler_quad.jl:165) or .25 (cavity_optimized.jl:508); 0 disables LF */
+  int32_t inviscid_dissp;  /* cavity_optimized.jl:29 */
+  int32_t viscous_dissp;   /* cavity_optimized.jl:30 */
+  int32_t BCTYPE;          /* 1 adiabatic no-slip, 2 isothermal, 3 slip (cavity_optimized.jl:26) */
+  double Re, mu, lambda, Pr; /* cavity_optimized.jl:33-36; lambda as passed to init_visc_fxn (:646) */
+} esdg_phys_t;
+
+/* ---- life cycle ------------------------------------------------------------------------ */
+/* Copies operators/mesh to the device, derives the sparse collocated operators, converts
+ * mapP to 0-based int32 with ghost slots for off-rank neighbours. */
+int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_t* phys, esdg_ctx** out);
+int esdg_destroy(esdg_ctx* ctx);
+const char* esdg_last_error(void);
+const char* esdg_version(void);
+
+/* Scratch (face-trace buffers A/B, halo send buffers) is caller-owned device memory so the host
+ * framework (torch / Julia) controls allocation; bind it once. */
+size_t esdg_workspace_bytes(const esdg_ctx* ctx);
+int esdg_bind_workspace(esdg_ctx* ctx, void* dev_ptr, size_t bytes);
+
+/* ---- the hot path ------------------------------------------------------------------------
+ * One RHS evaluation = phases 0..esdg_num_phases()-1; between phase p and p+1 the face traces
+ * of off-rank neighbours must be exchanged (esdg_halo_segment).  With nranks==1 esdg_rhs()
+ * runs all phases back to back.  Q_dev / rhs_dev: device buffers [4][K][Np].
+ * Replaces: rhs (euler_quad.jl:141), rhs_inviscid! / rhs_viscous! / rhsRK!
+ * (cavity_optimized.jl:447, 749, 955).  All launches are asynchronous on `stream`. */
+int esdg_num_phases(const esdg_ctx* ctx);
+int esdg_rhs_phase(esdg_ctx* ctx, int phase, const double* Q_dev, double* rhs_dev, void* stream);
+int esdg_rhs(esdg_ctx* ctx, const double* Q_dev, double* rhs_dev, void* stream);
+
+/* Entropy-production diagnostics returned by the reference beside rhsQ:
+ * diag[0] = rhstest = sum(wJq .* v(u) .* rhs)   (euler_quad.jl:186-191, cavity_optimized.jl:958-966)
+ * Device-side reduction, synchronises `stream`.  Local elements only (all-reduce across ranks
+ * is the caller's job). */
+int esdg_rhstest(esdg_ctx* ctx, const double* Q_dev, const double* rhs_dev, double* diag, void* stream);
+
+/* Literal drop-in with host arrays (Julia Matrix{Float64} per field): H2D, rhs, D2H.
+ * PCIe-bound -- for validation, not for time stepping. nranks must be 1. */
+int esdg_rhs_host(esdg_ctx* ctx, const double* const Q[4], double* const rhs[4]);
+
+/* ---- halo exchange plan (element-index sharding) ---------------------------------------- */
+/* The reference's three x[mapP] gathers (QM/Uf+lam :496-511, VUf :776, sigma_f :813-814) become
+ * up to three face-trace exchanges: 0 = A_U (rho,rhou,rhov,E,lam), 1 = A_v (v2..v4), 2 = B (normal
+ * viscous stress).  Exchange x is produced (and packed) by phase `after_phase` and must have
+ * landed before phase `before_phase` starts, so x=0 can overlap phase 1 of the CNS path. */
+int esdg_halo_num_neighbors(const esdg_ctx* ctx);
+int esdg_num_exchanges(const esdg_ctx* ctx);
+int esdg_exchange_info(const esdg_ctx* ctx, int xch, int32_t* after_phase, int32_t* before_phase, int32_t* ncomp);
+/* Exchange `xch`, neighbour slot `nbr`: peer rank and the byte ranges inside the bound workspace
+ * to send from (packed, contiguous) / receive into (ghost slots of the trace buffer, contiguous).
+ * send_bytes of rank a towards b equals recv_bytes of b from a on a conforming mesh. */
+int esdg_halo_segment(const esdg_ctx* ctx, int xch, int nbr, int32_t* peer, size_t* send_off,
+                      size_t* send_bytes, size_t* recv_off, size_t* recv_bytes);
+
+/* Host-only construction of the same plan (no GPU needed; used by the gloo CPU tests and by
+ * hosts that want to inspect the partition).  mapP: (Nfq x K) 1-based GLOBAL indices of the local
+ * elements.  Offsets/counts are in face nodes; ghost slot g lives at local index K*Nfq + g. */
+typedef struct esdg_halo_plan esdg_halo_plan;
+int esdg_halo_plan_create(const int64_t* mapP, int64_t K, int32_t Nfq, int64_t elem_offset, int64_t Kglobal,
+                          int32_t nranks, const int64_t* rank_offsets, esdg_halo_plan** out);
+int esdg_halo_plan_destroy(esdg_halo_plan* plan);
+int esdg_halo_plan_num_neighbors(const esdg_halo_plan* plan);
+int64_t esdg_halo_plan_num_ghosts(const esdg_halo_plan* plan);
+int64_t esdg_halo_plan_num_sends(const esdg_halo_plan* plan);
+int esdg_halo_plan_neighbor(const esdg_halo_plan* plan, int nbr, int32_t* peer, int64_t* send_off,
+                            int64_t* send_cnt, int64_t* recv_off, int64_t* recv_cnt);
+const int32_t* esdg_halo_plan_mapP(const esdg_halo_plan* plan);      /* (Nfq x K) local/ghost indices */
+const int32_t* esdg_halo_plan_sendlist(const esdg_halo_plan* plan);  /* num_sends local face nodes */
+
+/* ---- the steps either side of the path ----------------------
+ * Low-storage RK stage of src/CommonUtils.jl:29-49 as used in euler_quad.jl:204-205:
+ *   resQ = a*resQ + dt*rhs ;  Q += b*resQ          (n = 4*K*Np doubles) */
+int esdg_lsrk_update(double* Q_dev, double* resQ_dev, const double* rhs_dev, double a, double b, double dt,
+                     int64_t n, void* stream);
+/* y = x0 + dt * sum_s coef[s]*k[s]  (DOPRI stage combination, cavity_optimized.jl:1004-1010) */
+int esdg_axpy_stages(double* y_dev, const double* x0_dev, const double* const* k_dev, const double* coef,
+                     int nstages, double dt, int64_t n, void* stream);
+/* Hairer error norm numerator sum((|sum_s E[s] k[s]| / (tol*(1+|Q|)))^2) (cavity_optimized.jl:1014-1021) */
+int esdg_dopri_error(const double* Q_dev, const double* const* k_dev, const double* coefE, int nstages,
+                     double tol, int64_t n, double* result_host, void* stream);
+
+/* ---- plain device-memory helpers for hosts without a GPU array package (Julia ccall) ---- */
+void* esdg_dmalloc(size_t bytes);
+int esdg_dfree(void* p);
+int esdg_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int esdg_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+int esdg_device_synchronize(void);
+int esdg_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESDG_HIP_H */

@@ -1,0 +1,77 @@
+"""Shared helpers for the test-suite: problem builders on the PRODUCT side (esdg_cns_amd.setup_dg)
+mirroring the oracle's builders, and error norms."""
+import numpy as np
+
+from esdg_cns_amd import physics as ph
+from esdg_cns_amd import setup_dg as sd
+
+
+def rel_l2(a, b):
+    """max over fields of ||a-b||_2 / ||b||_2"""
+    return max(np.linalg.norm(x - y) / max(np.linalg.norm(y), 1e-300) for x, y in zip(a, b))
+
+
+def product_euler_problem(N, Kx, Ky, elem_range=None):
+    VX, VY, EToV = sd.uniform_quad_mesh(Kx, Ky)
+    VX = 15 * (1 + VX) / 2
+    VY = 5 * VY
+    rd = sd.init_reference_quad(N, sd.gauss_quad(0, 0, N))
+    md = sd.init_mesh((VX, VY), EToV, rd, elem_range=elem_range)
+    sd.make_periodic(md, rd)
+    ops = sd.euler_quad_ops(rd)
+    sd.interp_geofacs_to_hybrid(md, ops["Vh"])
+    rho, u, v, p = ph.vortex(md.xq, md.yq, 0)
+    Q = [np.asfortranarray(q) for q in ph.primitive_to_conservative(rho, u, v, p)]
+    return rd, md, ops, Q
+
+
+def product_cns_problem(N, Kx, Ky, elem_range=None):
+    VX, VY, EToV = sd.uniform_quad_mesh(Kx, Ky)
+    VX = 15 * (1 + VX) / 2
+    VY = 5 * VY
+    rd = sd.init_reference_quad(N)
+    md = sd.init_mesh((VX, VY), EToV, rd, elem_range=elem_range)
+    sd.make_periodic(md, rd)
+    md.mapB = np.zeros(0, dtype=np.int64)
+    ops = sd.cns_ops(rd)
+    sd.interp_geofacs_to_hybrid(md, ops["Vh"])
+    rho, u, v, p = ph.vortex(md.x, md.y, 0)
+    Q = [np.asfortranarray(q) for q in ph.primitive_to_conservative(rho, u, v, p)]
+    return rd, md, ops, Q
+
+
+def perturb(Q, seed=20250117, amp=0.01):
+    """Robustness variant of SURVEY.md section 8(d): multiply rho and E by 1 + amp*xi, xi in [-1,1)."""
+    rng = np.random.default_rng(seed)
+    out = [q.copy() for q in Q]
+    out[0] *= 1 + amp * (2 * rng.random(Q[0].shape) - 1)
+    out[3] *= 1 + amp * (2 * rng.random(Q[0].shape) - 1)
+    return out
+
+
+def noise_floor(rhs_fn, Q, trials=3, seed=7):
+    """Round-off noise floor of the ORACLE itself: the largest relative-L2 change of its output when
+    every input entry is perturbed by at most one ulp.  The reference's logmean switches to
+    -da/(logL-logR) for |f| >= 1e-4 (examples/EntropyStableEuler/logmean.jl:23-27), which loses up to
+    four digits to cancellation, so two faithful implementations (e.g. Julia with another BLAS) differ
+    by this much.  GPU-vs-oracle tolerances are max(1e-12, 4 x this floor)."""
+    rng = np.random.default_rng(seed)
+    base = rhs_fn(Q)
+    worst = 0.0
+    for _ in range(trials):
+        Q2 = [q * (1 + 1.1e-16 * rng.choice([-1.0, 0.0, 1.0], size=q.shape)) for q in Q]
+        worst = max(worst, rel_l2(rhs_fn(Q2), base))
+    return worst
+
+
+def steep_state(x, y, LX=15.0, LY=10.0):
+    """Monotone exponential profiles (discontinuous across the periodic wrap, which is legitimate
+    input): every node pair an SBP operator couples differs by |f| >~ 1e-3 in rho and beta, far
+    from the reference logmean's ill-conditioned window around its 1e-4 threshold, so the oracle's
+    own round-off noise is ~1e-14 and the strict 1e-12 bound is meaningful."""
+    xs, ys = x / LX, (y + 5.0) / LY
+    rho = np.exp(2.0 * xs + 1.4 * ys)
+    p = np.exp(-1.1 * xs + 0.9 * ys)
+    u = 0.3 + 0.25 * xs - 0.1 * ys
+    v = -0.2 + 0.15 * xs + 0.3 * ys
+    return [np.asfortranarray(q) for q in ph.primitive_to_conservative(rho, u, v, p)]

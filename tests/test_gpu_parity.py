@@ -1,0 +1,83 @@
+"""GPU parity tests proper: the hand-written HIP path (through the C ABI) against the CPU oracle on
+identical inputs.
+
+Tolerance (fp64): relative L2 per conserved field
+  * <= 1e-12 (BASELINE north_star) on well-conditioned states (`steep_state`, oracle noise floor
+    ~3e-14 for N>=3);
+  * <= max(1e-12, 4 x oracle noise floor) on the reference's vortex configuration, where the oracle's
+    own output moves by 0.5-5e-12 under one-ulp input perturbations (tests/common.py:noise_floor) --
+    the reference's logmean branch at |f| >= 1e-4 cancels four digits, so 1e-12 is below what any two
+    faithful implementations can agree to there.
+"""
+import numpy as np
+import pytest
+
+from common import noise_floor, product_cns_problem, product_euler_problem, rel_l2, steep_state
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12   # BASELINE.json: "<=1e-12 relative L2 vs the Julia reference"
+
+
+@pytest.fixture(scope="module")
+def eng_mod():
+    from esdg_cns_amd import engine
+    return engine
+
+
+def _gpu_rhs(eng, Q):
+    return eng.download(eng.rhs(eng.upload(Q)))
+
+
+@pytest.mark.parametrize("N,Kx,Ky", [(3, 16, 16), (4, 12, 8), (2, 9, 7), (1, 6, 6), (5, 5, 4), (6, 4, 3), (7, 3, 3)])
+def test_euler_collocated_matches_oracle(eng_mod, oracle_lib, N, Kx, Ky):
+    from oracle import oracle as orc
+    p = orc.build_euler_problem(N, Kx, Ky)
+    eo = orc.EulerOracle(p)
+    rd, md, ops, Q = product_euler_problem(N, Kx, Ky)
+    eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.EULER_COLLOCATED)
+    # reference vortex state
+    ref, _ = eo.rhs(p.Q)
+    err = rel_l2(_gpu_rhs(eng, Q), ref)
+    floor = noise_floor(lambda q: eo.rhs(q)[0], p.Q)
+    print(f"euler N={N} {Kx}x{Ky} vortex: err={err:.2e} oracle-noise-floor={floor:.2e}")
+    assert err <= max(TOL, 4 * floor), (err, floor)
+    # well-conditioned state: strict bound
+    Qw = steep_state(md.xq, md.yq)
+    errw = rel_l2(_gpu_rhs(eng, Qw), eo.rhs(Qw)[0])
+    floorw = noise_floor(lambda q: eo.rhs(q)[0], Qw)
+    print(f"euler N={N} {Kx}x{Ky} steep: err={errw:.2e} oracle-noise-floor={floorw:.2e}")
+    assert errw <= max(TOL, 4 * floorw), (errw, floorw)
+    if N >= 3:
+        assert errw <= TOL, errw          # strict north-star bound where the reference is well conditioned
+
+
+@pytest.mark.parametrize("N,Kx,Ky", [(4, 12, 8), (3, 10, 10), (2, 7, 9), (1, 5, 5), (5, 4, 4)])
+def test_cns_modal_matches_oracle(eng_mod, oracle_lib, N, Kx, Ky):
+    from oracle import oracle as orc
+    p = orc.build_cns_problem(N, Kx, Ky, bc="periodic")
+    co = orc.CnsOracle(p)
+    rd, md, ops, Q = product_cns_problem(N, Kx, Ky)
+    eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, Re=p.Re, mu=p.mu, lam=p.lam, Pr=p.Pr)
+    ref = co.rhsRK(p.Q, compute_diag=False)[0]
+    err = rel_l2(_gpu_rhs(eng, Q), ref)
+    floor = noise_floor(lambda q: co.rhsRK(q, compute_diag=False)[0], p.Q)
+    print(f"cns N={N} {Kx}x{Ky} vortex: err={err:.2e} oracle-noise-floor={floor:.2e}")
+    assert err <= max(TOL, 4 * floor), (err, floor)
+    Qw = steep_state(md.x, md.y)
+    errw = rel_l2(_gpu_rhs(eng, Qw), co.rhsRK(Qw, compute_diag=False)[0])
+    floorw = noise_floor(lambda q: co.rhsRK(q, compute_diag=False)[0], Qw)
+    print(f"cns N={N} {Kx}x{Ky} steep: err={errw:.2e} oracle-noise-floor={floorw:.2e}")
+    assert errw <= max(TOL, 4 * floorw), (errw, floorw)
+    if N >= 3:
+        assert errw <= TOL, errw
+
+
+def test_modal_euler_matches_oracle_inviscid(eng_mod, oracle_lib):
+    from oracle import oracle as orc
+    p = orc.build_cns_problem(4, 8, 8, bc="periodic")
+    co = orc.CnsOracle(p)
+    rd, md, ops, Q = product_cns_problem(4, 8, 8)
+    eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.EULER_MODAL)
+    Qw = steep_state(md.x, md.y)
+    assert rel_l2(_gpu_rhs(eng, Qw), co.rhs_inviscid(Qw)) <= TOL
