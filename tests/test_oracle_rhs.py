@@ -1,0 +1,109 @@
+"""Pins the full-RHS ORACLE (CPU): the loop-structured C restatement (oracle/oracle_rhs.c) against the
+independent vectorised numpy restatement (oracle/ref_rhs_numpy.py), against the committed golden
+vectors, and against the invariants that pin the reference scheme: free-stream
+preservation, conservation, entropy conservation with the LF penalty off, entropy dissipation with it
+on, dissipativity of the viscous terms."""
+import os
+
+import numpy as np
+import pytest
+
+from common import noise_floor, rel_l2, steep_state
+from oracle import oracle as orc
+from oracle import ref_physics as ph
+from oracle import ref_rhs_numpy as rr
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("N,Kx,Ky", [(3, 8, 8), (2, 5, 4), (4, 4, 4)])
+def test_euler_c_vs_numpy(oracle_lib, N, Kx, Ky):
+    p = orc.build_euler_problem(N, Kx, Ky)
+    eo = orc.EulerOracle(p)
+    a, ta = rr.euler_rhs(p.Q, p.md, p.ops, True)
+    b, tb = eo.rhs(p.Q, .5, True)
+    floor = noise_floor(lambda q: eo.rhs(q)[0], p.Q)
+    assert rel_l2(a, b) <= max(1e-12, 4 * floor)
+    assert abs(ta - tb) < 1e-11 * max(1, abs(tb))
+    Qs = steep_state(p.md.xq, p.md.yq)
+    assert rel_l2(rr.euler_rhs(Qs, p.md, p.ops)[0], eo.rhs(Qs)[0]) <= 1e-12
+
+
+@pytest.mark.parametrize("bc,BCTYPE", [("periodic", 1), ("cavity", 1), ("cavity", 2), ("cavity", 3)])
+def test_cns_c_vs_numpy(oracle_lib, bc, BCTYPE):
+    p = orc.build_cns_problem(3, 5, 5, bc=bc, BCTYPE=BCTYPE)
+    co = orc.CnsOracle(p)
+    bcf = rr.BCFuns(p.md, BCTYPE)
+    a, t1, t2 = rr.rhsRK(p.Q, p.rd, p.md, p.ops, bcf, p.Re, p.lam, p.mu, p.Pr)
+    b, s1, s2 = co.rhsRK(p.Q)
+    floor = noise_floor(lambda q: co.rhsRK(q, False)[0], p.Q)
+    assert rel_l2(a, b) <= max(1e-12, 4 * floor), (rel_l2(a, b), floor)
+    assert abs(t1 - s1) <= 1e-9 * max(1.0, abs(s1)) and abs(t2 - s2) <= 1e-9 * max(1.0, abs(s2))
+    av, _ = rr.rhs_viscous(p.Q, p.md, p.rd, bcf, p.Re, p.lam, p.mu, p.Pr)
+    bv, _ = co.rhs_viscous(p.Q)
+    assert rel_l2(av[1:], bv[1:]) <= 1e-11 and np.abs(bv[0]).max() == 0.0
+
+
+def test_golden_vectors(oracle_lib):
+    g = np.load(os.path.join(GOLD, "rhs_euler_N2_3x3.npz"))
+    p = orc.build_euler_problem(2, 3, 3)
+    assert np.array_equal(np.stack(p.Q), g["Q"])
+    out, rt = orc.EulerOracle(p).rhs(p.Q, .5, True)
+    assert np.allclose(np.stack(out), g["rhs"], rtol=0, atol=1e-12) and abs(rt - g["rhstest"]) < 1e-12
+    g = np.load(os.path.join(GOLD, "rhs_cns_N2_3x3.npz"))
+    p = orc.build_cns_problem(2, 3, 3, bc="periodic")
+    out, rt, rtv = orc.CnsOracle(p).rhsRK(p.Q)
+    assert np.allclose(np.stack(out), g["rhs"], rtol=0, atol=1e-12)
+    assert abs(rt - g["rhstest"]) < 1e-12 and abs(rtv - g["rhstest_visc"]) < 1e-12
+
+
+def _const_state(shape):
+    one = np.ones(shape)
+    return [np.asfortranarray(q) for q in ph.primitive_to_conservative(1.1 * one, .3 * one, -.2 * one, .9 * one)]
+
+
+def test_free_stream_and_conservation_euler(oracle_lib):
+    p = orc.build_euler_problem(3, 6, 5)
+    eo = orc.EulerOracle(p)
+    r, _ = eo.rhs(_const_state(p.Q[0].shape))
+    assert max(np.abs(x).max() for x in r) < 1e-12                     # invariant (2)
+    r, _ = eo.rhs(p.Q)
+    assert max(abs(np.sum(p.md.wJq * x)) for x in r) < 1e-11           # invariant (4)
+
+
+def test_entropy_conservation_and_dissipation_euler(oracle_lib):
+    p = orc.build_euler_problem(3, 6, 5)
+    eo = orc.EulerOracle(p)
+    _, rt0 = eo.rhs(p.Q, 0.0, True)        # LF off: entropy conservative, dg2D_euler_quad.jl:186-191
+    _, rt1 = eo.rhs(p.Q, 0.5, True)
+    assert abs(rt0) < 1e-12 and rt1 < -1e-6                            # invariant (3)
+
+
+def test_cns_invariants(oracle_lib):
+    p = orc.build_cns_problem(3, 5, 4, bc="periodic")
+    co = orc.CnsOracle(p)
+    r, _, _ = co.rhsRK(_const_state(p.Q[0].shape))
+    assert max(np.abs(x).max() for x in r) < 1e-11
+    r, rt, rtv = co.rhsRK(p.Q)
+    Vq = p.rd.Vq
+    # conservation holds without the entropy-variable jump penalty; the reference's penalty
+    # tau*[[v]] uses the one-sided tau = -1/(Re*v4^-) and no sJ/J scaling (quirk Q3), so it is not conservative
+    rc = orc.CnsOracle(p, viscous_dissp=False).rhsRK(p.Q, False)[0]
+    assert max(abs(np.sum(p.md.wJq * (Vq @ x))) for x in rc) < 1e-11
+    ec = orc.CnsOracle(p, inviscid_dissp=False, viscous_dissp=True)
+    inv = ec.rhs_inviscid(p.Q)
+    VU = ph.v_ufun(*[Vq @ q for q in p.Q])
+    assert abs(sum(np.sum(p.md.wJq * v * (Vq @ x)) for v, x in zip(VU, inv))) < 1e-12   # EC without LF
+    assert rt < 0 and rtv < 1e-12                                      # invariant (6): dissipative
+
+
+def test_omp_threads_do_not_change_results(oracle_lib):
+    p = orc.build_cns_problem(2, 6, 6, bc="periodic")
+    co = orc.CnsOracle(p)
+    a = co.rhsRK(p.Q, False)[0]
+    orc.lib().oracle_set_threads(4)
+    try:
+        b = co.rhsRK(p.Q, False)[0]
+    finally:
+        orc.lib().oracle_set_threads(1)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
