@@ -43,6 +43,7 @@ SYMBOLS = {
     "esdg_workspace_bytes": (C.c_size_t, [_vp]),
     "esdg_bind_workspace": (C.c_int, [_vp, _vp, C.c_size_t]),
     "esdg_num_phases": (C.c_int, [_vp]),
+    "esdg_uses_tensor_kernels": (C.c_int, [_vp]),
     "esdg_rhs_phase": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "esdg_rhs": (C.c_int, [_vp, _vp, _vp, _vp]),
     "esdg_rhstest": (C.c_int, [_vp, _vp, _vp, c_double_p, _vp]),

@@ -3,7 +3,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["csrc/esdg_kernels.hip", "csrc/esdg_api.hip"]
+SOURCES = ["csrc/esdg_kernels.hip", "csrc/esdg_kernels_fast.hip", "csrc/esdg_api.hip"]
 HEADERS = ["csrc/esdg_dev.hpp", "../include/esdg_hip.h"]
 OUT = os.path.join(HERE, "libesdg_hip.so")
 

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -129,6 +130,138 @@ struct Exchange {
   size_t send_off;  // byte offset of the packed send buffer in the workspace
 };
 
+// Host image of FastTables (esdg_dev.hpp).  build_fast_host() returns false when the operators do
+// not have the tensor-line structure; the generic kernels are used then.
+struct FastHost {
+  int NF = 0;
+  std::vector<uint8_t> fwd_id, bwd_src, face_id, fr_dir, fr_src, fr_slot, pl_fn;
+  std::vector<double> fwd_c, face_c, pl_ph, pl_lf, ph_diag, Iq, Ip;
+};
+
+bool build_fast_host(int N1, const Mat& Qr, const Mat& Qs, const Mat& PhC, const Mat& LfC, const Mat* Vq, const Mat* Pq,
+                     FastHost& F) {
+  const int Nq = N1 * N1, Nfq = 4 * N1, Nh = Nq + Nfq, NF = N1 / 2;
+  F.NF = NF;
+  auto nz = [](double x) { return std::fabs(x) > DROPTOL; };
+  // direction of every coupled pair; a pair carrying both a Qr and a Qs weight is not tensor-line
+  std::vector<std::vector<int>> vol[2], fac[2];
+  for (int d = 0; d < 2; ++d) { vol[d].assign(Nq, {}); fac[d].assign(Nq, {}); }
+  std::vector<int> fdir(Nfq, -1);
+  std::vector<std::vector<int>> fsrc(Nfq);
+  for (int i = 0; i < Nq; ++i)
+    for (int j = 0; j < Nh; ++j) {
+      if (i == j) continue;
+      const bool a = nz(Qr(i, j)), b = nz(Qs(i, j));
+      if (!a && !b) continue;
+      if (a && b) return false;
+      const int d = a ? 0 : 1;
+      if (j < Nq) vol[d][i].push_back(j);
+      else {
+        fac[d][i].push_back(j - Nq);
+        if (fdir[j - Nq] >= 0 && fdir[j - Nq] != d) return false;
+        fdir[j - Nq] = d;
+        fsrc[j - Nq].push_back(i);
+      }
+    }
+  F.fwd_id.assign((size_t)2 * Nq * NF, 0xFF);
+  F.bwd_src.assign((size_t)2 * Nq * NF, 0xFF);
+  F.fwd_c.assign((size_t)2 * Nq * NF * 2, 0.0);
+  F.face_id.assign((size_t)2 * Nq * 2, 0);
+  F.face_c.assign((size_t)2 * Nq * 2 * 2, 0.0);
+  for (int d = 0; d < 2; ++d)
+    for (int q = 0; q < Nq; ++q) {
+      if ((int)vol[d][q].size() != N1 - 1 || (int)fac[d][q].size() != 2) return false;
+      std::vector<int> line = vol[d][q];
+      line.push_back(q);
+      std::sort(line.begin(), line.end());
+      std::vector<int> faces = fac[d][q];
+      std::sort(faces.begin(), faces.end());
+      for (int p : line) {  // clique + same two faces for every node of the line
+        std::vector<int> lp = vol[d][p];
+        lp.push_back(p);
+        std::sort(lp.begin(), lp.end());
+        std::vector<int> fp = fac[d][p];
+        std::sort(fp.begin(), fp.end());
+        if (lp != line || fp != faces) return false;
+      }
+      const int pos = (int)(std::find(line.begin(), line.end(), q) - line.begin());
+      const size_t base = (size_t)d * Nq + q;
+      for (int k = 0; k < NF; ++k) {
+        const int o = k + 1;
+        const bool half = (N1 % 2 == 0) && (o == N1 / 2);
+        if (!(half && pos >= N1 / 2)) {
+          const int p = line[(pos + o) % N1];
+          F.fwd_id[base * NF + k] = (uint8_t)p;
+          F.fwd_c[(base * NF + k) * 2 + 0] = Qr(q, p);
+          F.fwd_c[(base * NF + k) * 2 + 1] = Qs(q, p);
+        }
+        const int sp = (pos - o + N1) % N1;
+        if (!(half && sp >= N1 / 2)) F.bwd_src[base * NF + k] = (uint8_t)line[sp];
+      }
+      for (int t = 0; t < 2; ++t) {
+        F.face_id[base * 2 + t] = (uint8_t)faces[t];
+        F.face_c[(base * 2 + t) * 2 + 0] = Qr(q, Nq + faces[t]);
+        F.face_c[(base * 2 + t) * 2 + 1] = Qs(q, Nq + faces[t]);
+      }
+    }
+  F.fr_dir.assign(Nfq, 0);
+  F.fr_src.assign((size_t)Nfq * N1, 0);
+  F.fr_slot.assign(Nfq, 0);
+  for (int f = 0; f < Nfq; ++f) {
+    if (fdir[f] < 0 || (int)fsrc[f].size() != N1) return false;
+    const int d = fdir[f];
+    std::sort(fsrc[f].begin(), fsrc[f].end());
+    F.fr_dir[f] = (uint8_t)d;
+    const int q0 = fsrc[f][0];
+    const size_t base = (size_t)d * Nq + q0;
+    const int slot = F.face_id[base * 2 + 0] == f ? 0 : 1;
+    if (F.face_id[base * 2 + slot] != f) return false;
+    F.fr_slot[f] = (uint8_t)slot;
+    for (int j = 0; j < N1; ++j) F.fr_src[(size_t)f * N1 + j] = (uint8_t)fsrc[f][j];
+  }
+  // collocated projection / lift: diagonal volume block + at most 4 face entries per node
+  F.pl_fn.assign((size_t)Nq * 4, 0);
+  F.pl_ph.assign((size_t)Nq * 4, 0.0);
+  F.pl_lf.assign((size_t)Nq * 4, 0.0);
+  F.ph_diag.assign(Nq, 0.0);
+  for (int q = 0; q < Nq; ++q) {
+    for (int j = 0; j < Nq; ++j)
+      if (j != q && nz(PhC(q, j))) return false;
+    F.ph_diag[q] = PhC(q, q);
+    int t = 0;
+    for (int f = 0; f < Nfq; ++f)
+      if (nz(PhC(q, Nq + f)) || nz(LfC(q, f))) {
+        if (t == 4) return false;
+        F.pl_fn[(size_t)q * 4 + t] = (uint8_t)f;
+        F.pl_ph[(size_t)q * 4 + t] = PhC(q, Nq + f);
+        F.pl_lf[(size_t)q * 4 + t] = LfC(q, f);
+        ++t;
+      }
+  }
+  // 1D factors of Vq, Pq (modal): Vq[(a+N1 b),(i+N1 j)] = Iq[b,i] Iq[a,j], rows of Iq sum to one
+  F.Iq.assign((size_t)N1 * N1, 0.0);
+  F.Ip.assign((size_t)N1 * N1, 0.0);
+  if (Vq && Pq) {
+    for (int a = 0; a < N1; ++a)
+      for (int j = 0; j < N1; ++j) {
+        double s = 0.0, t = 0.0;
+        for (int i = 0; i < N1; ++i) s += (*Vq)(a + N1 * 0, i + N1 * j);
+        for (int b = 0; b < N1; ++b) t += (*Pq)(0 + N1 * a, j + N1 * b);  // Ip[a_row=j_nodal, col=quad a]: see below
+        F.Iq[(size_t)a * N1 + j] = s;
+        F.Ip[(size_t)a * N1 + j] = t;
+      }
+    // Pq[(i+N1 j),(a+N1 b)] = Ip[i,b] Ip[j,a]; summing over b at i=0 gives Ip[j,a]: stored above as Ip[j=a_loop][a=j_loop]
+    for (int a = 0; a < N1; ++a)
+      for (int b = 0; b < N1; ++b)
+        for (int i = 0; i < N1; ++i)
+          for (int j = 0; j < N1; ++j) {
+            if (std::fabs((*Vq)(a + N1 * b, i + N1 * j) - F.Iq[(size_t)b * N1 + i] * F.Iq[(size_t)a * N1 + j]) > 1e-11) return false;
+            if (std::fabs((*Pq)(i + N1 * j, a + N1 * b) - F.Ip[(size_t)i * N1 + b] * F.Ip[(size_t)j * N1 + a]) > 1e-11) return false;
+          }
+  }
+  return true;
+}
+
 }  // namespace
 
 // Halo plan for element-index sharding: pure host logic, no device needed.
@@ -208,6 +341,9 @@ int build_halo_plan(const int64_t* mapP_g, int64_t K, int Nfq, int64_t e_lo, int
 
 struct esdg_ctx {
   Tables T{};
+  FastTables F{};
+  bool use_fast = false;
+  int au_nc = AU_NC;
   MeshDev M{};
   Phys ph{};
   int nphases = 2;
@@ -216,6 +352,8 @@ struct esdg_ctx {
   // device storage
   DevBuf d_pair_ij, d_pair_c, d_inc_ptr, d_inc, d_Ef_i, d_Ef_v, d_Ph_i, d_Ph_v, d_Lf_i, d_Lf_v, d_Dr_i, d_Dr_v, d_Ds_i,
       d_Ds_v, d_Vq, d_Pq, d_geo, d_mapP, d_bc, d_wJq, d_sendlist, d_partial;
+  DevBuf f_fwd_id, f_fwd_c, f_bwd_src, f_face_id, f_face_c, f_fr_dir, f_fr_src, f_fr_slot, f_pl_fn, f_pl_ph, f_pl_lf,
+      f_ph_diag, f_Iq, f_Ip;
   // halo plan
   std::vector<int32_t> nbr_rank;
   std::vector<int64_t> nbr_send_off, nbr_send_cnt, nbr_recv_off, nbr_recv_cnt;  // in face nodes
@@ -351,6 +489,15 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
     inc.insert(inc.end(), rows[i].begin(), rows[i].end());
   }
 
+  // ---- tensor-line schedule of the fast path (falls back to the generic kernels if absent) ----
+  FastHost fh;
+  bool use_fast = build_fast_host(N1, Qr, Qs, PhC, LfC, modal ? &Vq : nullptr, modal ? &Pq : nullptr, fh) &&
+                  eEf.w == N1 && (!visc || eDr.w == N1);
+  if (const char* env = getenv("ESDG_FORCE_GENERIC"))
+    if (env[0] == '1') use_fast = false;
+  c->use_fast = use_fast;
+  c->au_nc = use_fast ? FAU_NC : AU_NC;
+
   // ---- geometry: affine check + per-element records ---------------------------------------
   const int64_t K = mesh->K;
   const int ld = mesh->geo_ld > 0 ? mesh->geo_ld : Nh;
@@ -404,6 +551,19 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   UP(d_Dr_i, eDr.idx); UP(d_Dr_v, eDr.val); UP(d_Ds_i, eDs.idx); UP(d_Ds_v, eDs.val);
   UP(d_Vq, Vq.a); UP(d_Pq, Pq.a);
   UP(d_geo, geo); UP(d_mapP, mapP); UP(d_sendlist, sendlist);
+  if (use_fast) {
+    UP(f_fwd_id, fh.fwd_id); UP(f_fwd_c, fh.fwd_c); UP(f_bwd_src, fh.bwd_src); UP(f_face_id, fh.face_id);
+    UP(f_face_c, fh.face_c); UP(f_fr_dir, fh.fr_dir); UP(f_fr_src, fh.fr_src); UP(f_fr_slot, fh.fr_slot);
+    UP(f_pl_fn, fh.pl_fn); UP(f_pl_ph, fh.pl_ph); UP(f_pl_lf, fh.pl_lf); UP(f_ph_diag, fh.ph_diag);
+    UP(f_Iq, fh.Iq); UP(f_Ip, fh.Ip);
+    FastTables& F = c->F;
+    F.NF = fh.NF;
+    F.fwd_id = c->f_fwd_id.as<uint8_t>(); F.fwd_c = c->f_fwd_c.as<double>(); F.bwd_src = c->f_bwd_src.as<uint8_t>();
+    F.face_id = c->f_face_id.as<uint8_t>(); F.face_c = c->f_face_c.as<double>();
+    F.fr_dir = c->f_fr_dir.as<uint8_t>(); F.fr_src = c->f_fr_src.as<uint8_t>(); F.fr_slot = c->f_fr_slot.as<uint8_t>();
+    F.pl_fn = c->f_pl_fn.as<uint8_t>(); F.pl_ph = c->f_pl_ph.as<double>(); F.pl_lf = c->f_pl_lf.as<double>();
+    F.ph_diag = c->f_ph_diag.as<double>(); F.Iq = c->f_Iq.as<double>(); F.Ip = c->f_Ip.as<double>();
+  }
   if (mesh->wJq) {
     std::vector<double> w(mesh->wJq, mesh->wJq + (size_t)K * Nq);
     UP(d_wJq, w);
@@ -428,13 +588,13 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t nodes = (size_t)(K * Nfq + c->nghost);
   size_t off = 0;
-  c->off_AU = off; off = align(off + nodes * AU_NC * sizeof(double));
+  c->off_AU = off; off = align(off + nodes * c->au_nc * sizeof(double));
   if (visc) {
     c->off_Av = off; off = align(off + nodes * AV_NC * sizeof(double));
     c->off_B = off; off = align(off + nodes * B_NC * sizeof(double));
   }
-  Exchange x0{0, c->nphases - 1, AU_NC, c->off_AU, off};
-  off = align(off + (size_t)c->nsend * AU_NC * sizeof(double));
+  Exchange x0{0, c->nphases - 1, c->au_nc, c->off_AU, off};
+  off = align(off + (size_t)c->nsend * c->au_nc * sizeof(double));
   c->xch.push_back(x0);
   if (visc) {
     Exchange x1{0, 1, AV_NC, c->off_Av, off};
@@ -466,6 +626,7 @@ int esdg_bind_workspace(esdg_ctx* ctx, void* dev_ptr, size_t bytes) {
 }
 
 int esdg_num_phases(const esdg_ctx* ctx) { return ctx ? ctx->nphases : 0; }
+int esdg_uses_tensor_kernels(const esdg_ctx* ctx) { return ctx ? (int)ctx->use_fast : 0; }
 
 int esdg_rhs_phase(esdg_ctx* ctx, int phase, const double* Q, double* rhs, void* stream) {
   if (!ctx || !Q) return fail(ESDG_ERR_ARG, "null argument");
@@ -479,17 +640,20 @@ int esdg_rhs_phase(esdg_ctx* ctx, int phase, const double* Q, double* rhs, void*
   int rc = 0;
   const int32_t* sl = ctx->d_sendlist.as<int32_t>();
   if (phase == 0) {
-    rc = launch_project(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, s);
+    rc = ctx->use_fast ? launch_project_fast(ctx->T, ctx->F, ctx->M, ctx->ph, Q, A_U, A_v, s)
+                       : launch_project(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, s);
     if (!rc && ctx->nsend) {
-      rc = launch_pack(A_U, AU_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[0].send_off), s);
+      rc = launch_pack(A_U, ctx->au_nc, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[0].send_off), s);
       if (!rc && visc) rc = launch_pack(A_v, AV_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[1].send_off), s);
     }
   } else if (visc && phase == 1) {
-    rc = launch_sigma(ctx->T, ctx->M, ctx->ph, Q, A_v, B, s);
+    rc = ctx->use_fast ? launch_sigma_fast(ctx->T, ctx->F, ctx->M, ctx->ph, Q, A_v, B, s)
+                       : launch_sigma(ctx->T, ctx->M, ctx->ph, Q, A_v, B, s);
     if (!rc && ctx->nsend) rc = launch_pack(B, B_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[2].send_off), s);
   } else {
     if (!rhs) return fail(ESDG_ERR_ARG, "rhs output is null");
-    rc = launch_rhs(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, B, rhs, s);
+    rc = ctx->use_fast ? launch_rhs_fast(ctx->T, ctx->F, ctx->M, ctx->ph, Q, A_U, A_v, B, rhs, s)
+                       : launch_rhs(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, B, rhs, s);
   }
   if (rc) return fail(ESDG_ERR_NO_DEVICE, "kernel launch failed in phase %d: %s", phase, hipGetErrorString((hipError_t)rc));
   return ESDG_OK;
