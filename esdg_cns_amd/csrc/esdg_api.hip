@@ -412,6 +412,8 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   c->ph.BCTYPE = phys->BCTYPE;
   c->ph.Re = phys->Re; c->ph.mu = phys->mu; c->ph.lambda = phys->lambda; c->ph.Pr = phys->Pr;
   c->nphases = visc ? 3 : 2;
+  c->ph.dbg = 0;
+  if (const char* env = getenv("ESDG_DBG")) c->ph.dbg = atoi(env);
 
   // ---- collocated sparse operators -------------------------------------------------------
   Mat EfD, PhC, LfC, DrC, DsC, Vq, Pq;

@@ -87,6 +87,7 @@ struct Phys {
   double lf_scale;
   int inviscid_dissp, viscous_dissp, BCTYPE;
   double Re, mu, lambda, Pr;
+  int dbg;  // timing-ablation mask from ESDG_DBG (diagnostic builds only; 0 in normal use)
 };
 
 // kernel launchers (esdg_kernels.hip); return hipError_t as int

@@ -25,7 +25,7 @@ template <int N1> struct FCfg { static constexpr int T = 64, E = 1; };
 template <> struct FCfg<2> { static constexpr int T = 64, E = 8; };
 template <> struct FCfg<3> { static constexpr int T = 64, E = 5; };
 template <> struct FCfg<4> { static constexpr int T = 64, E = 4; };
-template <> struct FCfg<5> { static constexpr int T = 128, E = 5; };
+template <> struct FCfg<5> { static constexpr int T = 64, E = 2; };
 template <> struct FCfg<6> { static constexpr int T = 128, E = 3; };
 template <> struct FCfg<7> { static constexpr int T = 128, E = 2; };
 template <> struct FCfg<8> { static constexpr int T = 64, E = 1; };
@@ -157,18 +157,36 @@ __device__ __forceinline__ void viscous_stress(const double* v, const double* tx
 
 // ---- state load (+ Vq by sum factorisation) -------------------------------------------------
 // Returns the conservative state at this lane's Gauss node.  sA, sB: LDS scratch [E][4][Nq] each.
+template <int N1>
+__device__ __forceinline__ void issue_state_loads(const double* __restrict__ Q, int64_t K, int64_t e0, bool active,
+                                                  double* x) {
+  constexpr int Nq = N1 * N1;
+  x[0] = 1.0; x[1] = 0.0; x[2] = 0.0; x[3] = 1.0;
+  if (active) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) x[f] = Q[(int64_t)f * K * Nq + e0 * Nq + threadIdx.x];
+  }
+}
+
+template <int N1, bool MODAL>
+__device__ __forceinline__ void state_at_quad(const FastTables& F, bool active, int ev, int q, double* sA, double* sB,
+                                              const double* x, double* U);
+
 template <int N1, bool MODAL>
 __device__ __forceinline__ void load_state_at_quad(const FastTables& F, const double* __restrict__ Q, int64_t K,
                                                    int64_t e0, bool active, int ev, int q, double* sA, double* sB,
                                                    double* U) {
+  double x[4];
+  issue_state_loads<N1>(Q, K, e0, active, x);
+  state_at_quad<N1, MODAL>(F, active, ev, q, sA, sB, x, U);
+}
+
+template <int N1, bool MODAL>
+__device__ __forceinline__ void state_at_quad(const FastTables& F, bool active, int ev, int q, double* sA, double* sB,
+                                              const double* x, double* U) {
   constexpr int Nq = N1 * N1;
   const int tid = threadIdx.x;
   const bool inrange = tid < FCfg<N1>::E * Nq;   // lanes beyond E*Nq own no LDS slot
-  double x[4] = {1.0, 0.0, 0.0, 1.0};
-  if (active) {
-#pragma unroll
-    for (int f = 0; f < 4; ++f) x[f] = Q[(int64_t)f * K * Nq + e0 * Nq + tid];
-  }
   if (!MODAL) {
 #pragma unroll
     for (int f = 0; f < 4; ++f) U[f] = x[f];
@@ -252,10 +270,11 @@ __device__ __forceinline__ void store_rhs_from_quad(const FastTables& F, double*
 
 // ---- viscous stages ----------------------------------------------------------------------------
 // face lanes: half jumps of the projected entropy variables (+ penalty), dg_grad! :548-569, :817-822
-template <int N1, bool WITH_PEN>
+template <int N1, bool WITH_PEN, bool PRE = false>
 __device__ __forceinline__ void visc_face_jumps(const Tables& T, const MeshDev& M, const Phys& ph, int64_t e0,
                                                 bool factive, int ef, int fn, const double* __restrict__ sV,
-                                                const double* __restrict__ A_v, double* sDv, double* sPen) {
+                                                const double* __restrict__ A_v, const double* vPre, double* sDv,
+                                                double* sPen) {
   constexpr int Nq = N1 * N1, Nfq = 4 * N1;
   if (!factive) return;
   double vf[3] = {0, 0, 0};
@@ -266,9 +285,14 @@ __device__ __forceinline__ void visc_face_jumps(const Tables& T, const MeshDev& 
 #pragma unroll
     for (int c = 0; c < 3; ++c) vf[c] += a * sV[(ef * 3 + c) * Nq + col];
   }
-  const int64_t n = (e0 + ef) * Nfq + fn;
-  const double* vp = A_v + (int64_t)M.mapP[n] * AV_NC;
-  const double vP[3] = {vp[0], vp[1], vp[2]};
+  double vP[3];
+  if (PRE) {
+    vP[0] = vPre[0]; vP[1] = vPre[1]; vP[2] = vPre[2];
+  } else {
+    const int64_t n = (e0 + ef) * Nfq + fn;
+    const double* vp = A_v + (int64_t)M.mapP[n] * AV_NC;
+    vP[0] = vp[0]; vP[1] = vp[1]; vP[2] = vp[2];
+  }
   const double tau = -1 / ph.Re / vf[2];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -429,7 +453,7 @@ __global__ __launch_bounds__(FCfg<N1>::T) void kf_sigma(Tables T, FastTables F, 
     for (int c = 0; c < 3; ++c) sV[(ev * 3 + c) * Nq + q] = V[c + 1];
   }
   __syncthreads();
-  visc_face_jumps<N1, false>(T, M, ph, e0, factive, ef, fn, sV, A_v, sDv, nullptr);
+  visc_face_jumps<N1, false>(T, M, ph, e0, factive, ef, fn, sV, A_v, nullptr, sDv, nullptr);
   __syncthreads();
   if (vactive) {
     double sgx[3], sgy[3];
@@ -491,9 +515,32 @@ __global__ __launch_bounds__(FCfg<N1>::T) void kf_rhs(Tables T, FastTables F, Me
   const bool factive = tid < nE * Nfq;
   const double* g = M.geo + (e0 + (vactive ? ev : 0)) * GEO_STRIDE;
 
+  // ---- issue every global load this block needs up front: the state first (needed first; vmcnt
+  //      retires in order), then the face traces, which depend on nothing computed here ----------
+  double xq[4];
+  issue_state_loads<N1>(Q, M.K, e0, vactive, xq);
+  double qM[8], qP[8], vPn[3] = {0, 0, 0}, bPn[3] = {0, 0, 0};
+  if (factive && !(ph.dbg & 4)) {
+    const int64_t n = (e0 + ef) * Nfq + fn;
+    const int64_t mp = M.mapP[n];
+    const double2* aM = reinterpret_cast<const double2*>(A_U + n * FAU_NC);
+    const double2* aP = reinterpret_cast<const double2*>(A_U + mp * FAU_NC);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double2 m = aM[c], p = aP[c];
+      qM[2 * c] = m.x; qM[2 * c + 1] = m.y;
+      qP[2 * c] = p.x; qP[2 * c + 1] = p.y;
+    }
+    if (VISC) {
+      const double* vp = A_v + mp * AV_NC;
+      const double* bp = B + mp * B_NC;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { vPn[c] = vp[c]; bPn[c] = bp[c]; }
+    }
+  }
   // ---- state at the Gauss node, primitives + logs ------------------------------------------
   double U[4];
-  load_state_at_quad<N1, MODAL>(F, Q, M.K, e0, vactive, ev, q, sX, sX + E * 4 * Nq, U);
+  state_at_quad<N1, MODAL>(F, vactive, ev, q, sX, sX + E * 4 * Nq, xq, U);
   double qh[6];
   prim_logs<MODAL>(U, qh);
   if (vactive) {
@@ -508,18 +555,8 @@ __global__ __launch_bounds__(FCfg<N1>::T) void kf_rhs(Tables T, FastTables F, Me
       for (int c = 0; c < 3; ++c) sV[(ev * 3 + c) * Nq + q] = V[c + 1];
     }
   }
-  // ---- face lanes: own + neighbour traces, interface flux ------------------------------------
-  if (factive) {
-    const int64_t n = (e0 + ef) * Nfq + fn;
-    const double2* aM = reinterpret_cast<const double2*>(A_U + n * FAU_NC);
-    const double2* aP = reinterpret_cast<const double2*>(A_U + (int64_t)M.mapP[n] * FAU_NC);
-    double qM[8], qP[8];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const double2 m = aM[c], p = aP[c];
-      qM[2 * c] = m.x; qM[2 * c + 1] = m.y;
-      qP[2 * c] = p.x; qP[2 * c + 1] = p.y;
-    }
+  // ---- face lanes: interface flux from the prefetched own + neighbour traces -----------------
+  if (factive && !(ph.dbg & 4)) {
     double2* d = reinterpret_cast<double2*>(sQh + (ef * Nh + Nq + fn) * 6);
     d[0] = make_double2(qM[0], qM[1]);
     d[1] = make_double2(qM[2], qM[3]);
@@ -538,6 +575,7 @@ __global__ __launch_bounds__(FCfg<N1>::T) void kf_rhs(Tables T, FastTables F, Me
   double acc[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
+    if (ph.dbg & 1) break;   // ablation (diagnostic): no flux differencing
     if (vactive) {
       const int base = (d * Nq + q);
 #pragma unroll
@@ -625,12 +663,12 @@ __global__ __launch_bounds__(FCfg<N1>::T) void kf_rhs(Tables T, FastTables F, Me
     for (int c = 0; c < 4; ++c) R[c] = -a[c] / J;
   }
   // ---- viscous terms ---------------------------------------------------------------------------
-  if (VISC) {
+  if (VISC && !(ph.dbg & 2)) {
     double* sDv = sX;                    // [E][3][Nfq]
     double* sPen = sDv + E * 3 * Nfq;    // [E][3][Nfq]
     double* sSj = sPen + E * 3 * Nfq;    // [E][3][Nfq]
     double* sS = sSj + E * 3 * Nfq;      // [E][6][Nq]
-    visc_face_jumps<N1, true>(T, M, ph, e0, factive, ef, fn, sV, A_v, sDv, sPen);
+    visc_face_jumps<N1, true, true>(T, M, ph, e0, factive, ef, fn, sV, A_v, vPn, sDv, sPen);
     __syncthreads();
     if (vactive) {
       double sgx[3], sgy[3];
@@ -646,10 +684,8 @@ __global__ __launch_bounds__(FCfg<N1>::T) void kf_rhs(Tables T, FastTables F, Me
       const double* gn = M.geo + (e0 + ef) * GEO_STRIDE + 5 + 3 * (fn / N1);
       double sn[3];
       face_normal_stress<N1>(T, sS, ef, fn, gn[0], gn[1], sn);
-      const int64_t n = (e0 + ef) * Nfq + fn;
-      const double* bp = B + (int64_t)M.mapP[n] * B_NC;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) sSj[(ef * 3 + c) * Nfq + fn] = .5 * (-bp[c] - sn[c]);
+      for (int c = 0; c < 3; ++c) sSj[(ef * 3 + c) * Nfq + fn] = .5 * (-bPn[c] - sn[c]);
     }
     __syncthreads();
     if (vactive) {
