@@ -19,6 +19,7 @@
 
 #include "../../include/esdg_hip.h"
 #include "esdg_dev.hpp"
+#include "esdg_tensor_tables.hpp"
 
 using namespace esdg;
 
@@ -130,133 +131,136 @@ struct Exchange {
   size_t send_off;  // byte offset of the packed send buffer in the workspace
 };
 
-// Host image of FastTables (esdg_dev.hpp).  build_fast_host() returns false when the operators do
-// not have the tensor-line structure; the generic kernels are used then.
-struct FastHost {
-  int NF = 0;
-  std::vector<uint8_t> fwd_id, bwd_src, face_id, fr_dir, fr_src, fr_slot, pl_fn;
-  std::vector<double> fwd_c, face_c, pl_ph, pl_lf, ph_diag, Iq, Ip;
+// Host image of the 1D tensor tables (esdg_tensor_tables.hpp).  build_tensor_host() returns false when
+// the driver's operators do not factor that way (entry-by-entry check against the dense matrices, tolerance
+// 1e-11); the generic pair-list kernels are used then.
+struct TensorHost {
+  int op[2] = {0, 1};
+  std::vector<double> dbl;
+  std::vector<int32_t> ints;
 };
 
-bool build_fast_host(int N1, const Mat& Qr, const Mat& Qs, const Mat& PhC, const Mat& LfC, const Mat* Vq, const Mat* Pq,
-                     FastHost& F) {
-  const int Nq = N1 * N1, Nfq = 4 * N1, Nh = Nq + Nfq, NF = N1 / 2;
-  F.NF = NF;
+bool build_tensor_host(int N1, const Mat& Qr, const Mat& Qs, const Mat& PhC, const Mat& LfC, const Mat& EfD,
+                       const Mat* DrC, const Mat* DsC, const Mat* Vq, const Mat* Pq, TensorHost& H) {
+  const int Nq = N1 * N1, Nfq = 4 * N1, Nh = Nq + Nfq;
+  const double TOL = 1e-11;
+  const TensorLayout L(N1);
+  H.dbl.assign(L.NDBL, 0.0);
+  H.ints.assign(L.NINT, 0);
+  auto node = [&](int d, int i, int o) { return d == 0 ? i + N1 * o : o + N1 * i; };
   auto nz = [](double x) { return std::fabs(x) > DROPTOL; };
-  // direction of every coupled pair; a pair carrying both a Qr and a Qs weight is not tensor-line
-  std::vector<std::vector<int>> vol[2], fac[2];
-  for (int d = 0; d < 2; ++d) { vol[d].assign(Nq, {}); fac[d].assign(Nq, {}); }
-  std::vector<int> fdir(Nfq, -1);
-  std::vector<std::vector<int>> fsrc(Nfq);
-  for (int i = 0; i < Nq; ++i)
-    for (int j = 0; j < Nh; ++j) {
-      if (i == j) continue;
-      const bool a = nz(Qr(i, j)), b = nz(Qs(i, j));
-      if (!a && !b) continue;
-      if (a && b) return false;
-      const int d = a ? 0 : 1;
-      if (j < Nq) vol[d][i].push_back(j);
-      else {
-        fac[d][i].push_back(j - Nq);
-        if (fdir[j - Nq] >= 0 && fdir[j - Nq] != d) return false;
-        fdir[j - Nq] = d;
-        fsrc[j - Nq].push_back(i);
+  Mat Rr(Nq, Nh), Rs(Nq, Nh), RP(Nq, Nh), RE(Nfq, Nq), RDr(Nq, Nq), RDs(Nq, Nq);  // reconstructions
+  std::vector<int> face_seen(Nfq, 0);
+  for (int d = 0; d < 2; ++d) {
+    // operator family coupling the nodes of a d-line
+    const int n0 = node(d, 0, 0), n1 = node(d, 1, 0);
+    int op;
+    if (nz(Qr(n0, n1)) && !nz(Qs(n0, n1))) op = 0;
+    else if (nz(Qs(n0, n1)) && !nz(Qr(n0, n1))) op = 1;
+    else return false;
+    H.op[d] = op;
+    const Mat& Q = op ? Qs : Qr;
+    Mat& RQ = op ? Rs : Rr;
+    const double ref = Q(n0, n1);
+    for (int o = 0; o < N1; ++o) H.dbl[L.WT + d * N1 + o] = Q(node(d, 0, o), node(d, 1, o)) / ref;
+    for (int i = 0; i < N1; ++i)
+      for (int j = 0; j < N1; ++j) H.dbl[L.S + (d * N1 + i) * N1 + j] = Q(node(d, i, 0), node(d, j, 0));
+    for (int o = 0; o < N1; ++o)
+      for (int i = 0; i < N1; ++i)
+        for (int j = 0; j < N1; ++j)
+          RQ(node(d, i, o), node(d, j, o)) += H.dbl[L.S + (d * N1 + i) * N1 + j] * H.dbl[L.WT + d * N1 + o];
+    // the two face nodes at the ends of every line
+    for (int o = 0; o < N1; ++o) {
+      std::vector<int> fs;
+      for (int f = 0; f < Nfq; ++f) {
+        bool hit = false;
+        for (int i = 0; i < N1; ++i) hit = hit || nz(Q(node(d, i, o), Nq + f));
+        if (hit) fs.push_back(f);
       }
-    }
-  F.fwd_id.assign((size_t)2 * Nq * NF, 0xFF);
-  F.bwd_src.assign((size_t)2 * Nq * NF, 0xFF);
-  F.fwd_c.assign((size_t)2 * Nq * NF * 2, 0.0);
-  F.face_id.assign((size_t)2 * Nq * 2, 0);
-  F.face_c.assign((size_t)2 * Nq * 2 * 2, 0.0);
-  for (int d = 0; d < 2; ++d)
-    for (int q = 0; q < Nq; ++q) {
-      if ((int)vol[d][q].size() != N1 - 1 || (int)fac[d][q].size() != 2) return false;
-      std::vector<int> line = vol[d][q];
-      line.push_back(q);
-      std::sort(line.begin(), line.end());
-      std::vector<int> faces = fac[d][q];
-      std::sort(faces.begin(), faces.end());
-      for (int p : line) {  // clique + same two faces for every node of the line
-        std::vector<int> lp = vol[d][p];
-        lp.push_back(p);
-        std::sort(lp.begin(), lp.end());
-        std::vector<int> fp = fac[d][p];
-        std::sort(fp.begin(), fp.end());
-        if (lp != line || fp != faces) return false;
-      }
-      const int pos = (int)(std::find(line.begin(), line.end(), q) - line.begin());
-      const size_t base = (size_t)d * Nq + q;
-      for (int k = 0; k < NF; ++k) {
-        const int o = k + 1;
-        const bool half = (N1 % 2 == 0) && (o == N1 / 2);
-        if (!(half && pos >= N1 / 2)) {
-          const int p = line[(pos + o) % N1];
-          F.fwd_id[base * NF + k] = (uint8_t)p;
-          F.fwd_c[(base * NF + k) * 2 + 0] = Qr(q, p);
-          F.fwd_c[(base * NF + k) * 2 + 1] = Qs(q, p);
-        }
-        const int sp = (pos - o + N1) % N1;
-        if (!(half && sp >= N1 / 2)) F.bwd_src[base * NF + k] = (uint8_t)line[sp];
-      }
+      if (fs.size() != 2) return false;
       for (int t = 0; t < 2; ++t) {
-        F.face_id[base * 2 + t] = (uint8_t)faces[t];
-        F.face_c[(base * 2 + t) * 2 + 0] = Qr(q, Nq + faces[t]);
-        F.face_c[(base * 2 + t) * 2 + 1] = Qs(q, Nq + faces[t]);
+        H.ints[L.FN + (d * 2 + t) * N1 + o] = fs[t];
+        if (face_seen[fs[t]]++) return false;
+        H.ints[L.FINV + fs[t]] = d | (t << 1) | (o << 2);
       }
     }
-  F.fr_dir.assign(Nfq, 0);
-  F.fr_src.assign((size_t)Nfq * N1, 0);
-  F.fr_slot.assign(Nfq, 0);
-  for (int f = 0; f < Nfq; ++f) {
-    if (fdir[f] < 0 || (int)fsrc[f].size() != N1) return false;
-    const int d = fdir[f];
-    std::sort(fsrc[f].begin(), fsrc[f].end());
-    F.fr_dir[f] = (uint8_t)d;
-    const int q0 = fsrc[f][0];
-    const size_t base = (size_t)d * Nq + q0;
-    const int slot = F.face_id[base * 2 + 0] == f ? 0 : 1;
-    if (F.face_id[base * 2 + slot] != f) return false;
-    F.fr_slot[f] = (uint8_t)slot;
-    for (int j = 0; j < N1; ++j) F.fr_src[(size_t)f * N1 + j] = (uint8_t)fsrc[f][j];
-  }
-  // collocated projection / lift: diagonal volume block + at most 4 face entries per node
-  F.pl_fn.assign((size_t)Nq * 4, 0);
-  F.pl_ph.assign((size_t)Nq * 4, 0.0);
-  F.pl_lf.assign((size_t)Nq * 4, 0.0);
-  F.ph_diag.assign(Nq, 0.0);
-  for (int q = 0; q < Nq; ++q) {
-    for (int j = 0; j < Nq; ++j)
-      if (j != q && nz(PhC(q, j))) return false;
-    F.ph_diag[q] = PhC(q, q);
-    int t = 0;
-    for (int f = 0; f < Nfq; ++f)
-      if (nz(PhC(q, Nq + f)) || nz(LfC(q, f))) {
-        if (t == 4) return false;
-        F.pl_fn[(size_t)q * 4 + t] = (uint8_t)f;
-        F.pl_ph[(size_t)q * 4 + t] = PhC(q, Nq + f);
-        F.pl_lf[(size_t)q * 4 + t] = LfC(q, f);
-        ++t;
+    for (int t = 0; t < 2; ++t) {
+      auto fn = [&](int o) { return H.ints[L.FN + (d * 2 + t) * N1 + o]; };
+      // SF/WTF (SBP weight), PF/PTF (projection), EE (face interpolation): reference line o = 0, pivot = largest entry
+      int ip = 0, ipp = 0;
+      for (int i = 0; i < N1; ++i) {
+        H.dbl[L.SF + (d * 2 + t) * N1 + i] = Q(node(d, i, 0), Nq + fn(0));
+        H.dbl[L.PF + (d * 2 + t) * N1 + i] = PhC(node(d, i, 0), Nq + fn(0));
+        H.dbl[L.EE + (d * 2 + t) * N1 + i] = EfD(fn(0), node(d, i, 0));
+        if (std::fabs(H.dbl[L.SF + (d * 2 + t) * N1 + i]) > std::fabs(H.dbl[L.SF + (d * 2 + t) * N1 + ip])) ip = i;
+        if (std::fabs(H.dbl[L.PF + (d * 2 + t) * N1 + i]) > std::fabs(H.dbl[L.PF + (d * 2 + t) * N1 + ipp])) ipp = i;
       }
+      if (!nz(H.dbl[L.SF + (d * 2 + t) * N1 + ip]) || !nz(H.dbl[L.PF + (d * 2 + t) * N1 + ipp])) return false;
+      for (int o = 0; o < N1; ++o) {
+        H.dbl[L.WTF + (d * 2 + t) * N1 + o] = Q(node(d, ip, o), Nq + fn(o)) / H.dbl[L.SF + (d * 2 + t) * N1 + ip];
+        H.dbl[L.PTF + (d * 2 + t) * N1 + o] = PhC(node(d, ipp, o), Nq + fn(o)) / H.dbl[L.PF + (d * 2 + t) * N1 + ipp];
+        for (int i = 0; i < N1; ++i) {
+          RQ(node(d, i, o), Nq + fn(o)) += H.dbl[L.SF + (d * 2 + t) * N1 + i] * H.dbl[L.WTF + (d * 2 + t) * N1 + o];
+          RP(node(d, i, o), Nq + fn(o)) += H.dbl[L.PF + (d * 2 + t) * N1 + i] * H.dbl[L.PTF + (d * 2 + t) * N1 + o];
+          RE(fn(o), node(d, i, o)) += H.dbl[L.EE + (d * 2 + t) * N1 + i];
+        }
+      }
+    }
+    if (DrC && DsC) {
+      const Mat& D = op ? *DsC : *DrC;
+      Mat& RD = op ? RDs : RDr;
+      for (int i = 0; i < N1; ++i)
+        for (int j = 0; j < N1; ++j) H.dbl[L.DG + (d * N1 + i) * N1 + j] = D(node(d, i, 0), node(d, j, 0));
+      for (int o = 0; o < N1; ++o)
+        for (int i = 0; i < N1; ++i)
+          for (int j = 0; j < N1; ++j) RD(node(d, i, o), node(d, j, o)) += H.dbl[L.DG + (d * N1 + i) * N1 + j];
+    }
   }
-  // 1D factors of Vq, Pq (modal): Vq[(a+N1 b),(i+N1 j)] = Iq[b,i] Iq[a,j], rows of Iq sum to one
-  F.Iq.assign((size_t)N1 * N1, 0.0);
-  F.Ip.assign((size_t)N1 * N1, 0.0);
+  if (H.op[0] == H.op[1]) return false;
+  for (int f = 0; f < Nfq; ++f)
+    if (face_seen[f] != 1) return false;
+  for (int q = 0; q < Nq; ++q) {
+    H.dbl[L.PD + q] = PhC(q, q);
+    RP(q, q) += PhC(q, q);
+  }
+  // lift = projection * per-face-node weight
+  for (int f = 0; f < Nfq; ++f) {
+    int qb = 0;
+    for (int q = 0; q < Nq; ++q)
+      if (std::fabs(PhC(q, Nq + f)) > std::fabs(PhC(qb, Nq + f))) qb = q;
+    if (!nz(PhC(qb, Nq + f))) return false;
+    H.dbl[L.WFAC + f] = LfC(qb, f) / PhC(qb, Nq + f);
+  }
+  // ---- verification against the dense operators ---------------------------------------------
+  for (int i = 0; i < Nq; ++i) {
+    for (int j = 0; j < Nh; ++j) {
+      if (std::fabs(Rr(i, j) - Qr(i, j)) > TOL || std::fabs(Rs(i, j) - Qs(i, j)) > TOL) return false;
+      if (std::fabs(RP(i, j) - PhC(i, j)) > TOL) return false;
+    }
+    for (int f = 0; f < Nfq; ++f) {
+      if (std::fabs(RE(f, i) - EfD(f, i)) > TOL) return false;
+      if (std::fabs(RP(i, Nq + f) * H.dbl[L.WFAC + f] - LfC(i, f)) > TOL) return false;
+    }
+    if (DrC && DsC)
+      for (int j = 0; j < Nq; ++j)
+        if (std::fabs(RDr(i, j) - (*DrC)(i, j)) > TOL || std::fabs(RDs(i, j) - (*DsC)(i, j)) > TOL) return false;
+  }
+  // 1D factors of Vq, Pq (modal): Vq[(a+N1 b),(i+N1 j)] = IQ[b,i] IQ[a,j], rows of IQ sum to one
   if (Vq && Pq) {
     for (int a = 0; a < N1; ++a)
       for (int j = 0; j < N1; ++j) {
         double s = 0.0, t = 0.0;
         for (int i = 0; i < N1; ++i) s += (*Vq)(a + N1 * 0, i + N1 * j);
-        for (int b = 0; b < N1; ++b) t += (*Pq)(0 + N1 * a, j + N1 * b);  // Ip[a_row=j_nodal, col=quad a]: see below
-        F.Iq[(size_t)a * N1 + j] = s;
-        F.Ip[(size_t)a * N1 + j] = t;
+        for (int b = 0; b < N1; ++b) t += (*Pq)(0 + N1 * a, j + N1 * b);
+        H.dbl[L.IQ + a * N1 + j] = s;
+        H.dbl[L.IP + a * N1 + j] = t;
       }
-    // Pq[(i+N1 j),(a+N1 b)] = Ip[i,b] Ip[j,a]; summing over b at i=0 gives Ip[j,a]: stored above as Ip[j=a_loop][a=j_loop]
     for (int a = 0; a < N1; ++a)
       for (int b = 0; b < N1; ++b)
         for (int i = 0; i < N1; ++i)
           for (int j = 0; j < N1; ++j) {
-            if (std::fabs((*Vq)(a + N1 * b, i + N1 * j) - F.Iq[(size_t)b * N1 + i] * F.Iq[(size_t)a * N1 + j]) > 1e-11) return false;
-            if (std::fabs((*Pq)(i + N1 * j, a + N1 * b) - F.Ip[(size_t)i * N1 + b] * F.Ip[(size_t)j * N1 + a]) > 1e-11) return false;
+            if (std::fabs((*Vq)(a + N1 * b, i + N1 * j) - H.dbl[L.IQ + b * N1 + i] * H.dbl[L.IQ + a * N1 + j]) > TOL) return false;
+            if (std::fabs((*Pq)(i + N1 * j, a + N1 * b) - H.dbl[L.IP + i * N1 + b] * H.dbl[L.IP + j * N1 + a]) > TOL) return false;
           }
   }
   return true;
@@ -341,7 +345,7 @@ int build_halo_plan(const int64_t* mapP_g, int64_t K, int Nfq, int64_t e_lo, int
 
 struct esdg_ctx {
   Tables T{};
-  FastTables F{};
+  TensorTables TT{};
   bool use_fast = false;
   int au_nc = AU_NC;
   MeshDev M{};
@@ -352,8 +356,7 @@ struct esdg_ctx {
   // device storage
   DevBuf d_pair_ij, d_pair_c, d_inc_ptr, d_inc, d_Ef_i, d_Ef_v, d_Ph_i, d_Ph_v, d_Lf_i, d_Lf_v, d_Dr_i, d_Dr_v, d_Ds_i,
       d_Ds_v, d_Vq, d_Pq, d_geo, d_mapP, d_bc, d_wJq, d_sendlist, d_partial;
-  DevBuf f_fwd_id, f_fwd_c, f_bwd_src, f_face_id, f_face_c, f_fr_dir, f_fr_src, f_fr_slot, f_pl_fn, f_pl_ph, f_pl_lf,
-      f_ph_diag, f_Iq, f_Ip;
+  DevBuf t_dbl, t_int, d_stamps;
   // halo plan
   std::vector<int32_t> nbr_rank;
   std::vector<int64_t> nbr_send_off, nbr_send_cnt, nbr_recv_off, nbr_recv_cnt;  // in face nodes
@@ -492,9 +495,9 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   }
 
   // ---- tensor-line schedule of the fast path (falls back to the generic kernels if absent) ----
-  FastHost fh;
-  bool use_fast = build_fast_host(N1, Qr, Qs, PhC, LfC, modal ? &Vq : nullptr, modal ? &Pq : nullptr, fh) &&
-                  eEf.w == N1 && (!visc || eDr.w == N1);
+  TensorHost th;
+  bool use_fast = build_tensor_host(N1, Qr, Qs, PhC, LfC, EfD, visc ? &DrC : nullptr, visc ? &DsC : nullptr,
+                                    modal ? &Vq : nullptr, modal ? &Pq : nullptr, th);
   if (const char* env = getenv("ESDG_FORCE_GENERIC"))
     if (env[0] == '1') use_fast = false;
   c->use_fast = use_fast;
@@ -554,21 +557,11 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   UP(d_Vq, Vq.a); UP(d_Pq, Pq.a);
   UP(d_geo, geo); UP(d_mapP, mapP); UP(d_sendlist, sendlist);
   if (use_fast) {
-    UP(f_fwd_id, fh.fwd_id); UP(f_fwd_c, fh.fwd_c); UP(f_bwd_src, fh.bwd_src); UP(f_face_id, fh.face_id);
-    UP(f_face_c, fh.face_c); UP(f_fr_dir, fh.fr_dir); UP(f_fr_src, fh.fr_src); UP(f_fr_slot, fh.fr_slot);
-    UP(f_pl_fn, fh.pl_fn); UP(f_pl_ph, fh.pl_ph); UP(f_pl_lf, fh.pl_lf); UP(f_ph_diag, fh.ph_diag);
-    UP(f_Iq, fh.Iq); UP(f_Ip, fh.Ip);
-    FastTables& F = c->F;
-    F.NF = fh.NF;
-    F.fwd_id = c->f_fwd_id.as<uint8_t>(); F.fwd_c = c->f_fwd_c.as<double>(); F.bwd_src = c->f_bwd_src.as<uint8_t>();
-    F.face_id = c->f_face_id.as<uint8_t>(); F.face_c = c->f_face_c.as<double>();
-    F.fr_dir = c->f_fr_dir.as<uint8_t>(); F.fr_src = c->f_fr_src.as<uint8_t>(); F.fr_slot = c->f_fr_slot.as<uint8_t>();
-    F.pl_fn = c->f_pl_fn.as<uint8_t>(); F.pl_ph = c->f_pl_ph.as<double>(); F.pl_lf = c->f_pl_lf.as<double>();
-    F.ph_diag = c->f_ph_diag.as<double>(); F.Iq = c->f_Iq.as<double>(); F.Ip = c->f_Ip.as<double>();
-  }
-  if (mesh->wJq) {
-    std::vector<double> w(mesh->wJq, mesh->wJq + (size_t)K * Nq);
-    UP(d_wJq, w);
+    UP(t_dbl, th.dbl); UP(t_int, th.ints);
+    c->TT.dbl = c->t_dbl.as<double>();
+    c->TT.ints = c->t_int.as<int>();
+    c->TT.op0 = th.op[0];
+    c->TT.op1 = th.op[1];
   }
 #undef UP
   if ((rc = c->d_partial.alloc(sizeof(double) * esdg_ctx::NPARTIAL)) != 0) return rc;
@@ -585,6 +578,12 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   T.Vq = c->d_Vq.as<double>(); T.Pq = c->d_Pq.as<double>();
   c->M.K = K; c->M.geo = c->d_geo.as<double>(); c->M.mapP = c->d_mapP.as<int32_t>(); c->M.bc = nullptr;
   c->M.wJq = mesh->wJq ? c->d_wJq.as<double>() : nullptr;
+  c->M.stamps = nullptr;
+  if (c->ph.dbg & 8) {
+    if ((rc = c->d_stamps.alloc(4096 * 16 * 8)) != 0) return rc;
+    HIP_TRY(hipMemset(c->d_stamps.p, 0, 4096 * 16 * 8));
+    c->M.stamps = static_cast<unsigned long long*>(c->d_stamps.p);
+  }
 
   // ---- workspace layout ---------------------------------------------------------------------
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -642,19 +641,19 @@ int esdg_rhs_phase(esdg_ctx* ctx, int phase, const double* Q, double* rhs, void*
   int rc = 0;
   const int32_t* sl = ctx->d_sendlist.as<int32_t>();
   if (phase == 0) {
-    rc = ctx->use_fast ? launch_project_fast(ctx->T, ctx->F, ctx->M, ctx->ph, Q, A_U, A_v, s)
+    rc = ctx->use_fast ? launch_project_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, A_v, s)
                        : launch_project(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, s);
     if (!rc && ctx->nsend) {
       rc = launch_pack(A_U, ctx->au_nc, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[0].send_off), s);
       if (!rc && visc) rc = launch_pack(A_v, AV_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[1].send_off), s);
     }
   } else if (visc && phase == 1) {
-    rc = ctx->use_fast ? launch_sigma_fast(ctx->T, ctx->F, ctx->M, ctx->ph, Q, A_v, B, s)
+    rc = ctx->use_fast ? launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_v, B, s)
                        : launch_sigma(ctx->T, ctx->M, ctx->ph, Q, A_v, B, s);
     if (!rc && ctx->nsend) rc = launch_pack(B, B_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[2].send_off), s);
   } else {
     if (!rhs) return fail(ESDG_ERR_ARG, "rhs output is null");
-    rc = ctx->use_fast ? launch_rhs_fast(ctx->T, ctx->F, ctx->M, ctx->ph, Q, A_U, A_v, B, rhs, s)
+    rc = ctx->use_fast ? launch_rhs_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, A_v, B, rhs, s)
                        : launch_rhs(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, B, rhs, s);
   }
   if (rc) return fail(ESDG_ERR_NO_DEVICE, "kernel launch failed in phase %d: %s", phase, hipGetErrorString((hipError_t)rc));
@@ -709,6 +708,13 @@ int esdg_rhs_host(esdg_ctx* ctx, const double* const Q[4], double* const rhs[4])
   ctx->ws = static_cast<char*>(old_ws);
   if (rc) return rc;
   for (int f = 0; f < 4; ++f) HIP_TRY(hipMemcpy(rhs[f], static_cast<char*>(dR.p) + f * bytes, bytes, hipMemcpyDeviceToHost));
+  return ESDG_OK;
+}
+
+/* diagnostic: read back the s_memtime section stamps (ESDG_DBG & 8) */
+int esdg_debug_stamps(esdg_ctx* ctx, unsigned long long* out, int n) {
+  if (!ctx || !ctx->M.stamps || n > 4096 * 16) return fail(ESDG_ERR_STATE, "stamps not enabled");
+  HIP_TRY(hipMemcpy(out, ctx->M.stamps, (size_t)n * 8, hipMemcpyDeviceToHost));
   return ESDG_OK;
 }
 

@@ -40,39 +40,18 @@ struct Tables {
   const double* Pq;        // [Np][Nq] row-major (modal)
 };
 
-// Tensor-line schedule of the fast path (esdg_kernels_fast.hip), derived on the host from the pair
-// list when the SBP operators have the tensor-product Gauss structure: in each direction d the pair
-// graph splits into lines of N1 volume nodes (a complete graph) + 2 face nodes (each coupled to all
-// N1 volume nodes).  A lane owns one volume node; per direction it evaluates NF = N1/2 "forward"
-// volume pairs (circulant schedule: every unordered pair exactly once) and its 2 face pairs.
-constexpr int FAU_NC = 8;  // fast trace record: (rho, u, v, beta, log rho, log beta, lam, E)
+// Trace record of the tensor kernels (esdg_kernels_tensor.hip): (rho, u, v, beta, log rho, log beta, lam, E)
+constexpr int FAU_NC = 8;
 
-struct FastTables {
-  int NF;                  // forward slots per direction = N1/2
-  const uint8_t* fwd_id;   // [2][Nq][NF]     partner volume node, 0xFF = unused slot
-  const double* fwd_c;     // [2][Nq][NF][2]  (Qr, Qs) weight of pair (q, partner)
-  const uint8_t* bwd_src;  // [2][Nq][NF]     volume node whose forward slot k targets q, 0xFF = none
-  const uint8_t* face_id;  // [2][Nq][2]      face node (0..Nfq-1) at the two ends of q's line
-  const double* face_c;    // [2][Nq][2][2]   (Qr, Qs) weight of pair (q, Nq+face)
-  const uint8_t* fr_dir;   // [Nfq]           direction of the line a face node belongs to
-  const uint8_t* fr_src;   // [Nfq][N1]       the N1 volume nodes of that line
-  const uint8_t* fr_slot;  // [Nfq]           0/1: which face slot those volume nodes use for this face node
-  const uint8_t* pl_fn;    // [Nq][4]         face nodes with a non-zero collocated Ph/Lf entry
-  const double* pl_ph;     // [Nq][4]         (Vq*Ph)[q, Nq+fn]
-  const double* pl_lf;     // [Nq][4]         (Vq*LIFT)[q, fn]
-  const double* ph_diag;   // [Nq]            (Vq*Ph)[q, q]
-  const double* Iq;        // [N1][N1]        Vq = Iq (x) Iq  (1D LGL -> Gauss interpolation)
-  const double* Ip;        // [N1][N1]        Pq = Ip (x) Ip  (1D Gauss -> LGL)
-};
-
+struct TensorTables;
 struct MeshDev;
 struct Phys;
-int launch_project_fast(const Tables& T, const FastTables& F, const MeshDev& M, const Phys& ph, const double* Q,
-                        double* A_U, double* A_v, hipStream_t s);
-int launch_sigma_fast(const Tables& T, const FastTables& F, const MeshDev& M, const Phys& ph, const double* Q,
-                      const double* A_v, double* B, hipStream_t s);
-int launch_rhs_fast(const Tables& T, const FastTables& F, const MeshDev& M, const Phys& ph, const double* Q,
-                    const double* A_U, const double* A_v, const double* B, double* rhs, hipStream_t s);
+int launch_project_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
+                          double* A_U, double* A_v, hipStream_t s);
+int launch_sigma_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
+                        const double* A_v, double* B, hipStream_t s);
+int launch_rhs_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
+                      const double* A_U, const double* A_v, const double* B, double* rhs, hipStream_t s);
 
 struct MeshDev {
   int64_t K;               // local elements
@@ -80,6 +59,7 @@ struct MeshDev {
   const int32_t* mapP;     // [K][Nfq]  local face-node index, or ghost slot >= K*Nfq
   const uint8_t* bc;       // [K][Nfq]  0 interior/periodic, 1 wall, 2 lid; may be null (no walls)
   const double* wJq;       // [K][Nq] (diagnostics) may be null
+  unsigned long long* stamps;  // diagnostic builds only (ESDG_DBG & 8): [4096][16] s_memtime deltas
 };
 
 struct Phys {
