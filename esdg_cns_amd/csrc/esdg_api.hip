@@ -563,6 +563,10 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
     c->TT.op0 = th.op[0];
     c->TT.op1 = th.op[1];
   }
+  if (mesh->wJq) {
+    std::vector<double> w(mesh->wJq, mesh->wJq + (size_t)K * Nq);
+    UP(d_wJq, w);
+  }
 #undef UP
   if ((rc = c->d_partial.alloc(sizeof(double) * esdg_ctx::NPARTIAL)) != 0) return rc;
 

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_project(TensorTables TT, MeshDev 
 }
 
 // ---------------------------------------------------------------------------------------------
-// viscous building blocks (lane-mapped).  sVn: [E][Nq][4] = (v2,v3,v4,-) per volume node.
+// viscous building blocks (lane-mapped).  sVn: [E][3][Nq] = (v2,v3,v4) of the volume nodes (SoA: conflict-free).
 // ---------------------------------------------------------------------------------------------
 // face lanes: projected entropy variables at the face node, half jump to the neighbour, tau
 template <int N1>
@@ -391,11 +391,10 @@ __device__ __forceinline__ void visc_face_jumps(const Lane<N1>& ln, const double
 #pragma unroll
   for (int j = 0; j < N1; ++j) {
     const double w = sTab[L.EE + (d * 2 + t) * N1 + j];
-    const double* r = sVn + (ln.ef * Nq + node_of<N1>(d, j, o)) * 4;
-    const double2 v01 = *reinterpret_cast<const double2*>(r);
-    vf[0] += w * v01.x;
-    vf[1] += w * v01.y;
-    vf[2] += w * r[2];
+    const double* r = sVn + ln.ef * 3 * Nq + node_of<N1>(d, j, o);
+    vf[0] += w * r[0];
+    vf[1] += w * r[Nq];
+    vf[2] += w * r[2 * Nq];
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) sDv[(ln.ef * 3 + c) * Nfq + ln.fn] = .5 * (vP[c] - vf[c]);
@@ -419,11 +418,10 @@ __device__ __forceinline__ void visc_sigma(const Lane<N1>& ln, const double* sTa
 #pragma unroll
     for (int j = 0; j < N1; ++j) {
       const double w = sTab[L.DG + (d * N1 + pos) * N1 + j];
-      const double* r = sVn + (ln.ev * Nq + node_of<N1>(d, j, oth)) * 4;
-      const double2 v01 = *reinterpret_cast<const double2*>(r);
-      dv[0] += w * v01.x;
-      dv[1] += w * v01.y;
-      dv[2] += w * r[2];
+      const double* r = sVn + ln.ev * 3 * Nq + node_of<N1>(d, j, oth);
+      dv[0] += w * r[0];
+      dv[1] += w * r[Nq];
+      dv[2] += w * r[2 * Nq];
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) { tx[c] += gx * dv[c]; ty[c] += gy * dv[c]; }
@@ -445,8 +443,8 @@ __device__ __forceinline__ void visc_sigma(const Lane<N1>& ln, const double* sTa
   const double iJ = rcp_refined(g[4]);
 #pragma unroll
   for (int c = 0; c < 3; ++c) { tx[c] *= iJ; ty[c] *= iJ; }
-  const double* r = sVn + (ln.ev * Nq + ln.q) * 4;
-  const double v[3] = {r[0], r[1], r[2]};
+  const double* r = sVn + ln.ev * 3 * Nq + ln.q;
+  const double v[3] = {r[0], r[Nq], r[2 * Nq]};
   viscous_stress(v, tx, ty, -ph.lambda, ph.mu, 1.4 * ph.mu / ph.Pr, sgx, sgy);
 }
 
@@ -508,9 +506,8 @@ __global__ __launch_bounds__(TW * NWV) void kt_sigma(TensorTables TT, MeshDev M,
   v_of_prim<true>(qh, V);
   __syncthreads();
   if (ln.vin) {
-    double2* r = reinterpret_cast<double2*>(sA + (ln.ev * Nq + ln.q) * 4);
-    r[0] = make_double2(V[1], V[2]);
-    r[1] = make_double2(V[3], 0.0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sA[(ln.ev * 3 + c) * Nq + ln.q] = V[c + 1];
   }
   __syncthreads();
   if (ln.fin) visc_face_jumps<N1>(ln, sTab, sInt, sA, vP, 0.0, sDv, nullptr);
@@ -601,9 +598,8 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     dq[0] = make_double2(qh[0], qh[1]);
     dq[1] = make_double2(qh[2], qh[3]);
     dq[2] = make_double2(qh[4], qh[5]);
-    double2* z = reinterpret_cast<double2*>(sAcc + (ln.ev * Nq + ln.q) * 4);
-    z[0] = make_double2(0.0, 0.0);
-    z[1] = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sAcc[(ln.ev * 4 + c) * Nq + ln.q] = 0.0;
   }
   // ---- face lanes: interface flux (euler_quad.jl:158-169 / update_flux! :308-324), kept in registers
   double flx[4] = {0, 0, 0, 0};
@@ -612,9 +608,8 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     dq[0] = make_double2(qM[0], qM[1]);
     dq[1] = make_double2(qM[2], qM[3]);
     dq[2] = make_double2(qM[4], qM[5]);
-    double2* z = reinterpret_cast<double2*>(sG + (ln.ef * Nfq + ln.fn) * 4);
-    z[0] = make_double2(0.0, 0.0);
-    z[1] = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sG[(ln.ef * 4 + c) * Nfq + ln.fn] = 0.0;
     double Fx[4], Fy[4];
     ec_flux<MODAL>(qM, qP, Fx, Fy);
     const double* gn = M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
@@ -658,12 +653,12 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
           double Fx[4], Fy[4];
           ec_flux<MODAL>(qh, qj, Fx, Fy);
           const double cx = cw * gx, cy = cw * gy;
-          double* tgt = sAcc + (ln.ev * Nq + pid) * 4;
+          double* tgt = sAcc + ln.ev * 4 * Nq + pid;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const double v = cx * Fx[c] + cy * Fy[c];
             acc[c] += v;
-            lds_add(tgt + c, -v);
+            lds_add(tgt + c * Nq, -v);
           }
         }
       }
@@ -677,12 +672,12 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
         double Fx[4], Fy[4];
         ec_flux<MODAL>(qh, qj, Fx, Fy);
         const double cx = cw * gx, cy = cw * gy;
-        double* tgt = sG + (ln.ev * Nfq + f) * 4;
+        double* tgt = sG + ln.ev * 4 * Nfq + f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const double v = cx * Fx[c] + cy * Fy[c];
           acc[c] += v;
-          lds_add(tgt + c, -v);
+          lds_add(tgt + c * Nfq, -v);
         }
       }
     }
@@ -691,20 +686,18 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
   // face lanes: G_f = QF_f + wfac_f * flux_f
   if (ln.fin) {
     const double wf = sTab[L.WFAC + ln.fn];
-    double2* gq = reinterpret_cast<double2*>(sG + (ln.ef * Nfq + ln.fn) * 4);
-    const double2 g0 = gq[0], g1 = gq[1];
-    gq[0] = make_double2(g0.x + wf * flx[0], g0.y + wf * flx[1]);
-    gq[1] = make_double2(g1.x + wf * flx[2], g1.y + wf * flx[3]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sG[(ln.ef * 4 + c) * Nfq + ln.fn] += wf * flx[c];
   }
   __syncthreads();
   // ---- collocated rhs: -(Ph*QF + Lf*flux)/J  (euler_quad.jl:170-184 / cavity :514-518) -------
   const double iJ = rcp_refined(g[4]);
   double R[4];
   {
-    const double2* aq = reinterpret_cast<const double2*>(sAcc + (ln.ev * Nq + ln.q) * 4);
-    const double2 a0 = aq[0], a1 = aq[1];
     const double pd = sTab[L.PD + ln.q];
-    double r[4] = {pd * (acc[0] + a0.x), pd * (acc[1] + a0.y), pd * (acc[2] + a1.x), pd * (acc[3] + a1.y)};
+    double r[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r[c] = pd * (acc[c] + sAcc[(ln.ev * 4 + c) * Nq + ln.q]);
 #pragma unroll 1
     for (int d = 0; d < 2; ++d) {
       const int pos = ln.pos(d), oth = ln.oth(d);
@@ -712,9 +705,8 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
       for (int t = 0; t < 2; ++t) {
         const int f = sInt[L.FN + (d * 2 + t) * N1 + oth];
         const double w = sTab[L.PF + (d * 2 + t) * N1 + pos] * sTab[L.PTF + (d * 2 + t) * N1 + oth];
-        const double2* gq = reinterpret_cast<const double2*>(sG + (ln.ev * Nfq + f) * 4);
-        const double2 g0 = gq[0], g1 = gq[1];
-        r[0] += w * g0.x; r[1] += w * g0.y; r[2] += w * g1.x; r[3] += w * g1.y;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) r[c] += w * sG[(ln.ev * 4 + c) * Nfq + f];
       }
     }
 #pragma unroll
@@ -723,7 +715,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
   // ---- viscous terms (rhs_viscous! :749-849 in collocated form) ------------------------------------
   if (VISC && !(ph.dbg & 2)) {
     __syncthreads();   // sAcc / sG are dead; sR2 becomes the viscous scratch
-    double* sVn = sQh;                       // [E][Nq][4]  (v2,v3,v4,-): primitives no longer needed
+    double* sVn = sQh;                       // [E][3][Nq]  (v2,v3,v4): primitives no longer needed
     double* sDv = sR2;                       // [E][3][Nfq]
     double* sTau = sDv + E * 3 * Nfq;        // [E][Nfq]
     double* sSj = sTau + E * Nfq;            // [E][3][Nfq]
@@ -731,9 +723,8 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     if (ln.vin) {
       double V[4];
       v_of_prim<MODAL>(qh, V);
-      double2* r = reinterpret_cast<double2*>(sVn + (ln.ev * Nq + ln.q) * 4);
-      r[0] = make_double2(V[1], V[2]);
-      r[1] = make_double2(V[3], 0.0);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sVn[(ln.ev * 3 + c) * Nq + ln.q] = V[c + 1];
     }
     __syncthreads();
     if (ln.fin) visc_face_jumps<N1>(ln, sTab, sInt, sVn, vPn, 1.0 / ph.Re, sDv, sTau);

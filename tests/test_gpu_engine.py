@@ -1,0 +1,154 @@
+"""GPU tests of everything around the kernels: size-independent properties at BASELINE's full size,
+element-index sharding (two engines on one GPU exchanging their halo segments exactly as two ranks
+would), run-to-run bitwise reproducibility, the generic (pair-list) kernels against the tensor kernels,
+the host-array drop-in entry point, the entropy diagnostic and the LSRK45 step against the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from common import product_cns_problem, product_euler_problem, rel_l2, steep_state
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    from esdg_cns_amd import engine
+    return engine
+
+
+def _rhs(eng, Q):
+    return eng.download(eng.rhs(eng.upload(Q)))
+
+
+def test_uses_tensor_kernels_and_generic_fallback_agree(E):
+    rd, md, ops, Q = product_cns_problem(4, 8, 6)
+    Qs = steep_state(md.x, md.y)
+    fast = E.RhsEngine(rd, md, ops, E.CNS_MODAL)
+    assert fast.L.esdg_uses_tensor_kernels(fast.ctx) == 1
+    os.environ["ESDG_FORCE_GENERIC"] = "1"
+    try:
+        gen = E.RhsEngine(rd, md, ops, E.CNS_MODAL)
+    finally:
+        del os.environ["ESDG_FORCE_GENERIC"]
+    assert gen.L.esdg_uses_tensor_kernels(gen.ctx) == 0
+    a, b = _rhs(fast, Qs), _rhs(gen, Qs)
+    assert rel_l2(a, b) <= 1e-12          # two independent GPU implementations of the same path
+
+
+def test_bitwise_reproducible(E):
+    rd, md, ops, Q = product_cns_problem(4, 16, 16)
+    eng = E.RhsEngine(rd, md, ops, E.CNS_MODAL)
+    Qd = eng.upload(Q)
+    r1 = eng.rhs(Qd).clone()
+    for _ in range(3):
+        r2 = eng.rhs(Qd)
+        assert torch.equal(r1, r2)          # LDS accumulation order is fixed (one wave per element group)
+
+
+@pytest.mark.parametrize("form", ["euler", "cns"])
+def test_two_shards_on_one_gpu_match_unsharded(E, form):
+    N, Kx, Ky = 3, 6, 8
+    build = product_euler_problem if form == "euler" else product_cns_problem
+    code = E.EULER_COLLOCATED if form == "euler" else E.CNS_MODAL
+    rd, md, ops, Q = build(N, Kx, Ky)
+    ref = _rhs(E.RhsEngine(rd, md, ops, code), Q)
+    K = Kx * Ky
+    offsets = np.array([0, 3 * Kx, K], dtype=np.int64)
+    engs, Qd, out = [], [], []
+    for r in range(2):
+        rdr, mdr, opsr, Qr = build(N, Kx, Ky, elem_range=(int(offsets[r]), int(offsets[r + 1])))
+        e = E.RhsEngine(rdr, mdr, opsr, code, rank=r, nranks=2, rank_offsets=offsets)
+        assert e.halo is not None
+        engs.append(e)
+        Qd.append(e.upload(Qr))
+        out.append(e.new_state())
+    nph = engs[0].nphases
+    for ph in range(nph):
+        for r in range(2):
+            E.check(engs[r].L.esdg_rhs_phase(engs[r].ctx, ph, C.c_void_p(Qd[r].data_ptr()), C.c_void_p(out[r].data_ptr()), None))
+        torch.cuda.synchronize()
+        # deliver the segments of every exchange produced by this phase (what isend/irecv would do)
+        for x, (after, before, nc) in enumerate(engs[0].xinfo):
+            if after != ph:
+                continue
+            for r in range(2):
+                for (peer, so, sb, ro, rb) in engs[r].halo.segments[x]:
+                    back = [s for s in engs[peer].halo.segments[x] if s[0] == r][0]
+                    assert sb == back[4]
+                    engs[peer].ws[back[3]:back[3] + back[4]] = engs[r].ws[so:so + sb]
+        torch.cuda.synchronize()
+    got = [np.concatenate([E.RhsEngine.download(out[0])[f], E.RhsEngine.download(out[1])[f]], axis=1) for f in range(4)]
+    assert all(np.array_equal(a, b) for a, b in zip(got, ref))      # sharding must not change a single bit
+
+
+def test_full_size_properties_cns_512(E):
+    """BASELINE config 3 (N=4, 512x512): free stream, conservation, entropy inequality."""
+    rd, md, ops, Q = product_cns_problem(4, 512, 512)
+    eng = E.RhsEngine(rd, md, ops, E.CNS_MODAL, viscous_dissp=False)
+    one = np.ones_like(Q[0])
+    from esdg_cns_amd import physics as ph
+    Qc = [np.asfortranarray(q) for q in ph.primitive_to_conservative(1.1 * one, .3 * one, -.2 * one, .9 * one)]
+    r = eng.rhs(eng.upload(Qc))
+    # round-off of O(1) fluxes is amplified by 1/J = 4/(hx*hy) ~ 7e3 on this mesh
+    assert float(r.abs().max()) < 1e-11 / float(md.J.min())             # free-stream preservation
+    Qd = eng.upload(Q)
+    r = eng.rhs(Qd)
+    rh = eng.download(r)
+    wJ = md.wJq
+    scale = max(float(np.abs(wJ * (rd.Vq @ x)).sum()) for x in rh)
+    for x in rh:                                                     # discrete conservation (no penalty, quirk Q3)
+        assert abs(float((wJ * (rd.Vq @ x)).sum())) <= 1e-10 * max(scale, 1.0)   # 6.5M terms carrying ~1e-11/J round-off each
+    assert eng.rhstest(Qd, r) < 0                                    # LF + viscous dissipation: entropy decays
+    ec = E.RhsEngine(rd, md, ops, E.EULER_MODAL, inviscid_dissp=False)
+    r2 = ec.rhs(Qd)
+    assert abs(ec.rhstest(Qd, r2)) < 1e-9                            # entropy conservative without LF
+
+
+def test_rhstest_matches_oracle(E, oracle_lib):
+    from oracle import oracle as orc
+    p = orc.build_euler_problem(3, 8, 8)
+    _, rt = orc.EulerOracle(p).rhs(p.Q, .5, True)
+    rd, md, ops, Q = product_euler_problem(3, 8, 8)
+    eng = E.RhsEngine(rd, md, ops, E.EULER_COLLOCATED)
+    Qd = eng.upload(Q)
+    assert abs(eng.rhstest(Qd, eng.rhs(Qd)) - rt) < 1e-11
+
+
+def test_host_dropin_entry_points(E, oracle_lib):
+    from oracle import oracle as orc
+    p = orc.build_euler_problem(2, 5, 4)
+    Qs = steep_state(p.md.xq, p.md.yq)
+    ref, _ = orc.EulerOracle(p).rhs(Qs)
+    rd, md, ops, Q = product_euler_problem(2, 5, 4)
+    eng = E.RhsEngine(rd, md, ops, E.EULER_COLLOCATED)
+    assert rel_l2(eng.rhs_host(Qs), ref) <= 1e-11
+    out, rt = E.rhs(tuple(Qs), md, ops, None, True, rd=rd)          # reference signature rhs(Q,md,ops,flux_fun,compute_rhstest)
+    assert rel_l2(list(out), ref) <= 1e-11 and np.isfinite(rt)
+
+
+def test_lsrk45_steps_match_oracle(E, oracle_lib):
+    from esdg_cns_amd import setup_dg as sd
+    from oracle import oracle as orc
+    N, Kx, Ky = 3, 8, 8
+    p = orc.build_euler_problem(N, Kx, Ky)
+    eo = orc.EulerOracle(p)
+    rk4a, rk4b, _ = sd.rk45_coeffs()
+    dt = 2 * (2 / 8) / ((N + 1) * (N + 2) / 2) / 4
+    Qo = [q.copy() for q in p.Q]
+    res = [np.zeros_like(q) for q in Qo]
+    nsteps = 3
+    for _ in range(nsteps):                                           # dg2D_euler_quad.jl:198-207
+        for k in range(5):
+            r, _ = eo.rhs(Qo)
+            res = [rk4a[k] * a + dt * b for a, b in zip(res, r)]
+            Qo = [q + rk4b[k] * a for q, a in zip(Qo, res)]
+    rd, md, ops, Q = product_euler_problem(N, Kx, Ky)
+    eng = E.RhsEngine(rd, md, ops, E.EULER_COLLOCATED)
+    Qd, resd, rhsd = eng.upload(Q), eng.new_state(), eng.new_state()
+    for _ in range(nsteps):
+        eng.lsrk45_step(Qd, resd, rhsd, dt, (rk4a, rk4b))
+    assert rel_l2(eng.download(Qd), Qo) <= 1e-12
