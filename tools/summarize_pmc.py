@@ -1,0 +1,44 @@
+"""Summarises the FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh into profiles/pmc_traffic.json.
+
+Units and gfx950 corrections follow MI355X_MICROARCH.md section "HBM": rocprofv3 reports FETCH_SIZE / WRITE_SIZE
+in KiB; on gfx950 FETCH_SIZE counts 128-B fabric requests as 64 B for wide coalesced streaming reads (x2
+correction), WRITE_SIZE is exact for 16-B-per-lane streaming stores; other access widths are uncalibrated.
+Our kernels read the state with 8-B-per-lane coalesced loads and the traces with 16-B loads, so both the raw
+and the x2-corrected read figures are recorded and the corrected one is what bench.py reports as `traffic`."""
+import collections
+import csv
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+key = sys.argv[2] if len(sys.argv) > 2 else "cns_N4_512x512"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+f = per_kernel(os.path.join(src, "fetch_counters.csv"), "FETCH_SIZE")
+w = per_kernel(os.path.join(src, "write_counters.csv"), "WRITE_SIZE")
+out = {}
+for k in sorted(set(f) | set(w)):
+    if "esdg::" not in k:
+        continue
+    rd_raw, wr = f.get(k, 0.0) * 1024, w.get(k, 0.0) * 1024
+    out[k] = {"fetch_bytes_raw": rd_raw, "fetch_bytes_x2": 2 * rd_raw, "write_bytes": wr,
+              "hbm_bytes_per_launch": 2 * rd_raw + wr}
+dst = os.path.join(root, "profiles", "pmc_traffic.json")
+allj = json.load(open(dst)) if os.path.exists(dst) else {}
+rhs = [v for k, v in out.items() if "_rhs<" in k]
+allj[key] = {"source": f"gpurun_out/prof_{tag} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+             "kernels": out, "k_rhs_hbm_bytes_per_launch": rhs[0]["hbm_bytes_per_launch"] if rhs else None}
+json.dump(allj, open(dst, "w"), indent=1)
+for k, v in out.items():
+    print(f"{k:45s} fetch(raw) {v['fetch_bytes_raw']/1e6:9.1f} MB  x2 {v['fetch_bytes_x2']/1e6:9.1f} MB  write {v['write_bytes']/1e6:9.1f} MB")
