@@ -397,7 +397,8 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   if (mesh->K < 0 || !mesh->rxJ || !mesh->sxJ || !mesh->ryJ || !mesh->syJ || !mesh->J || !mesh->nxJ || !mesh->nyJ ||
       !mesh->sJ || !mesh->mapP)
     return fail(ESDG_ERR_ARG, "mesh arrays missing");
-  if (mesh->NmapB > 0) return fail(ESDG_ERR_ARG, "wall boundary conditions are not implemented yet (NmapB=%lld)", (long long)mesh->NmapB);
+  if (mesh->NmapB > 0 && !mesh->mapB) return fail(ESDG_ERR_ARG, "NmapB>0 but mapB is null");
+  if (mesh->NmapB > 0 && (phys->BCTYPE < 1 || phys->BCTYPE > 3)) return fail(ESDG_ERR_ARG, "BCTYPE must be 1, 2 or 3 with wall boundaries");
   if ((int64_t)mesh->K * Nfq > (int64_t)2000000000) return fail(ESDG_ERR_ARG, "too many local face nodes for int32 maps");
   if (esdg_device_count() < 1) return fail(ESDG_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
 
@@ -556,6 +557,19 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   UP(d_Dr_i, eDr.idx); UP(d_Dr_v, eDr.val); UP(d_Ds_i, eDs.idx); UP(d_Ds_v, eDs.val);
   UP(d_Vq, Vq.a); UP(d_Pq, Pq.a);
   UP(d_geo, geo); UP(d_mapP, mapP); UP(d_sendlist, sendlist);
+  // wall-boundary flags per local face node: 1 wall, 2 lid (init_BC_funs, cavity :135-155)
+  std::vector<uint8_t> bcflag;
+  if (mesh->NmapB > 0) {
+    if (!use_fast) return fail(ESDG_ERR_STRUCTURE, "wall boundary conditions need tensor-structured operators (generic kernels are periodic-only)");
+    bcflag.assign((size_t)K * Nfq, 0);
+    for (int64_t i = 0; i < mesh->NmapB; ++i) {
+      const int64_t l = mesh->mapB[i] - 1 - mesh->elem_offset * Nfq;
+      if (l < 0 || l >= K * Nfq) continue;   // boundary node of another rank
+      if (mapP[l] != l) return fail(ESDG_ERR_ARG, "mapB[%lld] is not a boundary node (mapP != mapM)", (long long)i);
+      bcflag[l] = (uint8_t)(1 + (mesh->bkind ? (mesh->bkind[i] != 0) : 0));
+    }
+    UP(d_bc, bcflag);
+  }
   if (use_fast) {
     UP(t_dbl, th.dbl); UP(t_int, th.ints);
     c->TT.dbl = c->t_dbl.as<double>();
@@ -580,7 +594,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   T.Dr_idx = c->d_Dr_i.as<uint8_t>(); T.Dr_val = c->d_Dr_v.as<double>();
   T.Ds_idx = c->d_Ds_i.as<uint8_t>(); T.Ds_val = c->d_Ds_v.as<double>(); T.wD = visc ? eDr.w : 0;
   T.Vq = c->d_Vq.as<double>(); T.Pq = c->d_Pq.as<double>();
-  c->M.K = K; c->M.geo = c->d_geo.as<double>(); c->M.mapP = c->d_mapP.as<int32_t>(); c->M.bc = nullptr;
+  c->M.K = K; c->M.geo = c->d_geo.as<double>(); c->M.mapP = c->d_mapP.as<int32_t>(); c->M.bc = bcflag.empty() ? nullptr : c->d_bc.as<uint8_t>();
   c->M.wJq = mesh->wJq ? c->d_wJq.as<double>() : nullptr;
   c->M.stamps = nullptr;
   if (c->ph.dbg & 8) {

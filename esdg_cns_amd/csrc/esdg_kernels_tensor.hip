@@ -378,11 +378,13 @@ __global__ __launch_bounds__(TW * NWV) void kt_project(TensorTables TT, MeshDev 
 // ---------------------------------------------------------------------------------------------
 // viscous building blocks (lane-mapped).  sVn: [E][3][Nq] = (v2,v3,v4) of the volume nodes (SoA: conflict-free).
 // ---------------------------------------------------------------------------------------------
-// face lanes: projected entropy variables at the face node, half jump to the neighbour, tau
+// face lanes: projected entropy variables at the face node, exterior state (neighbour, or the wall
+// boundary condition of impose_BCs_entropyvars!, cavity :178-216), half jump, penalty tau*[[v]] (:817-837)
+//   bc: 0 interior/periodic, 1 wall, 2 lid;  gn = (nxJ, nyJ, sJ) of the face;  sPn may be null (phase 1)
 template <int N1>
 __device__ __forceinline__ void visc_face_jumps(const Lane<N1>& ln, const double* sTab, const int* sInt,
-                                                const double* sVn, const double* vP, double invRe, double* sDv,
-                                                double* sTau) {
+                                                const double* sVn, const double* vPin, int bc, const double* gn,
+                                                const Phys& ph, double* sDv, double* sPn) {
   constexpr int Nq = N1 * N1, Nfq = 4 * N1;
   constexpr TensorLayout L(N1);
   int d, t, o;
@@ -396,9 +398,46 @@ __device__ __forceinline__ void visc_face_jumps(const Lane<N1>& ln, const double
     vf[1] += w * r[Nq];
     vf[2] += w * r[2 * Nq];
   }
+  double vP[3] = {vPin[0], vPin[1], vPin[2]};
+  if (bc) {
+    const double vlid = 1.0;                              // cavity :148
+    if (ph.BCTYPE == 1) {                                 // adiabatic no-slip
+      vP[0] = bc == 2 ? -vf[0] - 2 * vlid * vf[2] : -vf[0];
+      vP[1] = -vf[1];
+      vP[2] = vf[2];
+    } else if (ph.BCTYPE == 2) {                          // isothermal
+      const double theta = 1.0 / (0.3 * 0.3) / 1.4 / 0.4;
+      vP[0] = bc == 2 ? 2.0 / theta - vf[0] : -vf[0];
+      vP[1] = -vf[1];
+      vP[2] = -2.0 / theta - vf[2];
+    } else {                                              // slip / reflective
+      const double is = rcp_refined(gn[2]);
+      const double nx = gn[0] * is, ny = gn[1] * is;
+      const double vn = vf[0] * nx + vf[1] * ny;
+      vP[0] = vf[0] - 2 * vn * nx;
+      vP[1] = vf[1] - 2 * vn * ny;
+      vP[2] = vf[2];
+    }
+  }
+  double dV[3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) sDv[(ln.ef * 3 + c) * Nfq + ln.fn] = .5 * (vP[c] - vf[c]);
-  if (sTau) sTau[ln.ef * Nfq + ln.fn] = -invRe * rcp_refined(vf[2]);
+  for (int c = 0; c < 3; ++c) {
+    dV[c] = vP[c] - vf[c];
+    sDv[(ln.ef * 3 + c) * Nfq + ln.fn] = .5 * dV[c];
+  }
+  if (sPn) {
+    const double iv4 = rcp_refined(vf[2]);
+    const double tau = -iv4 / ph.Re;
+    double pn[3] = {tau * dV[0], tau * dV[1], tau * dV[2]};
+    if (bc) {   // :827-837
+      const double a2 = .5 * (vP[0] + vf[0]), a3 = .5 * (vP[1] + vf[1]);
+      double s = a2 * dV[0] + a3 * dV[1];
+      if (ph.BCTYPE != 1) s += dV[2] * dV[2] * .5;
+      pn[2] = -tau * s * iv4;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sPn[(ln.ef * 3 + c) * Nfq + ln.fn] = pn[c];
+  }
 }
 
 // volume lanes: BR1 gradient of (v2,v3,v4) at the node and sigma = K(v) grad v
@@ -451,12 +490,14 @@ __device__ __forceinline__ void visc_sigma(const Lane<N1>& ln, const double* sTa
 // face lanes: own normal stress (Ef*sigma_x)*nxJ + (Ef*sigma_y)*nyJ;  sS: [E][Nq][6]
 template <int N1>
 __device__ __forceinline__ void face_normal_stress(const Lane<N1>& ln, const double* sTab, const int* sInt,
-                                                   const double* sS, double nxJ, double nyJ, double* sn) {
+                                                   const double* sS, double nxJ, double nyJ, double* sn,
+                                                   double* fx, double* fy) {
   constexpr int Nq = N1 * N1;
   constexpr TensorLayout L(N1);
   int d, t, o;
   face_dto(sInt, L.FINV, ln.fn, d, t, o);
-  double fx[3] = {0, 0, 0}, fy[3] = {0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { fx[c] = 0.0; fy[c] = 0.0; }
 #pragma unroll
   for (int j = 0; j < N1; ++j) {
     const double w = sTab[L.EE + (d * 2 + t) * N1 + j];
@@ -510,7 +551,11 @@ __global__ __launch_bounds__(TW * NWV) void kt_sigma(TensorTables TT, MeshDev M,
     for (int c = 0; c < 3; ++c) sA[(ln.ev * 3 + c) * Nq + ln.q] = V[c + 1];
   }
   __syncthreads();
-  if (ln.fin) visc_face_jumps<N1>(ln, sTab, sInt, sA, vP, 0.0, sDv, nullptr);
+  if (ln.fin) {
+    const int64_t nn = (e0 + (factive ? ln.ef : 0)) * Nfq + ln.fn;
+    const int bc = (M.bc && factive) ? M.bc[nn] : 0;
+    visc_face_jumps<N1>(ln, sTab, sInt, sA, vP, bc, M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1), ph, sDv, nullptr);
+  }
   __syncthreads();
   if (ln.vin) {
     double sgx[3], sgy[3];
@@ -523,8 +568,8 @@ __global__ __launch_bounds__(TW * NWV) void kt_sigma(TensorTables TT, MeshDev M,
   __syncthreads();
   if (factive) {
     const double* gn = M.geo + (e0 + ln.ef) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
-    double sn[3];
-    face_normal_stress<N1>(ln, sTab, sInt, sB, gn[0], gn[1], sn);
+    double sn[3], fx[3], fy[3];
+    face_normal_stress<N1>(ln, sTab, sInt, sB, gn[0], gn[1], sn, fx, fy);
     double* bb = B + ((e0 + ln.ef) * Nfq + ln.fn) * B_NC;
     bb[0] = sn[0]; bb[1] = sn[1]; bb[2] = sn[2];
   }
@@ -538,7 +583,7 @@ struct RhsLds {
   static constexpr int Nq = N1 * N1, Nfq = 4 * N1, Nh = Nq + Nfq, E = TCfg<N1>::E;
   static constexpr int nQh = E * Nh * 6;                 // prims+logs of all hybrid nodes; also interp scratch
   static constexpr int nFlux = E * (4 * Nq + 4 * Nfq);   // sAcc + sG
-  static constexpr int nVisc = VISC ? E * (7 * Nfq + 6 * Nq) : 0;  // sDv(3) + sTau(1) + sSj(3) per face node, sS(6) per node
+  static constexpr int nVisc = VISC ? E * (9 * Nfq + 6 * Nq) : 0;  // sDv(3) + sPn(3) + sSj(3) per face node, sS(6) per node
   static constexpr int nR2 = nFlux > nVisc ? nFlux : nVisc;
   static_assert(8 * Nq <= 6 * Nh, "interp scratch must fit in the sQh region");
 };
@@ -571,11 +616,13 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
   issue_state_loads<N1>(Q, M.K, e0, vactive, x);
   double qM[8], qP[8], vPn[3] = {0, 0, 0}, bPn[3] = {0, 0, 0};
   int64_t mpk = 0;
+  int bcf = 0;
 #pragma unroll
   for (int c = 0; c < 8; ++c) { qM[c] = 1.0; qP[c] = 1.0; }
   if (factive) {
     const int64_t n = (e0 + ln.ef) * Nfq + ln.fn;
     const int64_t mp = M.mapP[n];
+    if (M.bc) bcf = M.bc[n];
     const double2* aM = reinterpret_cast<const double2*>(A_U + n * FAU_NC);
     const double2* aP = reinterpret_cast<const double2*>(A_U + mp * FAU_NC);
 #pragma unroll
@@ -610,11 +657,22 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     dq[2] = make_double2(qM[4], qM[5]);
 #pragma unroll
     for (int c = 0; c < 4; ++c) sG[(ln.ef * 4 + c) * Nfq + ln.fn] = 0.0;
+    const double* gn = M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
+    if (bcf) {   // wall: mirror state rho+ = rho, beta+ = beta, u+ = u - 2 (u.n) n  (impose_BCs_inviscid! :157-176)
+      const double is = rcp_refined(gn[2]);
+      const double nx = gn[0] * is, ny = gn[1] * is;
+      const double un = qM[1] * nx + qM[2] * ny;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) qP[c] = qM[c];
+      qP[1] = qM[1] - 2 * un * nx;
+      qP[2] = qM[2] - 2 * un * ny;
+    }
     double Fx[4], Fy[4];
     ec_flux<MODAL>(qM, qP, Fx, Fy);
-    const double* gn = M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
     const double LFc = ph.inviscid_dissp ? ph.lf_scale * fmax(qM[6], qP[6]) * gn[2] : 0.0;
-    const double dU[4] = {qP[0] - qM[0], qP[0] * qP[1] - qM[0] * qM[1], qP[0] * qP[2] - qM[0] * qM[2], qP[7] - qM[7]};
+    // LF jump uses Uf[mapP] - Uf, which vanishes at walls (mapP = self), cavity :511-513
+    double dU[4] = {qP[0] - qM[0], qP[0] * qP[1] - qM[0] * qM[1], qP[0] * qP[2] - qM[0] * qM[2], qP[7] - qM[7]};
+    if (bcf) { dU[0] = 0.0; dU[1] = 0.0; dU[2] = 0.0; dU[3] = 0.0; }
 #pragma unroll
     for (int c = 0; c < 4; ++c) flx[c] = Fx[c] * gn[0] + Fy[c] * gn[1] - LFc * dU[c];
   }
@@ -717,8 +775,8 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     __syncthreads();   // sAcc / sG are dead; sR2 becomes the viscous scratch
     double* sVn = sQh;                       // [E][3][Nq]  (v2,v3,v4): primitives no longer needed
     double* sDv = sR2;                       // [E][3][Nfq]
-    double* sTau = sDv + E * 3 * Nfq;        // [E][Nfq]
-    double* sSj = sTau + E * Nfq;            // [E][3][Nfq]
+    double* sPn = sDv + E * 3 * Nfq;         // [E][3][Nfq]  penalty tau*[[v]]
+    double* sSj = sPn + E * 3 * Nfq;         // [E][3][Nfq]
     double* sS = sSj + E * 3 * Nfq;          // [E][Nq][6]
     if (ln.vin) {
       double V[4];
@@ -727,7 +785,9 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
       for (int c = 0; c < 3; ++c) sVn[(ln.ev * 3 + c) * Nq + ln.q] = V[c + 1];
     }
     __syncthreads();
-    if (ln.fin) visc_face_jumps<N1>(ln, sTab, sInt, sVn, vPn, 1.0 / ph.Re, sDv, sTau);
+    if (ln.fin)
+      visc_face_jumps<N1>(ln, sTab, sInt, sVn, vPn, bcf, M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1),
+                          ph, sDv, sPn);
     __syncthreads();
     if (ln.vin) {
       double sgx[3], sgy[3];
@@ -742,10 +802,27 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     // its own outward normal = minus ours (dg_div! :606)
     if (ln.fin) {
       const double* gn = M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
-      double sn[3];
-      face_normal_stress<N1>(ln, sTab, sInt, sS, gn[0], gn[1], sn);
+      double sn[3], fx[3], fy[3], sj[3];
+      face_normal_stress<N1>(ln, sTab, sInt, sS, gn[0], gn[1], sn, fx, fy);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) sSj[(ln.ef * 3 + c) * Nfq + ln.fn] = .5 * (-bPn[c] - sn[c]);
+      for (int c = 0; c < 3; ++c) sj[c] = .5 * (-bPn[c] - sn[c]);
+      if (bcf) {   // impose_BCs_stress! :218-262
+        if (ph.BCTYPE == 1) {
+          sj[0] = 0.0; sj[1] = 0.0;
+          sj[2] = bcf == 2 ? -sn[2] + 1.0 * sn[0] : -sn[2];
+        } else if (ph.BCTYPE == 2) {
+          sj[0] = 0.0; sj[1] = 0.0; sj[2] = 0.0;
+        } else {
+          const double is = rcp_refined(gn[2]);
+          const double n1 = gn[0] * is, n2 = gn[1] * is;
+          const double snx = fx[0] * n1 + fx[1] * n2, sny = fy[0] * n1 + fy[1] * n2;
+          sj[0] = .5 * ((-2 * fx[0] + 2 * n1 * snx) * gn[0] + (-2 * fy[0] + 2 * n1 * sny) * gn[1]);
+          sj[1] = .5 * ((-2 * fx[1] + 2 * n2 * snx) * gn[0] + (-2 * fy[1] + 2 * n2 * sny) * gn[1]);
+          sj[2] = -sn[2];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sSj[(ln.ef * 3 + c) * Nfq + ln.fn] = sj[c];
     }
     __syncthreads();
     // divergence + penalty (dg_div! :590-611, penalty :817-845: NOT scaled by 1/J, quirk Q3)
@@ -770,11 +847,10 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
         for (int t = 0; t < 2; ++t) {
           const int f = sInt[L.FN + (d * 2 + t) * N1 + oth];
           const double lw = sTab[L.PF + (d * 2 + t) * N1 + pos] * sTab[L.PTF + (d * 2 + t) * N1 + oth] * sTab[L.WFAC + f];
-          const double tw = 2 * lw * sTau[ln.ev * Nfq + f];
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             dv[c] += lw * sSj[(ln.ev * 3 + c) * Nfq + f];
-            pn[c] += tw * sDv[(ln.ev * 3 + c) * Nfq + f];
+            pn[c] += lw * sPn[(ln.ev * 3 + c) * Nfq + f];
           }
         }
       }

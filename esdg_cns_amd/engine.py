@@ -91,7 +91,20 @@ class RhsEngine:
             setattr(m, n, _dp(keep["m_" + n]))
         keep["mapP"] = np.asfortranarray(np.asarray(md.mapP, dtype=np.int64))
         m.mapP = keep["mapP"].ctypes.data_as(_lib.c_int64_p)
-        m.mapB, m.NmapB, m.bkind = None, 0, None
+        mapB = np.asarray(getattr(md, "mapB", np.zeros(0)), dtype=np.int64)
+        if mapB.size:
+            # wall nodes; lid = boundary nodes with |y - 1| < 1e-12 (init_BC_funs, cavity_optimized.jl:139-148)
+            keep["mapB"] = np.ascontiguousarray(mapB)
+            loc = mapB - 1 - int(getattr(md, "elem_offset", 0)) * Nfq
+            inside = (loc >= 0) & (loc < md.K * Nfq)
+            yb = np.zeros(mapB.size)
+            yb[inside] = md.yf.flatten(order="F")[loc[inside]]
+            keep["bkind"] = np.ascontiguousarray(((np.abs(yb - 1) < 1e-12) & inside).astype(np.uint8))
+            m.mapB = keep["mapB"].ctypes.data_as(_lib.c_int64_p)
+            m.NmapB = int(mapB.size)
+            m.bkind = keep["bkind"].ctypes.data_as(_lib.c_uint8_p)
+        else:
+            m.mapB, m.NmapB, m.bkind = None, 0, None
         m.elem_offset = int(getattr(md, "elem_offset", 0))
         m.Kglobal = int(getattr(md, "Kglobal", md.K))
         m.nranks, m.rank = int(nranks), int(rank)

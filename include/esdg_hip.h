@@ -90,7 +90,9 @@ typedef struct {
   const double* wJq;     /* (Nq x K) -- diagnostics (rhstest) only, may be NULL */
   const double *nxJ, *nyJ, *sJ; /* (Nfq x K) */
   const int64_t* mapP;   /* (Nfq x K) 1-based GLOBAL linear index into (Nfq x Kglobal) */
-  const int64_t* mapB;   /* wall-boundary face nodes, 1-based GLOBAL linear index, may be NULL */
+  const int64_t* mapB;   /* wall-boundary face nodes (md.mapB), 1-based GLOBAL linear index, may be NULL (periodic);
+                          * walls: mirror state for the inviscid flux, BCTYPE-dependent entropy-variable and
+                          * stress traces, boundary penalty (init_BC_funs, cavity_optimized.jl:135-265, 827-837) */
   int64_t NmapB;
   const uint8_t* bkind;  /* per mapB entry: 0 = wall, 1 = lid (init_BC_funs :139-148); NULL = all wall */
   /* element-index sharding.  Single process: elem_offset=0, Kglobal=K, nranks=1. */

@@ -40,6 +40,26 @@ def product_cns_problem(N, Kx, Ky, elem_range=None):
     return rd, md, ops, Q
 
 
+def cavity_state(x, y):
+    """Smooth non-trivial low-Mach state on the [-1,1]^2 cavity (the same formula oracle.build_cns_problem uses)."""
+    rho = 1.0 + .2 * np.exp(-10 * (x ** 2 + y ** 2))
+    u = .1 * np.sin(np.pi * x) * np.cos(np.pi * y)
+    v = -.1 * np.cos(np.pi * x) * np.sin(np.pi * y)
+    p = (1 / (.3 ** 2 * ph.GAMMA)) * rho ** ph.GAMMA
+    return [np.asfortranarray(q) for q in ph.primitive_to_conservative(rho, u, v, p)]
+
+
+def product_cavity_problem(N, Kx, Ky, elem_range=None):
+    """Lid-driven-cavity mesh of examples/CompressibleNS/dg2D_CNS_cavity_optimized.jl on quads: walls on all four
+    sides (md.mapB kept), lid = the y = +1 side."""
+    VX, VY, EToV = sd.uniform_quad_mesh(Kx, Ky)
+    rd = sd.init_reference_quad(N)
+    md = sd.init_mesh((VX, VY), EToV, rd, elem_range=elem_range)
+    ops = sd.cns_ops(rd)
+    sd.interp_geofacs_to_hybrid(md, ops["Vh"])
+    return rd, md, ops, cavity_state(md.x, md.y)
+
+
 def perturb(Q, seed=20250117, amp=0.01):
     """Robustness variant of SURVEY.md section 8(d): multiply rho and E by 1 + amp*xi, xi in [-1,1)."""
     rng = np.random.default_rng(seed)
