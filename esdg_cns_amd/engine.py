@@ -93,6 +93,14 @@ class RhsEngine:
         m.mapP = keep["mapP"].ctypes.data_as(_lib.c_int64_p)
         mapB = np.asarray(getattr(md, "mapB", np.zeros(0)), dtype=np.int64)
         if mapB.size:
+            # md.mapB survives the periodic patch of the drivers (mapP[mapB] = mapPB); only nodes that still map to
+            # themselves are walls
+            locB = mapB - 1 - int(getattr(md, "elem_offset", 0)) * Nfq
+            okB = (locB >= 0) & (locB < md.K * Nfq)
+            selfmap = np.zeros(mapB.size, dtype=bool)
+            selfmap[okB] = keep["mapP"].flatten(order="F")[locB[okB]] == mapB[okB]
+            mapB = mapB[selfmap]
+        if mapB.size:
             # wall nodes; lid = boundary nodes with |y - 1| < 1e-12 (init_BC_funs, cavity_optimized.jl:139-148)
             keep["mapB"] = np.ascontiguousarray(mapB)
             loc = mapB - 1 - int(getattr(md, "elem_offset", 0)) * Nfq
