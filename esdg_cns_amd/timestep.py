@@ -1,0 +1,90 @@
+"""Device-resident time integrators: the steps either side of the RHS hot path.
+
+  lsrk45_run  <- the LSRK45 loop of examples/dg2D_euler_quad.jl:196-212 (coefficients src/CommonUtils.jl:29-49)
+  Dopri45     <- the adaptive Dormand-Prince loop of examples/CompressibleNS/dg2D_CNS_cavity_optimized.jl:974-1053
+                 (tableau :919-934, Hairer error norm :1014-1021, P/PI step-size controller :1027-1037)
+
+The state never leaves the GPU: stage combinations and the error norm run in libesdg_hip
+(esdg_lsrk_update / esdg_axpy_stages / esdg_dopri_error).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import setup_dg as sd
+from ._lib import check
+
+
+def lsrk45_run(eng, Qd, dt, nsteps, rhstest_every=0):
+    """Nsteps LSRK45 steps; returns the last rhstest if rhstest_every > 0 (computed on stage 5 like the driver)."""
+    rk4a, rk4b, _ = sd.rk45_coeffs()
+    resd = torch.zeros_like(Qd)
+    rhsd = torch.empty_like(Qd)
+    rt = 0.0
+    for i in range(1, nsteps + 1):
+        for k in range(5):
+            eng.rhs_into(Qd, rhsd)
+            if rhstest_every and k == 4 and (i % rhstest_every == 0 or i == nsteps):
+                rt = eng.rhstest(Qd, rhsd)
+            eng.lsrk_update(Qd, resd, rhsd, rk4a[k], rk4b[k], dt)
+    return rt
+
+
+class Dopri45:
+    """Adaptive DOPRI45 with FSAL exactly as the CNS drivers run it."""
+
+    def __init__(self, eng, Qd, dt0, err_tol=1e-5):
+        self.eng, self.Q, self.dt, self.dt0, self.tol = eng, Qd, float(dt0), float(dt0), float(err_tol)
+        self.rka, self.rkE, self.rkc = sd.dopri45_coeffs()
+        self.k = [torch.zeros_like(Qd) for _ in range(7)]
+        self.Qtmp = torch.empty_like(Qd)
+        self.t, self.i, self.prev_err = 0.0, 0, 0.0
+        self.n_rhs = 0
+        eng.rhs_into(Qd, self.k[0])                     # initialise the FSAL slot (:997-998)
+        self.n_rhs += 1
+
+    def _ptrs(self, tensors):
+        return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    def step(self):
+        """One attempted step; returns (accepted, errEst)."""
+        eng, L = self.eng, self.eng.L
+        n = self.Q.numel()
+        s = eng._stream()
+        for INTRK in range(1, 7):                       # stages 2..7 (:1002-1012)
+            coef = (C.c_double * INTRK)(*[float(self.rka[INTRK, j]) for j in range(INTRK)])
+            check(L.esdg_axpy_stages(C.c_void_p(self.Qtmp.data_ptr()), C.c_void_p(self.Q.data_ptr()),
+                                     self._ptrs(self.k[:INTRK]), coef, INTRK, self.dt, n, s))
+            eng.rhs_into(self.Qtmp, self.k[INTRK])
+            self.n_rhs += 1
+        coefE = (C.c_double * 7)(*[float(x) for x in self.rkE])
+        acc = C.c_double(0.0)
+        check(L.esdg_dopri_error(C.c_void_p(self.Q.data_ptr()), self._ptrs(self.k), coefE, 7, self.tol, n, C.byref(acc), s))
+        if self.eng.nranks > 1:
+            import torch.distributed as dist
+            t = torch.tensor([acc.value], dtype=torch.float64, device=self.Q.device)
+            dist.all_reduce(t)
+            acc.value = float(t.item())
+            n_glob = torch.tensor([float(n)], dtype=torch.float64, device=self.Q.device)
+            dist.all_reduce(n_glob)
+            n = int(n_glob.item())
+        err = math.sqrt(acc.value / n)                  # sqrt(sum/(length(Q[1])*4)) (:1021)
+        accepted = err < 1.0
+        if accepted:
+            self.Q.copy_(self.Qtmp)
+            self.t += self.dt
+            self.k[0], self.k[6] = self.k[6], self.k[0]  # FSAL (:1025)
+        order = 5
+        dtnew = .8 * self.dt * (.9 / err) ** (.4 / (order + 1))
+        if self.i > 0:
+            dtnew *= (self.prev_err / max(1e-14, err)) ** (.3 / (order + 1))
+        self.dt = max(min(10 * self.dt0, dtnew), 1e-9)
+        self.prev_err = err
+        self.i += 1
+        return accepted, err
+
+    def run(self, T, max_steps=10 ** 9):
+        while self.t < T and self.i < max_steps:
+            self.step()
+        return self.t

@@ -1,0 +1,74 @@
+"""The steps either side of the hot path on the GPU: the transliterated Euler-quad driver
+(LSRK45, vortex L2 error, invariant (5): order N+1 convergence) and the DOPRI45 loop of the CNS drivers against
+the same loop driven by the oracle."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from common import product_cns_problem, rel_l2
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "examples"))
+
+
+def test_euler_quad_driver_converges_at_order_N_plus_1():
+    import dg2D_euler_quad as drv
+    N = 3
+    e1, rt1 = drv.run(N=N, K1D=6, T=0.5, verbose=False)
+    e2, rt2 = drv.run(N=N, K1D=12, T=0.5, verbose=False)
+    rate = math.log2(e1 / e2)
+    print(f"vortex L2 error N={N}: K1D=6 {e1:.3e}, K1D=12 {e2:.3e}, rate {rate:.2f}")
+    assert e2 < e1 and rate > N + 0.3                       # dg2D_euler_quad.jl:218-233 error functional
+    assert rt2 <= 1e-12                                     # LF penalty on: entropy dissipative (:186-191)
+
+
+def test_dopri45_loop_matches_oracle_driven_loop(oracle_lib):
+    from esdg_cns_amd import engine, setup_dg as sd, timestep
+    from oracle import oracle as orc
+    N, Kx, Ky = 2, 6, 6
+    p = orc.build_cns_problem(N, Kx, Ky, bc="periodic")
+    co = orc.CnsOracle(p)
+    rka, rkE, _ = sd.dopri45_coeffs()
+    dt0 = 0.5 * (2 / Kx) / ((N + 1) * (N + 2) / 2)
+    # oracle-driven restatement of dg2D_CNS_cavity_optimized.jl:997-1037
+    Q = [q.copy() for q in p.Q]
+    k = [None] * 7
+    k[0] = co.rhsRK(Q, False)[0]
+    dt, prev, t, hist = dt0, 0.0, 0.0, []
+    for i in range(6):
+        for s in range(1, 7):
+            Qt = [q + dt * sum(rka[s, j] * k[j][f] for j in range(s)) for f, q in enumerate(Q)]
+            k[s] = co.rhsRK(Qt, False)[0]
+        err = 0.0
+        for f in range(4):
+            e = sum(rkE[j] * k[j][f] for j in range(7))
+            err += np.sum((np.abs(e) / (1e-5 * (1 + np.abs(Q[f])))) ** 2)
+        err = math.sqrt(err / (Q[0].size * 4))
+        if err < 1.0:
+            Q, t, k[0] = Qt, t + dt, k[6]
+        dtn = .8 * dt * (.9 / err) ** (.4 / 6)
+        if i > 0:
+            dtn *= (prev / max(1e-14, err)) ** (.3 / 6)
+        dt, prev = max(min(10 * dt0, dtn), 1e-9), err
+        hist.append((err, dt))
+    rd, md, ops, Qp = product_cns_problem(N, Kx, Ky)
+    eng = engine.RhsEngine(rd, md, ops, engine.CNS_MODAL, Re=p.Re, mu=p.mu, lam=p.lam, Pr=p.Pr)
+    Qd = eng.upload(Qp)
+    integ = timestep.Dopri45(eng, Qd, dt0)
+    for i in range(6):
+        ok, err = integ.step()
+        assert abs(err - hist[i][0]) <= 1e-8 * max(1.0, hist[i][0]) and abs(integ.dt - hist[i][1]) <= 1e-9 * hist[i][1]
+    # the step sizes follow from the error estimates (agreeing to ~1e-10 relative), so t and Q agree to that level
+    assert abs(integ.t - t) < 1e-9 and rel_l2(eng.download(Qd), Q) <= 1e-9
+
+
+def test_cavity_driver_runs_all_wall_types():
+    import dg2D_CNS_quad as drv
+    for bct in (1, 2, 3):
+        Q, integ = drv.run("cavity", N=2, K1D=6, T=0.02, BCTYPE=bct, verbose=False)
+        assert integ.t >= 0.02 and all(np.isfinite(q).all() for q in Q)
+        assert np.abs(Q[1]).max() > 0 if bct != 3 else True      # the lid drags the fluid (no-slip types)
