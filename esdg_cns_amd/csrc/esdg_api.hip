@@ -729,6 +729,13 @@ int esdg_rhs_host(esdg_ctx* ctx, const double* const Q[4], double* const rhs[4])
   return ESDG_OK;
 }
 
+/* diagnostic: the kernels' own logarithm on device arrays (accuracy test) */
+int esdg_debug_log(const double* x_dev, double* y_dev, int64_t n, void* stream) {
+  int rc = launch_log_test(x_dev, y_dev, n, static_cast<hipStream_t>(stream));
+  if (rc) return fail(ESDG_ERR_NO_DEVICE, "log test launch failed");
+  return ESDG_OK;
+}
+
 /* diagnostic: read back the s_memtime section stamps (ESDG_DBG & 8) */
 int esdg_debug_stamps(esdg_ctx* ctx, unsigned long long* out, int n) {
   if (!ctx || !ctx->M.stamps || n > 4096 * 16) return fail(ESDG_ERR_STATE, "stamps not enabled");

@@ -86,5 +86,6 @@ int launch_axpy_stages(double* y, const double* x0, const double* const* k, cons
 int launch_dopri_err(const double* Q, const double* const* k, const double* coefE, int ns, double tol, int64_t n,
                      double* partial, int nblocks, hipStream_t s);
 bool supported_degree(int N1);
+int launch_log_test(const double* x, double* y, int64_t n, hipStream_t s);
 
 }  // namespace esdg

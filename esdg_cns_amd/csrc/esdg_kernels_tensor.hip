@@ -50,6 +50,28 @@ __device__ __forceinline__ double rcp_refined(double x) {
   return __builtin_fma(r, e, r);
 }
 
+// Natural logarithm for positive normal doubles: fdlibm's e_log.c algorithm (argument reduction to
+// [sqrt(1/2), sqrt(2)), s = f/(2+f), degree-14 even polynomial; error < 1 ulp) on v_frexp_* and one refined
+// v_rcp_f64: ~40 VALU instructions instead of the ~100 of the device-library log (its double-double
+// path).  Five logs per face/volume lane made the library log 2/3 of the phase-0 kernel.
+__device__ __forceinline__ double log_pos(double x) {
+  double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? m + m : m;
+  e = lo ? e - 1 : e;
+  const double f = m - 1.0;
+  const double s = f * rcp_refined(2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+  const double t2 = z * (6.666666666666735130e-01 +
+                         w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)e;
+  return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+
 __device__ __forceinline__ void lds_add(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -106,8 +128,8 @@ __device__ __forceinline__ void prim_logs(const double* U, double* q) {
   q[1] = U[1] * ir;
   q[2] = U[2] * ir;
   q[3] = (U[0] * U[0]) * (U[0] * R) * (1.0 / (2 * GM1));   // rho/(2 GM1 rhoe) = rho^3 R /(2 GM1)
-  q[4] = log(U[0]);
-  q[5] = log(q[3]);
+  q[4] = log_pos(U[0]);
+  q[5] = log_pos(q[3]);
 }
 
 // entropy variables from primitives + logs (identities of euler_variables.jl:79-92)
@@ -129,7 +151,7 @@ __device__ __forceinline__ void u_of_v(const double* V, double* U) {
   const double vUnorm = V[1] * V[1] + V[2] * V[2];
   const double h = vUnorm * .5 * rcp_refined(V[3]);
   const double s = 1.4 - V[0] + h;
-  const double rhoeV = exp((log(GM1) - 1.4 * log(-V[3]) - s) * (1.0 / GM1));
+  const double rhoeV = exp((log(GM1) - 1.4 * log_pos(-V[3]) - s) * (1.0 / GM1));
   U[0] = rhoeV * (-V[3]);
   U[1] = rhoeV * V[1];
   U[2] = rhoeV * V[2];
@@ -731,11 +753,19 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
         ec_flux<MODAL>(qh, qj, Fx, Fy);
         const double cx = cw * gx, cy = cw * gy;
         double* tgt = sG + ln.ev * 4 * Nfq + f;
+        double vv[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const double v = cx * Fx[c] + cy * Fy[c];
-          acc[c] += v;
-          lds_add(tgt + c * Nfq, -v);
+          vv[c] = cx * Fx[c] + cy * Fy[c];
+          acc[c] += vv[c];
+        }
+        // all N1 lanes of the line add into the same face node: rotate the field order by the lane's
+        // position so that one ds_add_f64 instruction hits (almost) distinct addresses instead of N1 equal ones
+        const int rot = pos & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const double w = rot == 0 ? vv[i] : (rot == 1 ? vv[(i + 1) & 3] : (rot == 2 ? vv[(i + 2) & 3] : vv[(i + 3) & 3]));
+          lds_add(tgt + ((i + rot) & 3) * Nfq, -w);
         }
       }
     }
@@ -864,6 +894,16 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
   }
   __syncthreads();   // sQh is dead: it becomes the Pq scratch
   store_rhs_from_quad<N1, MODAL>(ln, sTab, rhs, M.K, e0, vactive, sQh, sQh + E * 4 * Nq, R);
+}
+
+__global__ void kt_log_test(const double* __restrict__ x, double* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = tdev::log_pos(x[i]);
+}
+
+int launch_log_test(const double* x, double* y, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(kt_log_test, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n);
+  return (int)hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
