@@ -647,7 +647,7 @@ int esdg_bind_workspace(esdg_ctx* ctx, void* dev_ptr, size_t bytes) {
 int esdg_num_phases(const esdg_ctx* ctx) { return ctx ? ctx->nphases : 0; }
 int esdg_uses_tensor_kernels(const esdg_ctx* ctx) { return ctx ? (int)ctx->use_fast : 0; }
 
-int esdg_rhs_phase(esdg_ctx* ctx, int phase, const double* Q, double* rhs, void* stream) {
+static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs, const LsrkFuse& lf, void* stream) {
   if (!ctx || !Q) return fail(ESDG_ERR_ARG, "null argument");
   if (!ctx->ws) return fail(ESDG_ERR_STATE, "workspace not bound (esdg_bind_workspace)");
   if (phase < 0 || phase >= ctx->nphases) return fail(ESDG_ERR_ARG, "bad phase %d", phase);
@@ -670,11 +670,35 @@ int esdg_rhs_phase(esdg_ctx* ctx, int phase, const double* Q, double* rhs, void*
                        : launch_sigma(ctx->T, ctx->M, ctx->ph, Q, A_v, B, s);
     if (!rc && ctx->nsend) rc = launch_pack(B, B_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[2].send_off), s);
   } else {
-    if (!rhs) return fail(ESDG_ERR_ARG, "rhs output is null");
-    rc = ctx->use_fast ? launch_rhs_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, A_v, B, rhs, s)
+    if (!rhs && !lf.Qw) return fail(ESDG_ERR_ARG, "rhs output is null");
+    if (lf.Qw && !ctx->use_fast) return fail(ESDG_ERR_STATE, "the fused RK update needs the tensor kernels");
+    rc = ctx->use_fast ? launch_rhs_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, A_v, B, rhs, lf, s)
                        : launch_rhs(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, B, rhs, s);
   }
   if (rc) return fail(ESDG_ERR_NO_DEVICE, "kernel launch failed in phase %d: %s", phase, hipGetErrorString((hipError_t)rc));
+  return ESDG_OK;
+}
+
+int esdg_rhs_phase(esdg_ctx* ctx, int phase, const double* Q, double* rhs, void* stream) {
+  const LsrkFuse none{nullptr, nullptr, 0.0, 0.0, 0.0};
+  return rhs_phase_impl(ctx, phase, Q, rhs, none, stream);
+}
+
+int esdg_rhs_phase_lsrk(esdg_ctx* ctx, int phase, double* Q, double* resQ, double a, double b, double dt, void* stream) {
+  if (!resQ) return fail(ESDG_ERR_ARG, "null argument");
+  const LsrkFuse lf{Q, resQ, a, b, dt};
+  const LsrkFuse none{nullptr, nullptr, 0.0, 0.0, 0.0};
+  const bool last = ctx && phase == ctx->nphases - 1;
+  return rhs_phase_impl(ctx, phase, Q, nullptr, last ? lf : none, stream);
+}
+
+int esdg_rhs_lsrk(esdg_ctx* ctx, double* Q, double* resQ, double a, double b, double dt, void* stream) {
+  if (!ctx) return fail(ESDG_ERR_ARG, "null ctx");
+  if (ctx->nghost) return fail(ESDG_ERR_STATE, "mesh is sharded: drive esdg_rhs_phase_lsrk + halo exchange from the host");
+  for (int p = 0; p < ctx->nphases; ++p) {
+    int rc = esdg_rhs_phase_lsrk(ctx, p, Q, resQ, a, b, dt, stream);
+    if (rc) return rc;
+  }
   return ESDG_OK;
 }
 

@@ -50,8 +50,10 @@ int launch_project_tensor(int N1, const TensorTables& TT, const MeshDev& M, cons
                           double* A_U, double* A_v, hipStream_t s);
 int launch_sigma_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
                         const double* A_v, double* B, hipStream_t s);
+struct LsrkFuse;
 int launch_rhs_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
-                      const double* A_U, const double* A_v, const double* B, double* rhs, hipStream_t s);
+                      const double* A_U, const double* A_v, const double* B, double* rhs, const LsrkFuse& lf,
+                      hipStream_t s);
 
 struct MeshDev {
   int64_t K;               // local elements
@@ -60,6 +62,14 @@ struct MeshDev {
   const uint8_t* bc;       // [K][Nfq]  0 interior/periodic, 1 wall, 2 lid; may be null (no walls)
   const double* wJq;       // [K][Nq] (diagnostics) may be null
   unsigned long long* stamps;  // diagnostic builds only (ESDG_DBG & 8): [4096][16] s_memtime deltas
+};
+
+// optional fusion of the low-storage RK update into the last phase (esdg_rhs_lsrk):
+//   res = a*res + dt*rhs ; Q += b*res   instead of storing rhs   (dg2D_euler_quad.jl:204-205)
+struct LsrkFuse {
+  double* Qw;   // the state, updated in place (null = plain rhs store)
+  double* res;
+  double a, b, dt;
 };
 
 struct Phys {

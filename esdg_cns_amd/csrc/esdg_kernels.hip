@@ -620,9 +620,9 @@ __global__ void k_pack(const double* __restrict__ src, int ncomp, const int32_t*
 __global__ void k_lsrk(double* __restrict__ Q, double* __restrict__ resQ, const double* __restrict__ rhs, double a,
                        double b, double dt, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const double r = a * resQ[i] + dt * rhs[i];
+    const double r = __builtin_fma(a, resQ[i], dt * rhs[i]);   // same rounding sequence as the fused form in kt_rhs
     resQ[i] = r;
-    Q[i] += b * r;
+    Q[i] = __builtin_fma(b, r, Q[i]);
   }
 }
 

@@ -281,8 +281,8 @@ __device__ __forceinline__ void state_at_quad(const Lane<N1>& ln, const double* 
 // out = (IP (x) IP) R by sum factorisation, then the coalesced store
 template <int N1, bool MODAL>
 __device__ __forceinline__ void store_rhs_from_quad(const Lane<N1>& ln, const double* sTab, double* __restrict__ rhs,
-                                                    int64_t K, int64_t e0, bool active, double* sA, double* sB,
-                                                    const double* R) {
+                                                    const LsrkFuse& lf, int64_t K, int64_t e0, bool active, double* sA,
+                                                    double* sB, const double* R) {
   constexpr int Nq = N1 * N1;
   constexpr TensorLayout L(N1);
   double out[4];
@@ -318,7 +318,16 @@ __device__ __forceinline__ void store_rhs_from_quad(const Lane<N1>& ln, const do
   }
   if (active) {
 #pragma unroll
-    for (int f = 0; f < 4; ++f) rhs[(int64_t)f * K * Nq + e0 * Nq + (threadIdx.x & (TW - 1))] = out[f];
+    for (int f = 0; f < 4; ++f) {
+      const int64_t idx = (int64_t)f * K * Nq + e0 * Nq + (threadIdx.x & (TW - 1));
+      if (lf.Qw) {   // fused low-storage RK stage
+        const double r = __builtin_fma(lf.a, lf.res[idx], lf.dt * out[f]);
+        lf.res[idx] = r;
+        lf.Qw[idx] = __builtin_fma(lf.b, r, lf.Qw[idx]);
+      } else {
+        rhs[idx] = out[f];
+      }
+    }
   }
 }
 
@@ -611,9 +620,9 @@ struct RhsLds {
 };
 
 template <int N1, bool MODAL, bool VISC>
-__global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
+__global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, Phys ph, const double* Q,
                                              const double* __restrict__ A_U, const double* __restrict__ A_v,
-                                             const double* __restrict__ B, double* __restrict__ rhs) {
+                                             const double* __restrict__ B, double* rhs, LsrkFuse lf) {
   using LD = RhsLds<N1, VISC>;
   constexpr int Nq = LD::Nq, Nfq = LD::Nfq, Nh = LD::Nh, E = LD::E, NF = N1 / 2;
   constexpr TensorLayout L(N1);
@@ -893,7 +902,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     }
   }
   __syncthreads();   // sQh is dead: it becomes the Pq scratch
-  store_rhs_from_quad<N1, MODAL>(ln, sTab, rhs, M.K, e0, vactive, sQh, sQh + E * 4 * Nq, R);
+  store_rhs_from_quad<N1, MODAL>(ln, sTab, rhs, lf, M.K, e0, vactive, sQh, sQh + E * 4 * Nq, R);
 }
 
 __global__ void kt_log_test(const double* __restrict__ x, double* __restrict__ y, int64_t n) {
@@ -950,18 +959,19 @@ int launch_sigma_tensor(int N1v, const TensorTables& TT, const MeshDev& M, const
 }
 
 int launch_rhs_tensor(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
-                      const double* A_U, const double* A_v, const double* B, double* rhs, hipStream_t s) {
+                      const double* A_U, const double* A_v, const double* B, double* rhs, const LsrkFuse& lf,
+                      hipStream_t s) {
   if (M.K == 0) return 0;
   const bool modal = ph.formulation != 0, visc = ph.formulation == 1;
   ESDG_DISPATCH_N1(N1v, {
     constexpr int E = TCfg<N1>::E;
     const int nb = (int)((M.K + (int64_t)E * NWV - 1) / ((int64_t)E * NWV));
     if (!modal)
-      hipLaunchKernelGGL((kt_rhs<N1, false, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs);
+      hipLaunchKernelGGL((kt_rhs<N1, false, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs, lf);
     else if (visc)
-      hipLaunchKernelGGL((kt_rhs<N1, true, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs);
+      hipLaunchKernelGGL((kt_rhs<N1, true, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs, lf);
     else
-      hipLaunchKernelGGL((kt_rhs<N1, true, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs);
+      hipLaunchKernelGGL((kt_rhs<N1, true, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs, lf);
   });
   return (int)hipGetLastError();
 }

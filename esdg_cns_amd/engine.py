@@ -225,6 +225,27 @@ class RhsEngine:
         check(self.L.esdg_lsrk_update(C.c_void_p(Qd.data_ptr()), C.c_void_p(resd.data_ptr()), C.c_void_p(rhsd.data_ptr()),
                                       float(a), float(b), float(dt), Qd.numel(), self._stream()))
 
+    def rhs_lsrk_fused(self, Qd, resd, a, b, dt):
+        """RHS + low-storage RK stage in one pass: resQ = a*resQ + dt*rhs(Q); Q += b*resQ (no rhs array)."""
+        L, ctx, s = self.L, self.ctx, self._stream()
+        if self.halo is None:
+            check(L.esdg_rhs_lsrk(ctx, C.c_void_p(Qd.data_ptr()), C.c_void_p(resd.data_ptr()), float(a), float(b), float(dt), s))
+            return
+        pending = {}
+        for ph in range(self.nphases):
+            for x, (aft, bef, _) in enumerate(self.xinfo):
+                if bef == ph and x in pending:
+                    HaloExchanger.wait(pending.pop(x))
+            check(L.esdg_rhs_phase_lsrk(ctx, ph, C.c_void_p(Qd.data_ptr()), C.c_void_p(resd.data_ptr()), float(a), float(b), float(dt), s))
+            for x, (aft, bef, _) in enumerate(self.xinfo):
+                if aft == ph:
+                    pending[x] = self.halo.start(self.ws, x)
+
+    def lsrk45_step_fused(self, Qd, resd, dt, coeffs):
+        rk4a, rk4b = coeffs[0], coeffs[1]
+        for k in range(5):
+            self.rhs_lsrk_fused(Qd, resd, rk4a[k], rk4b[k], dt)
+
     def lsrk45_step(self, Qd, resd, rhsd, dt, coeffs):
         """for INTRK = 1:5: rhs; resQ = rk4a*resQ + dt*rhs; Q += rk4b*resQ  (euler_quad.jl:200-206)."""
         rk4a, rk4b = coeffs[0], coeffs[1]

@@ -20,12 +20,19 @@ def lsrk45_run(eng, Qd, dt, nsteps, rhstest_every=0):
     """Nsteps LSRK45 steps; returns the last rhstest if rhstest_every > 0 (computed on stage 5 like the driver)."""
     rk4a, rk4b, _ = sd.rk45_coeffs()
     resd = torch.zeros_like(Qd)
-    rhsd = torch.empty_like(Qd)
+    rhsd = None
+    fused = bool(eng.L.esdg_uses_tensor_kernels(eng.ctx))   # RHS + stage update in one pass, no rhs array
     rt = 0.0
     for i in range(1, nsteps + 1):
         for k in range(5):
+            want_rt = rhstest_every and k == 4 and (i % rhstest_every == 0 or i == nsteps)
+            if fused and not want_rt:
+                eng.rhs_lsrk_fused(Qd, resd, rk4a[k], rk4b[k], dt)
+                continue
+            if rhsd is None:
+                rhsd = torch.empty_like(Qd)
             eng.rhs_into(Qd, rhsd)
-            if rhstest_every and k == 4 and (i % rhstest_every == 0 or i == nsteps):
+            if want_rt:
                 rt = eng.rhstest(Qd, rhsd)
             eng.lsrk_update(Qd, resd, rhsd, rk4a[k], rk4b[k], dt)
     return rt

@@ -137,6 +137,15 @@ int esdg_uses_tensor_kernels(const esdg_ctx* ctx);
 int esdg_rhs_phase(esdg_ctx* ctx, int phase, const double* Q_dev, double* rhs_dev, void* stream);
 int esdg_rhs(esdg_ctx* ctx, const double* Q_dev, double* rhs_dev, void* stream);
 
+/* RHS evaluation fused with the low-storage RK stage that consumes it (dg2D_euler_quad.jl:200-206):
+ *   rhs = RHS(Q);  resQ = a*resQ + dt*rhs;  Q += b*resQ
+ * The last phase updates Q and resQ in place and never writes rhs to memory (saves five full-state sweeps per
+ * stage).  Tensor kernels only (ESDG_ERR_STATE otherwise); esdg_rhs_phase_lsrk is the per-phase form for
+ * sharded meshes (non-final phases behave exactly like esdg_rhs_phase). */
+int esdg_rhs_lsrk(esdg_ctx* ctx, double* Q_dev, double* resQ_dev, double a, double b, double dt, void* stream);
+int esdg_rhs_phase_lsrk(esdg_ctx* ctx, int phase, double* Q_dev, double* resQ_dev, double a, double b, double dt,
+                        void* stream);
+
 /* Entropy-production diagnostics returned by the reference beside rhsQ:
  * diag[0] = rhstest = sum(wJq .* v(u) .* rhs)   (euler_quad.jl:186-191, cavity_optimized.jl:958-966)
  * Device-side reduction, synchronises `stream`.  Local elements only (all-reduce across ranks

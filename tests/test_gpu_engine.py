@@ -156,3 +156,17 @@ def test_lsrk45_steps_match_oracle(E, oracle_lib):
     for _ in range(nsteps):
         eng.lsrk45_step(Qd, resd, rhsd, dt, (rk4a, rk4b))
     assert rel_l2(eng.download(Qd), Qo) <= 1e-12
+
+
+def test_fused_lsrk_stage_is_bitwise_the_unfused_one(E):
+    from esdg_cns_amd import setup_dg as sd
+    rd, md, ops, Q = product_cns_problem(4, 10, 9)
+    eng = E.RhsEngine(rd, md, ops, E.CNS_MODAL)
+    rk = sd.rk45_coeffs()
+    dt = 1e-3
+    Qa, ra, rhs = eng.upload(Q), eng.new_state(), eng.new_state()
+    Qb, rb = eng.upload(Q), eng.new_state()
+    for _ in range(2):
+        eng.lsrk45_step(Qa, ra, rhs, dt, rk)
+        eng.lsrk45_step_fused(Qb, rb, dt, rk)
+    assert torch.equal(Qa, Qb) and torch.equal(ra, rb)
