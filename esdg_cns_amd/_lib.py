@@ -25,6 +25,19 @@ class esdg_mesh_t(C.Structure):
                 ("rank_offsets", c_int64_p)]
 
 
+class esdg_hex_ops_t(C.Structure):
+    _fields_ = [("N", C.c_int32), ("Nq", C.c_int32), ("Nfq", C.c_int32)] + [
+        (n, c_double_p) for n in ("Qrhskew", "Qshskew", "Qthskew", "Ph", "Lf", "Ef", "wq", "wf")]
+
+
+class esdg_hex_mesh_t(C.Structure):
+    _fields_ = ([("K", C.c_int64), ("geo_ld", C.c_int32)]
+                + [(n, c_double_p) for n in ("rxJ", "sxJ", "txJ", "ryJ", "syJ", "tyJ", "rzJ", "szJ", "tzJ", "J", "wJq",
+                                             "nxJ", "nyJ", "nzJ", "sJ")]
+                + [("mapP", c_int64_p), ("elem_offset", C.c_int64), ("Kglobal", C.c_int64), ("nranks", C.c_int32),
+                   ("rank", C.c_int32), ("rank_offsets", c_int64_p)])
+
+
 class esdg_phys_t(C.Structure):
     _fields_ = [("formulation", C.c_int32), ("lf_scale", C.c_double), ("inviscid_dissp", C.c_int32),
                 ("viscous_dissp", C.c_int32), ("BCTYPE", C.c_int32), ("Re", C.c_double), ("mu", C.c_double),
@@ -37,6 +50,8 @@ _szp = C.POINTER(C.c_size_t)
 _i32p = C.POINTER(C.c_int32)
 SYMBOLS = {
     "esdg_create": (C.c_int, [C.POINTER(esdg_ops_t), C.POINTER(esdg_mesh_t), C.POINTER(esdg_phys_t), C.POINTER(_vp)]),
+    "esdg_create_hex": (C.c_int, [C.POINTER(esdg_hex_ops_t), C.POINTER(esdg_hex_mesh_t), C.POINTER(esdg_phys_t), C.POINTER(_vp)]),
+    "esdg_num_fields": (C.c_int, [_vp]),
     "esdg_destroy": (C.c_int, [_vp]),
     "esdg_last_error": (C.c_char_p, []),
     "esdg_version": (C.c_char_p, []),

@@ -20,6 +20,7 @@
 #include "../../include/esdg_hip.h"
 #include "esdg_dev.hpp"
 #include "esdg_tensor_tables.hpp"
+#include "esdg_hex_tables.hpp"
 
 using namespace esdg;
 
@@ -266,6 +267,106 @@ bool build_tensor_host(int N1, const Mat& Qr, const Mat& Qs, const Mat& PhC, con
   return true;
 }
 
+// Host image of the hexahedral 1D tables (esdg_hex_tables.hpp), derived from the dense matrices of the driver
+// (Qrhskew/Qshskew/Qthskew, Ph, Lf, Ef of dg3D_euler_hex.jl:34-98) and verified entry by entry (1e-11).
+struct HexHost {
+  int op[3] = {0, 1, 2};
+  std::vector<double> dbl;
+  std::vector<int32_t> ints;
+};
+
+bool build_hex_host(int N1, const Mat* Q3, const Mat& Ph, const Mat& Lf, const Mat& Ef, HexHost& H, std::string& why) {
+  const int NN = N1 * N1, Nq = NN * N1, Nfq = 6 * NN, Nh = Nq + Nfq;
+  const double TOL = 1e-11;
+  const HexLayout L(N1);
+  H.dbl.assign(L.NDBL, 0.0);
+  H.ints.assign(L.NINT, 0);
+  auto nz = [](double x) { return std::fabs(x) > DROPTOL; };
+  auto node = [&](int d, int i, int o) { return hex_node_rt(N1, d, i, o); };
+  Mat RQ[3] = {Mat(Nq, Nh), Mat(Nq, Nh), Mat(Nq, Nh)}, RP(Nq, Nh), RE(Nfq, Nq);
+  std::vector<int> face_seen(Nfq, 0);
+  bool op_used[3] = {false, false, false};
+  for (int d = 0; d < 3; ++d) {
+    const int n0 = node(d, 0, 0), n1 = node(d, 1, 0);
+    int op = -1, cnt = 0;
+    for (int m = 0; m < 3; ++m)
+      if (nz(Q3[m](n0, n1))) { op = m; ++cnt; }
+    if (cnt != 1 || op_used[op]) { why = "lines of the Gauss nodes do not select one SBP operator each"; return false; }
+    op_used[op] = true;
+    H.op[d] = op;
+    const Mat& Q = Q3[op];
+    const double ref = Q(n0, n1);
+    for (int o = 0; o < NN; ++o) H.dbl[L.WT + d * NN + o] = Q(node(d, 0, o), node(d, 1, o)) / ref;
+    for (int i = 0; i < N1; ++i)
+      for (int j = 0; j < N1; ++j) H.dbl[L.S + (d * N1 + i) * N1 + j] = Q(node(d, i, 0), node(d, j, 0));
+    for (int o = 0; o < NN; ++o)
+      for (int i = 0; i < N1; ++i)
+        for (int j = 0; j < N1; ++j)
+          RQ[op](node(d, i, o), node(d, j, o)) += H.dbl[L.S + (d * N1 + i) * N1 + j] * H.dbl[L.WT + d * NN + o];
+    for (int o = 0; o < NN; ++o) {
+      std::vector<int> fs;
+      for (int f = 0; f < Nfq; ++f) {
+        bool hit = false;
+        for (int i = 0; i < N1; ++i) hit = hit || nz(Q(node(d, i, o), Nq + f));
+        if (hit) fs.push_back(f);
+      }
+      if (fs.size() != 2) { why = "a line of Gauss nodes does not end in exactly two face nodes"; return false; }
+      for (int t = 0; t < 2; ++t) {
+        H.ints[L.FN + (d * 2 + t) * NN + o] = fs[t];
+        if (face_seen[fs[t]]++) { why = "face node shared by two lines"; return false; }
+        H.ints[L.FINV + fs[t]] = d | (t << 2) | (o << 3);
+      }
+    }
+    for (int t = 0; t < 2; ++t) {
+      auto fn = [&](int o) { return H.ints[L.FN + (d * 2 + t) * NN + o]; };
+      const int b = (d * 2 + t);
+      int ip = 0, ipp = 0;
+      for (int i = 0; i < N1; ++i) {
+        H.dbl[L.SF + b * N1 + i] = Q(node(d, i, 0), Nq + fn(0));
+        H.dbl[L.PF + b * N1 + i] = Ph(node(d, i, 0), Nq + fn(0));
+        H.dbl[L.EE + b * N1 + i] = Ef(fn(0), node(d, i, 0));
+        if (std::fabs(H.dbl[L.SF + b * N1 + i]) > std::fabs(H.dbl[L.SF + b * N1 + ip])) ip = i;
+        if (std::fabs(H.dbl[L.PF + b * N1 + i]) > std::fabs(H.dbl[L.PF + b * N1 + ipp])) ipp = i;
+      }
+      if (!nz(H.dbl[L.SF + b * N1 + ip]) || !nz(H.dbl[L.PF + b * N1 + ipp])) { why = "empty face coupling"; return false; }
+      for (int o = 0; o < NN; ++o) {
+        H.dbl[L.WTF + b * NN + o] = Q(node(d, ip, o), Nq + fn(o)) / H.dbl[L.SF + b * N1 + ip];
+        H.dbl[L.PTF + b * NN + o] = Ph(node(d, ipp, o), Nq + fn(o)) / H.dbl[L.PF + b * N1 + ipp];
+        for (int i = 0; i < N1; ++i) {
+          RQ[op](node(d, i, o), Nq + fn(o)) += H.dbl[L.SF + b * N1 + i] * H.dbl[L.WTF + b * NN + o];
+          RP(node(d, i, o), Nq + fn(o)) += H.dbl[L.PF + b * N1 + i] * H.dbl[L.PTF + b * NN + o];
+          RE(fn(o), node(d, i, o)) += H.dbl[L.EE + b * N1 + i];
+        }
+      }
+    }
+  }
+  for (int f = 0; f < Nfq; ++f)
+    if (face_seen[f] != 1) { why = "face node not attached to a line"; return false; }
+  for (int q = 0; q < Nq; ++q) {
+    H.dbl[L.PD + q] = Ph(q, q);
+    RP(q, q) += Ph(q, q);
+  }
+  for (int f = 0; f < Nfq; ++f) {
+    int qb = 0;
+    for (int q = 0; q < Nq; ++q)
+      if (std::fabs(Ph(q, Nq + f)) > std::fabs(Ph(qb, Nq + f))) qb = q;
+    if (!nz(Ph(qb, Nq + f))) { why = "Ph has an empty face column"; return false; }
+    H.dbl[L.WFAC + f] = Lf(qb, f) / Ph(qb, Nq + f);
+  }
+  for (int i = 0; i < Nq; ++i) {
+    for (int j = 0; j < Nh; ++j) {
+      for (int m = 0; m < 3; ++m)
+        if (std::fabs(RQ[m](i, j) - Q3[m](i, j)) > TOL) { why = "SBP operator is not the tensor product of 1D tables"; return false; }
+      if (std::fabs(RP(i, j) - Ph(i, j)) > TOL) { why = "Ph is not the tensor product of 1D tables"; return false; }
+    }
+    for (int f = 0; f < Nfq; ++f) {
+      if (std::fabs(RE(f, i) - Ef(f, i)) > TOL) { why = "Ef is not a line extrapolation"; return false; }
+      if (std::fabs(RP(i, Nq + f) * H.dbl[L.WFAC + f] - Lf(i, f)) > TOL) { why = "Lf is not Ph times a face weight"; return false; }
+    }
+  }
+  return true;
+}
+
 }  // namespace
 
 // Halo plan for element-index sharding: pure host logic, no device needed.
@@ -347,6 +448,8 @@ struct esdg_ctx {
   Tables T{};
   TensorTables TT{};
   bool use_fast = false;
+  int dim = 2, nfld = 4;   // 3 / 5 on the hexahedral path
+  HexTables HT{};
   int au_nc = AU_NC;
   MeshDev M{};
   Phys ph{};
@@ -629,6 +732,127 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   return ESDG_OK;
 }
 
+int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, const esdg_phys_t* phys, esdg_ctx** out) {
+  if (!ops || !mesh || !phys || !out) return fail(ESDG_ERR_ARG, "null argument");
+  *out = nullptr;
+  const int N1 = ops->N + 1, NN = N1 * N1, Nq = ops->Nq, Nfq = ops->Nfq, Nh = Nq + Nfq;
+  if (!hex_supported_degree(N1)) return fail(ESDG_ERR_ARG, "unsupported hex degree N=%d (need 1..3: one wavefront per element)", ops->N);
+  if (Nq != NN * N1 || Nfq != 6 * NN)
+    return fail(ESDG_ERR_STRUCTURE, "need tensor hex sizes Nq=(N+1)^3, Nfq=6(N+1)^2; got Nq=%d Nfq=%d", Nq, Nfq);
+  if (phys->formulation != ESDG_EULER_HEX_COLLOCATED) return fail(ESDG_ERR_ARG, "esdg_create_hex needs formulation ESDG_EULER_HEX_COLLOCATED");
+  if (!ops->Qrhskew || !ops->Qshskew || !ops->Qthskew || !ops->Ph || !ops->Lf || !ops->Ef) return fail(ESDG_ERR_ARG, "Qrhskew/Qshskew/Qthskew/Ph/Lf/Ef required");
+  const double* gsrc[9] = {mesh->rxJ, mesh->sxJ, mesh->txJ, mesh->ryJ, mesh->syJ, mesh->tyJ, mesh->rzJ, mesh->szJ, mesh->tzJ};
+  for (int m = 0; m < 9; ++m)
+    if (!gsrc[m]) return fail(ESDG_ERR_ARG, "mesh metric arrays missing");
+  if (mesh->K < 1 || !mesh->J || !mesh->nxJ || !mesh->nyJ || !mesh->nzJ || !mesh->sJ || !mesh->mapP) return fail(ESDG_ERR_ARG, "mesh arrays missing");
+  if ((int64_t)mesh->K * Nfq > (int64_t)2000000000) return fail(ESDG_ERR_ARG, "too many local face nodes for int32 maps");
+  if (esdg_device_count() < 1) return fail(ESDG_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+
+  esdg_ctx* c = new esdg_ctx();
+  struct Guard {
+    esdg_ctx* c;
+    ~Guard() { delete c; }
+  } guard{c};
+  c->dim = 3; c->nfld = HEX_NFLD;
+  c->Np = Nq; c->Nq = Nq; c->Nfq = Nfq; c->K = mesh->K;
+  c->ph.formulation = phys->formulation;
+  c->ph.lf_scale = phys->lf_scale;
+  c->ph.inviscid_dissp = 1; c->ph.viscous_dissp = 0; c->ph.BCTYPE = 0;
+  c->ph.Re = c->ph.mu = c->ph.lambda = c->ph.Pr = 0.0;
+  c->ph.dbg = 0;
+  if (const char* env = getenv("ESDG_DBG")) c->ph.dbg = atoi(env);
+  c->nphases = 2;
+  c->use_fast = true;
+  c->au_nc = HEX_AU_NC;
+  c->T = Tables{};
+  c->T.N1 = N1; c->T.Np = Nq; c->T.Nq = Nq; c->T.Nfq = Nfq; c->T.Nh = Nh;
+
+  // ---- operators: skew-symmetry, empty face-face block, tensor tables --------------------------
+  Mat Q3[3] = {from_colmajor(ops->Qrhskew, Nh, Nh), from_colmajor(ops->Qshskew, Nh, Nh), from_colmajor(ops->Qthskew, Nh, Nh)};
+  for (int m = 0; m < 3; ++m)
+    for (int i = 0; i < Nh; ++i)
+      for (int j = i; j < Nh; ++j) {
+        if (std::fabs(Q3[m](i, j) + Q3[m](j, i)) > 1e-10) return fail(ESDG_ERR_STRUCTURE, "SBP operator %d not skew-symmetric at (%d,%d)", m, i, j);
+        if (i >= Nq && j >= Nq && std::fabs(Q3[m](i, j)) > DROPTOL) return fail(ESDG_ERR_STRUCTURE, "non-zero face-face SBP weight at (%d,%d)", i, j);
+      }
+  HexHost hh;
+  std::string why;
+  if (!build_hex_host(N1, Q3, from_colmajor(ops->Ph, Nq, Nh), from_colmajor(ops->Lf, Nq, Nfq), from_colmajor(ops->Ef, Nfq, Nq), hh, why))
+    return fail(ESDG_ERR_STRUCTURE, "operators are not those of a tensor-product Gauss hexahedron: %s", why.c_str());
+
+  // ---- geometry: affine check + per-element records ---------------------------------------------
+  const int64_t K = mesh->K;
+  const int ld = mesh->geo_ld > 0 ? mesh->geo_ld : Nh;
+  std::vector<double> geo((size_t)K * HEX_GEO_STRIDE);
+  for (int64_t e = 0; e < K; ++e) {
+    double* g = &geo[(size_t)e * HEX_GEO_STRIDE];
+    double scale = 0;
+    for (int m = 0; m < 9; ++m) scale = std::max(scale, std::fabs(gsrc[m][(size_t)e * ld]));
+    for (int m = 0; m < 9; ++m) {
+      const double* src = gsrc[m] + (size_t)e * ld;
+      for (int i = 1; i < ld; ++i)
+        if (std::fabs(src[i] - src[0]) > 1e-10 * scale) return fail(ESDG_ERR_STRUCTURE, "element %lld is not affine (metric term %d varies)", (long long)e, m);
+      g[m] = src[0];
+    }
+    const double* J = mesh->J + (size_t)e * Nq;
+    for (int i = 1; i < Nq; ++i)
+      if (std::fabs(J[i] - J[0]) > 1e-10 * std::fabs(J[0])) return fail(ESDG_ERR_STRUCTURE, "element %lld is not affine (J varies)", (long long)e);
+    if (J[0] == 0.0) return fail(ESDG_ERR_ARG, "element %lld has J = 0", (long long)e);
+    g[9] = J[0];
+    for (int f = 0; f < 6; ++f) {
+      const size_t o = (size_t)e * Nfq + (size_t)f * NN;
+      for (int i = 1; i < NN; ++i)
+        if (std::fabs(mesh->nxJ[o + i] - mesh->nxJ[o]) > 1e-10 * mesh->sJ[o] || std::fabs(mesh->nyJ[o + i] - mesh->nyJ[o]) > 1e-10 * mesh->sJ[o] ||
+            std::fabs(mesh->nzJ[o + i] - mesh->nzJ[o]) > 1e-10 * mesh->sJ[o])
+          return fail(ESDG_ERR_STRUCTURE, "element %lld face %d is curved", (long long)e, f);
+      g[10 + 4 * f] = mesh->nxJ[o]; g[11 + 4 * f] = mesh->nyJ[o]; g[12 + 4 * f] = mesh->nzJ[o]; g[13 + 4 * f] = mesh->sJ[o];
+    }
+  }
+
+  // ---- mapP -> local int32 with ghost slots; halo plan -----------------------------------------
+  esdg_halo_plan pl;
+  {
+    int prc = build_halo_plan(mesh->mapP, K, Nfq, mesh->elem_offset, mesh->Kglobal > 0 ? mesh->Kglobal : K,
+                              std::max(1, mesh->nranks), mesh->rank_offsets, pl);
+    if (prc) return prc;
+  }
+  c->nghost = pl.nghost; c->nsend = pl.nsend;
+  c->nbr_rank = pl.nbr_rank;
+  c->nbr_send_off = pl.nbr_send_off; c->nbr_send_cnt = pl.nbr_send_cnt;
+  c->nbr_recv_off = pl.nbr_recv_off; c->nbr_recv_cnt = pl.nbr_recv_cnt;
+
+  int rc;
+#define UP(buf, vec) if ((rc = c->buf.upload(vec)) != 0) return rc
+  UP(d_geo, geo); UP(d_mapP, pl.mapP); UP(d_sendlist, pl.sendlist);
+  UP(t_dbl, hh.dbl); UP(t_int, hh.ints);
+  if (mesh->wJq) {
+    std::vector<double> w(mesh->wJq, mesh->wJq + (size_t)K * Nq);
+    UP(d_wJq, w);
+  }
+#undef UP
+  if ((rc = c->d_partial.alloc(sizeof(double) * esdg_ctx::NPARTIAL)) != 0) return rc;
+  c->HT.dbl = c->t_dbl.as<double>();
+  c->HT.ints = c->t_int.as<int>();
+  for (int d = 0; d < 3; ++d) c->HT.op[d] = hh.op[d];
+  c->M.K = K; c->M.geo = c->d_geo.as<double>(); c->M.mapP = c->d_mapP.as<int32_t>(); c->M.bc = nullptr;
+  c->M.wJq = mesh->wJq ? c->d_wJq.as<double>() : nullptr;
+  c->M.stamps = nullptr;
+
+  auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t nodes = (size_t)(K * Nfq + c->nghost);
+  size_t off = 0;
+  c->off_AU = off; off = align(off + nodes * HEX_AU_NC * sizeof(double));
+  Exchange x0{0, 1, HEX_AU_NC, c->off_AU, off};
+  off = align(off + (size_t)c->nsend * HEX_AU_NC * sizeof(double));
+  c->xch.push_back(x0);
+  c->ws_bytes = off;
+  guard.c = nullptr;
+  *out = c;
+  return ESDG_OK;
+}
+
+int esdg_num_fields(const esdg_ctx* ctx) { return ctx ? ctx->nfld : 0; }
+
 int esdg_destroy(esdg_ctx* ctx) {
   delete ctx;
   return ESDG_OK;
@@ -658,7 +882,16 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
   double* B = visc ? reinterpret_cast<double*>(ctx->ws + ctx->off_B) : nullptr;
   int rc = 0;
   const int32_t* sl = ctx->d_sendlist.as<int32_t>();
-  if (phase == 0) {
+  if (ctx->dim == 3) {
+    if (phase == 0) {
+      rc = launch_project_hex(ctx->T.N1, ctx->HT, ctx->M, ctx->ph, Q, A_U, s);
+      if (!rc && ctx->nsend)
+        rc = launch_pack(A_U, ctx->au_nc, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[0].send_off), s);
+    } else {
+      if (!rhs && !lf.Qw) return fail(ESDG_ERR_ARG, "rhs output is null");
+      rc = launch_rhs_hex(ctx->T.N1, ctx->HT, ctx->M, ctx->ph, Q, A_U, rhs, lf, s);
+    }
+  } else if (phase == 0) {
     rc = ctx->use_fast ? launch_project_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, A_v, s)
                        : launch_project(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, s);
     if (!rc && ctx->nsend) {
@@ -717,7 +950,8 @@ int esdg_rhstest(esdg_ctx* ctx, const double* Q, const double* rhs, double* diag
   if (!ctx->M.wJq) return fail(ESDG_ERR_STATE, "wJq was not supplied at esdg_create");
   hipStream_t s = static_cast<hipStream_t>(stream);
   double* partial = static_cast<double*>(ctx->d_partial.p);
-  int rc = launch_rhstest(ctx->T, ctx->M, ctx->ph, Q, rhs, partial, esdg_ctx::NPARTIAL, s);
+  int rc = ctx->dim == 3 ? launch_rhstest_hex(ctx->K * ctx->Nq, ctx->M.wJq, Q, rhs, partial, esdg_ctx::NPARTIAL, s)
+                         : launch_rhstest(ctx->T, ctx->M, ctx->ph, Q, rhs, partial, esdg_ctx::NPARTIAL, s);
   if (rc) return fail(ESDG_ERR_NO_DEVICE, "rhstest launch: %s", hipGetErrorString((hipError_t)rc));
   std::vector<double> h(esdg_ctx::NPARTIAL);
   HIP_TRY(hipMemcpyAsync(h.data(), partial, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));
@@ -729,19 +963,20 @@ int esdg_rhstest(esdg_ctx* ctx, const double* Q, const double* rhs, double* diag
   return ESDG_OK;
 }
 
-int esdg_rhs_host(esdg_ctx* ctx, const double* const Q[4], double* const rhs[4]) {
+int esdg_rhs_host(esdg_ctx* ctx, const double* const* Q, double* const* rhs) {
   if (!ctx || !Q || !rhs) return fail(ESDG_ERR_ARG, "null argument");
   if (ctx->nghost) return fail(ESDG_ERR_STATE, "esdg_rhs_host needs an unsharded mesh");
   const size_t n = (size_t)ctx->K * ctx->Np, bytes = n * sizeof(double);
   DevBuf dQ, dR, dW;
   int rc;
-  if ((rc = dQ.alloc(4 * bytes)) || (rc = dR.alloc(4 * bytes))) return rc;
+  const int nf = ctx->nfld;
+  if ((rc = dQ.alloc(nf * bytes)) || (rc = dR.alloc(nf * bytes))) return rc;
   void* old_ws = ctx->ws;
   if (!ctx->ws) {
     if ((rc = dW.alloc(ctx->ws_bytes))) return rc;
     ctx->ws = static_cast<char*>(dW.p);
   }
-  for (int f = 0; f < 4; ++f) HIP_TRY(hipMemcpy(static_cast<char*>(dQ.p) + f * bytes, Q[f], bytes, hipMemcpyHostToDevice));
+  for (int f = 0; f < nf; ++f) HIP_TRY(hipMemcpy(static_cast<char*>(dQ.p) + f * bytes, Q[f], bytes, hipMemcpyHostToDevice));
   rc = esdg_rhs(ctx, static_cast<const double*>(dQ.p), static_cast<double*>(dR.p), nullptr);
   if (!rc) {
     hipError_t e = hipDeviceSynchronize();
@@ -749,7 +984,7 @@ int esdg_rhs_host(esdg_ctx* ctx, const double* const Q[4], double* const rhs[4])
   }
   ctx->ws = static_cast<char*>(old_ws);
   if (rc) return rc;
-  for (int f = 0; f < 4; ++f) HIP_TRY(hipMemcpy(rhs[f], static_cast<char*>(dR.p) + f * bytes, bytes, hipMemcpyDeviceToHost));
+  for (int f = 0; f < nf; ++f) HIP_TRY(hipMemcpy(rhs[f], static_cast<char*>(dR.p) + f * bytes, bytes, hipMemcpyDeviceToHost));
   return ESDG_OK;
 }
 

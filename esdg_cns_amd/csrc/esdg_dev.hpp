@@ -96,6 +96,16 @@ int launch_axpy_stages(double* y, const double* x0, const double* const* k, cons
 int launch_dopri_err(const double* Q, const double* const* k, const double* coefE, int ns, double tol, int64_t n,
                      double* partial, int nblocks, hipStream_t s);
 bool supported_degree(int N1);
+
+// hexahedral path (esdg_kernels_hex.hip)
+struct HexTables;
+bool hex_supported_degree(int N1);
+int launch_project_hex(int N1, const HexTables& HT, const MeshDev& M, const Phys& ph, const double* Q, double* A_U,
+                       hipStream_t s);
+int launch_rhs_hex(int N1, const HexTables& HT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
+                   double* rhs, const LsrkFuse& lf, hipStream_t s);
+int launch_rhstest_hex(int64_t n, const double* wJq, const double* Q, const double* rhs, double* partial, int nblocks,
+                       hipStream_t s);
 int launch_log_test(const double* x, double* y, int64_t n, hipStream_t s);
 
 }  // namespace esdg

@@ -1,0 +1,472 @@
+// esdg_kernels_hex.hip -- gfx950 (MI355X / CDNA4) kernels for the collocated entropy-stable Euler right-hand
+// side on hexahedra: `rhs` of examples/dg3D_euler_hex.jl:167-222 with sparse_hadamard_sum (:122-164), the 3D
+// entropy-conservative flux (examples/EntropyStableEuler/euler_fluxes.jl:51-89, logmean.jl:14-28) and the 3D
+// entropy-variable maps (euler_variables.jl:79-120).
+//
+// Mapping (N = 3: Nq = 64 Gauss nodes = exactly one wavefront):
+//   * one wave per element, lane <-> Gauss node (i0,i1,i2); 4 independent waves per workgroup share the 1D
+//     operator tables in LDS (esdg_hex_tables.hpp), each wave owns its LDS slice.  The first Nfq = 6 N1^2 lane
+//     slots (1.5 rounds at N = 3) double as face-node lanes.
+//   * two phases with the face-trace protocol of the 2D path:
+//       phase 0  kh_project : v(u) at the Gauss nodes, extrapolation to the 96 face nodes (4-term line dot
+//                             products, Ef has N+1 non-zeros per row), u(v) -> (rho,u,v,w,beta) trace record
+//       phase 1  kh_rhs     : own + neighbour traces (mapP gather), surface flux (+LF), flux differencing, lift
+//   * flux differencing: each unordered pair once.  Volume-volume pairs by the circulant line schedule (per
+//     direction N1/2 rounds, lane = lower node, partner share pushed with ds_add_f64); volume-face pairs are
+//     walked by the FACE lanes (4 per face node; the two ends of a line start at opposite offsets, so no two
+//     lanes ever hit the same accumulator in one instruction).  672 EC fluxes per element at N = 3 (the
+//     reference evaluates 1344), each a *directional* flux g.F with the pair's metric vector g -- affine
+//     elements only, so the reference's per-pair metric average (:145-146) is the element constant.
+//   * one wave owns an element, so every accumulation order is fixed by the instruction stream: results are
+//     bitwise reproducible.
+//   * workgroup -> element-block mapping is XCD-aware: consecutive workgroup ids rotate over the 8 XCDs, so
+//     XCD x is given the x-th contiguous eighth of the element range and face neighbours meet in one L2.
+#include "esdg_dev.hpp"
+#include "esdg_devmath.hpp"
+#include "esdg_hex_tables.hpp"
+
+namespace esdg {
+namespace hdev {
+
+using namespace devmath;
+
+constexpr double GM1 = 1.4 - 1;   // gamma - 1 with the package's gamma (EntropyStableEuler.jl:9)
+constexpr int HW = 64;            // wave
+constexpr int HNWV = 4;           // waves (= elements) per workgroup
+constexpr int NXCD = 8;
+
+template <int N1> struct HCfg {
+  static constexpr int Nq = N1 * N1 * N1, Nfq = 6 * N1 * N1, NIT = (Nfq + HW - 1) / HW;
+};
+
+// conservative (rho, rho u, rho v, rho w, E) -> (rho,u,v,w,beta,log rho,log beta); one reciprocal
+__device__ __forceinline__ void prim_logs3(const double* U, double* q) {
+  const double m2 = U[1] * U[1] + U[2] * U[2] + U[3] * U[3];
+  const double rre = U[0] * U[4] - .5 * m2;            // rho * rhoe
+  const double R = rcp_refined(U[0] * rre);            // 1/(rho^2 rhoe)
+  const double ir = R * rre;                           // 1/rho
+  q[0] = U[0];
+  q[1] = U[1] * ir;
+  q[2] = U[2] * ir;
+  q[3] = U[3] * ir;
+  q[4] = (U[0] * U[0]) * (U[0] * R) * (1.0 / (2 * GM1));   // beta = rho/(2 (gamma-1) rhoe)
+  q[5] = log_pos(U[0]);
+  q[6] = log_pos(q[4]);
+}
+
+// entropy variables from (rho,u,v,w,beta,logs): identities of euler_variables.jl:79-92
+__device__ __forceinline__ void v_of_prim3(const double* q, double* V) {
+  const double s = -GM1 * q[5] - q[6] - 0.6931471805599453;
+  const double b2 = 2 * GM1 * q[4];                    // rho/rhoe
+  V[0] = 1.4 - s - .5 * b2 * (q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  V[1] = b2 * q[1];
+  V[2] = b2 * q[2];
+  V[3] = b2 * q[3];
+  V[4] = -b2;
+}
+
+// (rho,u,v,w,beta) of entropy variables: u_vfun (euler_variables.jl:95-120) followed by the driver's
+// u = rhoU/rho, beta = betafun(...) (dg3D_euler_hex.jl:179-182), which reduce to u_i = -v_i/v5, beta = -v5/(2(gamma-1))
+__device__ __forceinline__ void prim_of_v3(const double* V, double* q) {
+  const double iv = rcp_refined(V[4]);
+  const double h = (V[1] * V[1] + V[2] * V[2] + V[3] * V[3]) * .5 * iv;
+  const double s = 1.4 - V[0] + h;
+  const double rhoeV = exp((log(GM1) - 1.4 * log_pos(-V[4]) - s) * (1.0 / GM1));
+  q[0] = rhoeV * (-V[4]);
+  q[1] = -V[1] * iv;
+  q[2] = -V[2] * iv;
+  q[3] = -V[3] * iv;
+  q[4] = V[4] * (-1.0 / (2 * GM1));
+}
+
+// g . (Fx,Fy,Fz) of the entropy-conservative flux (euler_fluxes.jl:51-89), q = (rho,u,v,w,beta,lrho,lbeta).
+// One reciprocal serves the rho log-mean, 1/(beta log-mean) and pa; logmean's |f| < 1e-4 series branch is
+// selected, not branched (same construction as ec_flux of the 2D tensor kernels).
+__device__ __forceinline__ void ec_flux_dir(const double* qL, const double* qR, double gx, double gy, double gz,
+                                            double* F) {
+  const double dr = qR[0] - qL[0], ravg = .5 * (qR[0] + qL[0]);
+  const double db = qR[4] - qL[4], bavg = .5 * (qR[4] + qL[4]);
+  const double A = qL[5] - qR[5], B = qL[6] - qR[6];
+  const bool ser_r = fabs(dr) < 1e-4 * ravg, ser_b = fabs(db) < 1e-4 * bavg;
+  const double yr = ser_r ? ravg : A;
+  const double yb = ser_b ? bavg : db;
+  const double yp = qL[4] + qR[4];
+  const double ybp = yb * yp;
+  const double R = rcp_refined(yr * ybp);
+  const double ir = R * ybp;
+  const double ryr = R * yr;
+  const double ib = ryr * yp;
+  const double ip = ryr * yb;
+  const double fr = dr * ir, vr = fr * fr;
+  const double rholog = ser_r ? ravg * (1 + vr * (-.2 - vr * (.0512 - vr * 0.026038857142857))) : -fr;
+  const double fb = db * ib, vb = fb * fb;
+  const double ibetalog = ser_b ? ib * (1 + vb * (.2 + vb * .0912)) : -(B * ib);
+  const double ua = .5 * (qL[1] + qR[1]), va = .5 * (qL[2] + qR[2]), wa = .5 * (qL[3] + qR[3]);
+  const double unorm = qL[1] * qR[1] + qL[2] * qR[2] + qL[3] * qR[3];
+  const double pa = ravg * ip;
+  const double Ep = rholog * ibetalog * (1.0 / (2 * GM1)) + pa + .5 * rholog * unorm;
+  const double un = gx * ua + gy * va + gz * wa;
+  F[0] = rholog * un;
+  F[1] = F[0] * ua + pa * gx;
+  F[2] = F[0] * va + pa * gy;
+  F[3] = F[0] * wa + pa * gz;
+  F[4] = Ep * un;
+}
+
+// |wavespeed(rho, rhoU_n, E)| of dg3D_euler_hex.jl:190-192 (euler_variables.jl:7-10, sqrt(|u_n|) quirk Q1),
+// from a primitive record; also returns the conservative vector
+__device__ __forceinline__ double lf_lambda3(const double* q, double nx, double ny, double nz, double isJ, double* U) {
+  U[0] = q[0];
+  U[1] = q[0] * q[1];
+  U[2] = q[0] * q[2];
+  U[3] = q[0] * q[3];
+  const double p = q[0] * .5 * rcp_refined(q[4]);
+  U[4] = p * (1.0 / GM1) + .5 * q[0] * (q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const double ir = rcp_refined(q[0]);
+  const double rhoUn = (U[1] * nx + U[2] * ny + U[3] * nz) * isJ;
+  const double pn = GM1 * (U[4] - .5 * (rhoUn * rhoUn) * ir);
+  return fabs(sqrt(fabs(rhoUn * ir)) + sqrt(1.4 * pn * ir));
+}
+
+template <int N1>
+__device__ __forceinline__ void stage_tables(const HexTables& HT, double* sTab, int* sInt) {
+  constexpr HexLayout L(N1);
+  for (int i = threadIdx.x; i < L.NDBL; i += HW * HNWV) sTab[i] = HT.dbl[i];
+  for (int i = threadIdx.x; i < L.NINT; i += HW * HNWV) sInt[i] = HT.ints[i];
+}
+
+// XCD-aware element-block id (see the header); returns -1 for padding workgroups
+__device__ __forceinline__ int64_t block_of(int64_t nblk, bool remap) {
+  const int64_t b = blockIdx.x;
+  if (!remap) return b < nblk ? b : -1;
+  const int64_t chunk = (nblk + NXCD - 1) / NXCD;
+  const int64_t blk = (b % NXCD) * chunk + b / NXCD;
+  return blk < nblk ? blk : -1;
+}
+
+// line of direction d through face node code (d | t<<2 | o<<3): base node and stride
+template <int N1>
+__device__ __forceinline__ void line_of(int d, int o, int& base, int& stride) {
+  stride = d == 0 ? 1 : (d == 1 ? N1 : N1 * N1);
+  base = d == 0 ? N1 * o : (d == 1 ? (o % N1) + N1 * N1 * (o / N1) : o);
+}
+
+// ---- phase 0 -----------------------------------------------------------------------------------------------
+template <int N1>
+__global__ __launch_bounds__(HW * HNWV) void kh_project(HexTables HT, MeshDev M, int remap,
+                                                         const double* __restrict__ Q, double* __restrict__ A_U) {
+  constexpr HexLayout L(N1);
+  constexpr int Nq = HCfg<N1>::Nq, Nfq = HCfg<N1>::Nfq, NIT = HCfg<N1>::NIT;
+  __shared__ double sTab[L.NDBL];
+  __shared__ int sInt[L.NINT];
+  __shared__ double sV[HNWV][HEX_NFLD * HW];
+  const int64_t nblk = (M.K + HNWV - 1) / HNWV;
+  const int64_t blk = block_of(nblk, remap != 0);
+  if (blk < 0) return;
+  const int lane = threadIdx.x & (HW - 1), wv = threadIdx.x / HW;
+  const int64_t e = blk * HNWV + wv;
+  const bool active = e < M.K;
+  const int64_t ec = active ? e : M.K - 1;
+  const bool vin = lane < Nq;
+  double U[HEX_NFLD] = {1.0, 0.0, 0.0, 0.0, 1.0};
+  if (vin) {
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) U[c] = Q[(int64_t)c * M.K * Nq + ec * Nq + lane];
+  }
+  stage_tables<N1>(HT, sTab, sInt);
+  double q[7], V[HEX_NFLD];
+  prim_logs3(U, q);
+  v_of_prim3(q, V);
+  if (vin) {
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) sV[wv][c * HW + lane] = V[c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int f = lane + HW * it;
+    if (f < Nfq) {
+      const int code = sInt[L.FINV + f];
+      const int d = code & 3, t = (code >> 2) & 1, o = code >> 3;
+      int base, stride;
+      line_of<N1>(d, o, base, stride);
+      double Vf[HEX_NFLD] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i < N1; ++i) {
+        const double w = sTab[L.EE + (d * 2 + t) * N1 + i];
+#pragma unroll
+        for (int c = 0; c < HEX_NFLD; ++c) Vf[c] += w * sV[wv][c * HW + base + i * stride];
+      }
+      double qf[HEX_NFLD];
+      prim_of_v3(Vf, qf);
+      if (active) {
+#pragma unroll
+        for (int c = 0; c < HEX_NFLD; ++c) A_U[(e * Nfq + f) * HEX_AU_NC + c] = qf[c];
+      }
+    }
+  }
+}
+
+// ---- phase 1 -----------------------------------------------------------------------------------------------
+template <int N1>
+__global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phys ph, int remap,
+                                                     const double* __restrict__ Q, const double* __restrict__ A_U,
+                                                     double* __restrict__ rhs, LsrkFuse lf) {
+  constexpr HexLayout L(N1);
+  constexpr int Nq = HCfg<N1>::Nq, Nfq = HCfg<N1>::Nfq, NIT = HCfg<N1>::NIT, NN = N1 * N1;
+  constexpr int SP = 7 * HW > HEX_NFLD * Nfq ? 7 * HW : HEX_NFLD * Nfq;   // sP doubles (sG aliases it)
+  __shared__ double sTab[L.NDBL];
+  __shared__ int sInt[L.NINT];
+  __shared__ double sGeo[HNWV][HEX_GEO_STRIDE + 2];
+  __shared__ double sPs[HNWV][SP];
+  __shared__ double sAccs[HNWV][HEX_NFLD * HW];
+  const int64_t nblk = (M.K + HNWV - 1) / HNWV;
+  const int64_t blk = block_of(nblk, remap != 0);
+  if (blk < 0) return;
+  const int lane = threadIdx.x & (HW - 1), wv = threadIdx.x / HW;
+  const int64_t e = blk * HNWV + wv;
+  const bool active = e < M.K;
+  const int64_t ec = active ? e : M.K - 1;
+  const bool vin = lane < Nq;
+  double* sP = sPs[wv];
+  double* sAcc = sAccs[wv];
+  const double* geo = sGeo[wv];
+
+  // ---- issue the global loads ---------------------------------------------------------------------
+  double U[HEX_NFLD] = {1.0, 0.0, 0.0, 0.0, 1.0};
+  if (vin) {
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) U[c] = Q[(int64_t)c * M.K * Nq + ec * Nq + lane];
+  }
+  double qm[NIT][7], qp[NIT][7];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int f = lane + HW * it;
+    const int fc = f < Nfq ? f : Nfq - 1;
+    const int64_t nm = ec * Nfq + fc;
+    const int64_t np = M.mapP[nm];
+#pragma unroll
+    for (int c = 0; c < HEX_AU_NC; ++c) {
+      qm[it][c] = A_U[nm * HEX_AU_NC + c];
+      qp[it][c] = A_U[np * HEX_AU_NC + c];
+    }
+  }
+  if (lane < HEX_GEO_STRIDE) sGeo[wv][lane] = M.geo[ec * HEX_GEO_STRIDE + lane];
+  stage_tables<N1>(HT, sTab, sInt);
+#pragma unroll
+  for (int c = 0; c < HEX_NFLD; ++c) sAcc[c * HW + lane] = 0.0;
+
+  // ---- pointwise: primitives + logs ------------------------------------------------------------------
+  double qv[7];
+  prim_logs3(U, qv);
+#pragma unroll
+  for (int c = 0; c < 7; ++c) sP[c * HW + lane] = qv[c];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    qm[it][5] = log_pos(qm[it][0]);
+    qm[it][6] = log_pos(qm[it][4]);
+    qp[it][5] = log_pos(qp[it][0]);
+    qp[it][6] = log_pos(qp[it][4]);
+  }
+  __syncthreads();
+
+  const int lq = vin ? lane : 0;
+  const int i0 = lq % N1, i1 = (lq / N1) % N1, i2 = lq / NN;
+  double acc[HEX_NFLD] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  double G[NIT][HEX_NFLD];
+
+  // ---- face lanes: surface flux (:185-198) and the four volume partners of every face node -----------
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int f = lane + HW * it;
+    const bool fin = f < Nfq;
+    const int fc = fin ? f : Nfq - 1;
+    const int face = fc / NN;
+    const double nx = geo[10 + 4 * face], ny = geo[11 + 4 * face], nz = geo[12 + 4 * face], sJ = geo[13 + 4 * face];
+    double fs[HEX_NFLD];
+    ec_flux_dir(qm[it], qp[it], nx, ny, nz, fs);
+    if (ph.lf_scale != 0.0) {
+      double UM[HEX_NFLD], UP[HEX_NFLD];
+      const double isJ = rcp_refined(sJ);
+      const double lM = lf_lambda3(qm[it], nx, ny, nz, isJ, UM);
+      const double lP = lf_lambda3(qp[it], nx, ny, nz, isJ, UP);
+      const double LFc = ph.lf_scale * fmax(lM, lP) * sJ;
+#pragma unroll
+      for (int c = 0; c < HEX_NFLD; ++c) fs[c] -= LFc * (UP[c] - UM[c]);
+    }
+    const double wfac = sTab[L.WFAC + fc];
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) G[it][c] = wfac * fs[c];
+
+    const int code = sInt[L.FINV + fc];
+    const int d = code & 3, t = (code >> 2) & 1, o = code >> 3;
+    int base, stride;
+    line_of<N1>(d, o, base, stride);
+    const int opd = d == 0 ? HT.op[0] : (d == 1 ? HT.op[1] : HT.op[2]);
+    const double gx = geo[opd], gy = geo[3 + opd], gz = geo[6 + opd];
+    const double wtf = sTab[L.WTF + (d * 2 + t) * NN + o];
+    int ii = t ? (N1 + 1) / 2 : 0;
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+      const int node = base + ii * stride;
+      double qn[7], F[HEX_NFLD];
+#pragma unroll
+      for (int c = 0; c < 7; ++c) qn[c] = sP[c * HW + node];
+      const double W = sTab[L.SF + (d * 2 + t) * N1 + ii] * wtf;
+      ec_flux_dir(qn, qm[it], gx, gy, gz, F);
+#pragma unroll
+      for (int c = 0; c < HEX_NFLD; ++c) {
+        const double wf = W * F[c];
+        G[it][c] -= wf;
+        if (fin) lds_add(&sAcc[c * HW + node], wf);
+      }
+      ii = ii + 1 == N1 ? 0 : ii + 1;
+    }
+  }
+
+  // ---- volume lanes: circulant line schedule, each unordered pair once ---------------------------------
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int opd = HT.op[d];
+    const double gx = geo[opd], gy = geo[3 + opd], gz = geo[6 + opd];
+    const int id = d == 0 ? i0 : (d == 1 ? i1 : i2);
+    const int o = d == 0 ? i1 + N1 * i2 : (d == 1 ? i0 + N1 * i2 : i0 + N1 * i1);
+    const int stride = d == 0 ? 1 : (d == 1 ? N1 : NN);
+    const double wt = sTab[L.WT + d * NN + o];
+#pragma unroll
+    for (int m = 1; m <= N1 / 2; ++m) {
+      int j = id + m;
+      j = j >= N1 ? j - N1 : j;
+      const bool half = (N1 % 2 == 0) && (m == N1 / 2);
+      const bool act = vin && (!half || id < N1 / 2);
+      const int node = act ? lane + (j - id) * stride : lane;
+      double qn[7], F[HEX_NFLD];
+#pragma unroll
+      for (int c = 0; c < 7; ++c) qn[c] = sP[c * HW + node];
+      const double W = sTab[L.S + (d * N1 + id) * N1 + j] * wt;
+      ec_flux_dir(qv, qn, gx, gy, gz, F);
+      if (act) {
+#pragma unroll
+        for (int c = 0; c < HEX_NFLD; ++c) {
+          const double wf = W * F[c];
+          acc[c] += wf;
+          lds_add(&sAcc[c * HW + node], -wf);
+        }
+      }
+    }
+  }
+  __syncthreads();   // all pair work done: sP is dead and becomes sG
+
+  double* sG = sP;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int f = lane + HW * it;
+    if (f < Nfq) {
+#pragma unroll
+      for (int c = 0; c < HEX_NFLD; ++c) sG[c * Nfq + f] = G[it][c];
+    }
+  }
+  __syncthreads();
+
+  // ---- Ph*QF + Lf*flux, -(.)/J (:198-212) -------------------------------------------------------------
+  if (vin) {
+    double tot[HEX_NFLD];
+    const double pd = sTab[L.PD + lq];
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) tot[c] = pd * (acc[c] + sAcc[c * HW + lane]);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int id = d == 0 ? i0 : (d == 1 ? i1 : i2);
+      const int o = d == 0 ? i1 + N1 * i2 : (d == 1 ? i0 + N1 * i2 : i0 + N1 * i1);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int fi = sInt[L.FN + (d * 2 + t) * NN + o];
+        const double w = sTab[L.PF + (d * 2 + t) * N1 + id] * sTab[L.PTF + (d * 2 + t) * NN + o];
+#pragma unroll
+        for (int c = 0; c < HEX_NFLD; ++c) tot[c] += w * sG[c * Nfq + fi];
+      }
+    }
+    const double miJ = -rcp_refined(geo[9]);
+    if (active) {
+#pragma unroll
+      for (int c = 0; c < HEX_NFLD; ++c) {
+        const int64_t idx = (int64_t)c * M.K * Nq + e * Nq + lane;
+        const double out = tot[c] * miJ;
+        if (lf.Qw) {   // fused low-storage RK stage (same rounding sequence as k_lsrk)
+          const double r = __builtin_fma(lf.a, lf.res[idx], lf.dt * out);
+          lf.res[idx] = r;
+          lf.Qw[idx] = __builtin_fma(lf.b, r, lf.Qw[idx]);
+        } else {
+          rhs[idx] = out;
+        }
+      }
+    }
+  }
+}
+
+// rhstest = sum(wJq .* v(Q) .* rhs) (dg3D_euler_hex.jl:214-219): per-block partial sums
+__global__ void kh_rhstest(int64_t n, const double* __restrict__ wJq, const double* __restrict__ Q,
+                           const double* __restrict__ rhs, double* __restrict__ partial) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double U[HEX_NFLD], q[7], V[HEX_NFLD];
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) U[c] = Q[(int64_t)c * n + i];
+    prim_logs3(U, q);
+    v_of_prim3(q, V);
+    double t = 0.0;
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) t += V[c] * rhs[(int64_t)c * n + i];
+    s += wJq[i] * t;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+}  // namespace hdev
+
+bool hex_supported_degree(int N1) { return N1 >= 2 && N1 <= 4; }
+
+#define ESDG_HEX_DISPATCH(N1v, STMT)   \
+  switch (N1v) {                        \
+    case 2: { constexpr int N1 = 2; STMT; } break; \
+    case 3: { constexpr int N1 = 3; STMT; } break; \
+    case 4: { constexpr int N1 = 4; STMT; } break; \
+    default: return (int)hipErrorInvalidValue;     \
+  }
+
+static inline unsigned hex_grid(int64_t K, bool remap) {
+  const int64_t nblk = (K + hdev::HNWV - 1) / hdev::HNWV;
+  if (!remap) return (unsigned)nblk;
+  return (unsigned)(((nblk + hdev::NXCD - 1) / hdev::NXCD) * hdev::NXCD);
+}
+
+int launch_project_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phys& ph, const double* Q, double* A_U,
+                       hipStream_t s) {
+  if (M.K == 0) return 0;
+  const int remap = (ph.dbg & 16) ? 0 : 1;
+  ESDG_HEX_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_project<N1>), dim3(hex_grid(M.K, remap)), dim3(hdev::HW * hdev::HNWV), 0, s, HT, M, remap, Q, A_U));
+  return (int)hipGetLastError();
+}
+
+int launch_rhs_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
+                   double* rhs, const LsrkFuse& lf, hipStream_t s) {
+  if (M.K == 0) return 0;
+  const int remap = (ph.dbg & 16) ? 0 : 1;
+  ESDG_HEX_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_rhs<N1>), dim3(hex_grid(M.K, remap)), dim3(hdev::HW * hdev::HNWV), 0, s, HT, M, ph, remap, Q, A_U, rhs, lf));
+  return (int)hipGetLastError();
+}
+
+int launch_rhstest_hex(int64_t n, const double* wJq, const double* Q, const double* rhs, double* partial, int nblocks,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(hdev::kh_rhstest, dim3(nblocks), dim3(256), 0, s, n, wJq, Q, rhs, partial);
+  return (int)hipGetLastError();
+}
+
+}  // namespace esdg

@@ -24,6 +24,7 @@
 //     arithmetic.
 #include "esdg_dev.hpp"
 #include "esdg_tensor_tables.hpp"
+#include "esdg_devmath.hpp"
 
 namespace esdg {
 
@@ -38,43 +39,11 @@ template <> struct TCfg<8> { static constexpr int E = 1; };
 
 namespace tdev {
 
+using namespace devmath;
+
 template <bool MODAL> struct Gas {
   static constexpr double GM1 = MODAL ? 0.4 : (1.4 - 1);  // literal 0.4 in the CNS drivers, gamma-1 in the Euler one
 };
-
-__device__ __forceinline__ double rcp_refined(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  double e = __builtin_fma(-x, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  e = __builtin_fma(-x, r, 1.0);
-  return __builtin_fma(r, e, r);
-}
-
-// Natural logarithm for positive normal doubles: fdlibm's e_log.c algorithm (argument reduction to
-// [sqrt(1/2), sqrt(2)), s = f/(2+f), degree-14 even polynomial; error < 1 ulp) on v_frexp_* and one refined
-// v_rcp_f64: ~40 VALU instructions instead of the ~100 of the device-library log (its double-double
-// path).  Five logs per face/volume lane made the library log 2/3 of the phase-0 kernel.
-__device__ __forceinline__ double log_pos(double x) {
-  double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
-  int e = __builtin_amdgcn_frexp_exp(x);
-  const bool lo = m < 0.70710678118654752440;
-  m = lo ? m + m : m;
-  e = lo ? e - 1 : e;
-  const double f = m - 1.0;
-  const double s = f * rcp_refined(2.0 + f);
-  const double z = s * s, w = z * z;
-  const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
-  const double t2 = z * (6.666666666666735130e-01 +
-                         w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
-  const double R = t2 + t1;
-  const double hfsq = 0.5 * f * f;
-  const double dk = (double)e;
-  return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
-}
-
-__device__ __forceinline__ void lds_add(double* p, double v) {
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 
 // Entropy-conservative flux (euler_fluxes.jl:23-48 with logmean.jl:14-28), q = (rho,u,v,beta,lrho,lbeta).
 // One reciprocal serves rho log-mean, 1/(beta log-mean) and pa; the reference's series branch for

@@ -3,6 +3,7 @@ reference drivers' operator surface so their time loops transliterate one to one
 
   rhs(Q, md, ops, flux_fun, compute_rhstest)        examples/dg2D_euler_quad.jl:141
   rhsRK(Q, rd, md, ops, ...)                        examples/CompressibleNS/dg2D_CNS_cavity_optimized.jl:955
+  rhs_hex(Q, md, ops, flux_fun, compute_rhstest)    examples/dg3D_euler_hex.jl:167
   lsrk45 loop                                       examples/dg2D_euler_quad.jl:196-212
 
 torch supplies device memory, streams and torch.distributed only; all arithmetic happens in the
@@ -14,9 +15,9 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import check, esdg_mesh_t, esdg_ops_t, esdg_phys_t
+from ._lib import check, esdg_hex_mesh_t, esdg_hex_ops_t, esdg_mesh_t, esdg_ops_t, esdg_phys_t
 
-EULER_COLLOCATED, CNS_MODAL, EULER_MODAL = 0, 1, 2
+EULER_COLLOCATED, CNS_MODAL, EULER_MODAL, EULER_HEX_COLLOCATED = 0, 1, 2, 3
 
 
 def _f(a):
@@ -64,11 +65,80 @@ class RhsEngine:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         torch.cuda.set_device(self.device)
         self.formulation = formulation
+        self.nfld = 5 if formulation == EULER_HEX_COLLOCATED else 4
+        keep = self._keep = {}
+        if formulation == EULER_HEX_COLLOCATED:
+            ctx = self._create_hex(L, rd, md, ops, 0.0 if lf_scale is None else lf_scale, rank, nranks, rank_offsets)
+        else:
+            ctx = self._create_2d(L, rd, md, ops, formulation, lf_scale, inviscid_dissp, viscous_dissp, BCTYPE, Re, mu, lam, Pr,
+                                  rank, nranks, rank_offsets)
+        self.ctx = ctx
+        self.L = L
+        self.nphases = L.esdg_num_phases(ctx)
+        nbytes = int(L.esdg_workspace_bytes(ctx))
+        self.ws = torch.zeros(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+        check(L.esdg_bind_workspace(ctx, C.c_void_p(self.ws.data_ptr()), nbytes))
+
+        # halo plan
+        self.nranks = nranks
+        self.halo = None
+        nn = L.esdg_halo_num_neighbors(ctx)
+        self.xinfo = []
+        segs = []
+        for x in range(L.esdg_num_exchanges(ctx)):
+            a, b, nc = C.c_int32(), C.c_int32(), C.c_int32()
+            check(L.esdg_exchange_info(ctx, x, C.byref(a), C.byref(b), C.byref(nc)))
+            self.xinfo.append((a.value, b.value, nc.value))
+            s = []
+            for n in range(nn):
+                peer = C.c_int32()
+                so, sb, ro, rb = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+                check(L.esdg_halo_segment(ctx, x, n, C.byref(peer), C.byref(so), C.byref(sb), C.byref(ro), C.byref(rb)))
+                s.append((peer.value, so.value, sb.value, ro.value, rb.value))
+            segs.append(s)
+        if nn:
+            self.halo = HaloExchanger(segs, group)
+
+    def _create_hex(self, L, rd, md, ops, lf_scale, rank, nranks, rank_offsets):
+        """esdg_create_hex from the arrays examples/dg3D_euler_hex.jl holds when it calls `rhs` (:167)."""
+        keep = self._keep
+        Nq, Nfq = rd.wq.size, rd.wf.size
+        self.Np, self.Nq, self.Nfq, self.K = Nq, Nq, Nfq, int(md.K)
+        o = esdg_hex_ops_t()
+        o.N, o.Nq, o.Nfq = rd.N, Nq, Nfq
+        for n in ("Qrhskew", "Qshskew", "Qthskew", "Ph", "Lf", "Ef"):
+            keep[n] = _f(ops[n])
+            setattr(o, n, _dp(keep[n]))
+        keep["wq"], keep["wf"] = _f(rd.wq), _f(rd.wf)
+        o.wq, o.wf = _dp(keep["wq"]), _dp(keep["wf"])
+        m = esdg_hex_mesh_t()
+        m.K = int(md.K)
+        m.geo_ld = int(md.rxJ.shape[0])
+        for n in ("rxJ", "sxJ", "txJ", "ryJ", "syJ", "tyJ", "rzJ", "szJ", "tzJ", "J", "wJq", "nxJ", "nyJ", "nzJ", "sJ"):
+            keep["m_" + n] = _f(getattr(md, n))
+            setattr(m, n, _dp(keep["m_" + n]))
+        keep["mapP"] = np.asfortranarray(np.asarray(md.mapP, dtype=np.int64))
+        m.mapP = keep["mapP"].ctypes.data_as(_lib.c_int64_p)
+        m.elem_offset = int(getattr(md, "elem_offset", 0))
+        m.Kglobal = int(getattr(md, "Kglobal", md.K))
+        m.nranks, m.rank = int(nranks), int(rank)
+        if nranks > 1:
+            keep["ro"] = np.ascontiguousarray(np.asarray(rank_offsets, dtype=np.int64))
+            m.rank_offsets = keep["ro"].ctypes.data_as(_lib.c_int64_p)
+        p = esdg_phys_t()
+        p.formulation = EULER_HEX_COLLOCATED
+        p.lf_scale = float(lf_scale)
+        ctx = C.c_void_p()
+        check(L.esdg_create_hex(C.byref(o), C.byref(m), C.byref(p), C.byref(ctx)))
+        return ctx
+
+    def _create_2d(self, L, rd, md, ops, formulation, lf_scale, inviscid_dissp, viscous_dissp, BCTYPE, Re, mu, lam, Pr,
+                   rank, nranks, rank_offsets):
+        keep = self._keep
         modal = formulation != EULER_COLLOCATED
         Nq, Nfq = rd.wq.size, rd.wf.size
         Np = rd.Pq.shape[0] if modal else Nq
         self.Np, self.Nq, self.Nfq, self.K = Np, Nq, Nfq, int(md.K)
-        keep = self._keep = {}
 
         o = esdg_ops_t()
         o.N, o.Np, o.Nq, o.Nfq = rd.N, Np, Nq, Nfq
@@ -130,32 +200,7 @@ class RhsEngine:
 
         ctx = C.c_void_p()
         check(L.esdg_create(C.byref(o), C.byref(m), C.byref(p), C.byref(ctx)))
-        self.ctx = ctx
-        self.L = L
-        self.nphases = L.esdg_num_phases(ctx)
-        nbytes = int(L.esdg_workspace_bytes(ctx))
-        self.ws = torch.zeros(max(nbytes, 256), dtype=torch.uint8, device=self.device)
-        check(L.esdg_bind_workspace(ctx, C.c_void_p(self.ws.data_ptr()), nbytes))
-
-        # halo plan
-        self.nranks = nranks
-        self.halo = None
-        nn = L.esdg_halo_num_neighbors(ctx)
-        self.xinfo = []
-        segs = []
-        for x in range(L.esdg_num_exchanges(ctx)):
-            a, b, nc = C.c_int32(), C.c_int32(), C.c_int32()
-            check(L.esdg_exchange_info(ctx, x, C.byref(a), C.byref(b), C.byref(nc)))
-            self.xinfo.append((a.value, b.value, nc.value))
-            s = []
-            for n in range(nn):
-                peer = C.c_int32()
-                so, sb, ro, rb = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
-                check(L.esdg_halo_segment(ctx, x, n, C.byref(peer), C.byref(so), C.byref(sb), C.byref(ro), C.byref(rb)))
-                s.append((peer.value, so.value, sb.value, ro.value, rb.value))
-            segs.append(s)
-        if nn:
-            self.halo = HaloExchanger(segs, group)
+        return ctx
 
     def __del__(self):
         try:
@@ -178,7 +223,7 @@ class RhsEngine:
         return [np.asfortranarray(h[f].T) for f in range(h.shape[0])]
 
     def new_state(self):
-        return torch.zeros((4, self.K, self.Np), dtype=torch.float64, device=self.device)
+        return torch.zeros((self.nfld, self.K, self.Np), dtype=torch.float64, device=self.device)
 
     # -- the hot path -------------------------------------------------------------------------
     def _stream(self):
@@ -215,8 +260,8 @@ class RhsEngine:
         """Literal drop-in on host arrays through esdg_rhs_host (H2D + rhs + D2H)."""
         Qh = [_f(q) for q in Q]
         out = [np.zeros_like(q) for q in Qh]
-        qa = (_lib.c_double_p * 4)(*[_dp(q) for q in Qh])
-        ra = (_lib.c_double_p * 4)(*[_dp(r) for r in out])
+        qa = (_lib.c_double_p * len(Qh))(*[_dp(q) for q in Qh])
+        ra = (_lib.c_double_p * len(Qh))(*[_dp(r) for r in out])
         check(self.L.esdg_rhs_host(self.ctx, qa, ra))
         return out
 
@@ -271,6 +316,16 @@ def rhs(Q, md, ops, flux_fun=None, compute_rhstest=False, rd=None):
     accepted and ignored (only euler_fluxes exists in the reference).  Host arrays in, host arrays
     out: PCIe-bound, for validation; time loops should keep the state on device via RhsEngine."""
     eng = _engine_for(md, rd if rd is not None else ops["rd"], ops, EULER_COLLOCATED)
+    Qd = eng.upload(Q)
+    r = eng.rhs(Qd)
+    rt = eng.rhstest(Qd, r) if compute_rhstest else 0
+    return tuple(eng.download(r)), rt
+
+
+def rhs_hex(Q, md, ops, flux_fun=None, compute_rhstest=False, rd=None, lf_scale=0.0):
+    """Drop-in for `rhs(Q,md,ops,flux_fun,compute_rhstest)` of examples/dg3D_euler_hex.jl:167: Q = tuple of 5
+    (Nq x K) matrices at the Gauss nodes; returns (rhsQ, rhstest).  lf_scale is the literal `0*.25` of :193."""
+    eng = _engine_for(md, rd if rd is not None else ops["rd"], ops, EULER_HEX_COLLOCATED, lf_scale=lf_scale)
     Qd = eng.upload(Q)
     r = eng.rhs(Qd)
     rt = eng.rhstest(Qd, r) if compute_rhstest else 0

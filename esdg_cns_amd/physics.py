@@ -26,3 +26,15 @@ def v_ufun(rho, rhou, rhov, E):
     rhoe = E - .5 * (rhou ** 2 + rhov ** 2) / rho
     s = np.log((GAMMA - 1) * rhoe / rho ** GAMMA)
     return (-E + rhoe * (GAMMA + 1 - s)) / rhoe, rhou / rhoe, rhov / rhoe, -rho / rhoe
+
+
+def primitive_to_conservative_3d(rho, u, v, w, p):
+    """euler_variables.jl:15-27 (3D method)."""
+    return rho, rho * u, rho * v, rho * w, p / (GAMMA - 1) + .5 * rho * (u ** 2 + v ** 2 + w ** 2)
+
+
+def v_ufun_3d(rho, rhou, rhov, rhow, E):
+    """Entropy variables, euler_variables.jl:79-92 (3D method)."""
+    rhoe = E - .5 * (rhou ** 2 + rhov ** 2 + rhow ** 2) / rho
+    s = np.log((GAMMA - 1) * rhoe / rho ** GAMMA)
+    return (-E + rhoe * (GAMMA + 1 - s)) / rhoe, rhou / rhoe, rhov / rhoe, rhow / rhoe, -rho / rhoe

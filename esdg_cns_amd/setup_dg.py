@@ -433,3 +433,269 @@ def interp_geofacs_to_hybrid(md, Vh):
     for n in ("rxJ", "sxJ", "ryJ", "syJ"):
         setattr(md, n, np.asfortranarray(Vh @ getattr(md, n)))
     return md
+
+
+# =======================================================================================
+# 3D hexahedra: host-side mirror of init_reference_hex / init_mesh (3D) / uniform_hex_mesh and of the
+# operator assembly of examples/dg3D_euler_hex.jl:34-98.
+#
+#   init_reference_hex    src/SetupDG.jl:323-387        uniform_hex_mesh   src/UniformHexMesh.jl:25-76
+#   init_mesh (3D)        src/SetupDG.jl:389-434        hex_face_vertices  src/UniformHexMesh.jl:83-93 (*)
+#   geometric_factors 3D  src/geometric_factors.jl:34-67
+#   build_periodic_boundary_maps (3D)  src/node_map_functions.jl:139-213
+#
+# (*) the reference's hex_face_vertices is the bug behind the driver's "Currently broken" banner: it
+# returns CartesianIndex components instead of vertex ids.  The intended sets are used here.  The reference's
+# vertex conventions are kept (reference vertices s-fastest, mesh vertices x-fastest), which makes every
+# element map a reflection (J < 0); see DESIGN.md.
+# =======================================================================================
+def hex_face_vertices():
+    """1-based local vertex ids (2x2x2 meshgrid order: s fastest, then r, then t) on r=-1, r=+1, s=-1, s=+1, t=-1, t=+1."""
+    return [1, 2, 5, 6], [3, 4, 7, 8], [1, 3, 5, 7], [2, 4, 6, 8], [1, 2, 3, 4], [5, 6, 7, 8]
+
+
+def _kron3(T, R, S):
+    """operator acting on index n = i + n*(j + n*k) with S on i (s, fastest), R on j (r), T on k (t)."""
+    return np.kron(T, np.kron(R, S))
+
+
+def init_reference_hex(N, quad_nodes_1D=None):
+    """RefElemData of the degree-N hexahedron.  Nodal (LGL) and quadrature nodes are both ordered s fastest, then
+    r, then t (vec.(meshgrid(r1D,r1D,r1D)), src/Basis3DHex.jl:79-82, SetupDG.jl:361); faces r=-1, r=+1, s=-1, s=+1,
+    t=-1, t=+1 with face nodes (rquad slow, squad fast) as in SetupDG.jl:343-352."""
+    if quad_nodes_1D is None:
+        quad_nodes_1D = gauss_quad(0, 0, N)
+    r1D, w1D = (np.asarray(a, dtype=float) for a in quad_nodes_1D)
+    n1, nq1 = N + 1, r1D.size
+    rd = RefElemData()
+    rd.N, rd.dim = N, 3
+    rd.fv = hex_face_vertices()
+    rd.Nfaces = 6
+    x1, _ = gauss_lobatto_quad(0, 0, N)
+    idx = np.arange(n1 ** 3)
+    rd.s, rd.r, rd.t = x1[idx % n1], x1[(idx // n1) % n1], x1[idx // (n1 * n1)]
+    D1, I1 = lagrange_diff_1D(x1), np.eye(n1)
+    Dr, Ds, Dt = _kron3(I1, D1, I1), _kron3(I1, I1, D1), _kron3(D1, I1, I1)
+    v = np.arange(8)
+    sv, rv, tv = 2.0 * (v % 2) - 1, 2.0 * ((v // 2) % 2) - 1, 2.0 * (v // 4) - 1
+    rd.V1 = 0.125 * (1 + np.outer(rd.r, rv)) * (1 + np.outer(rd.s, sv)) * (1 + np.outer(rd.t, tv))
+
+    m = np.arange(nq1 * nq1)
+    rquad, squad = r1D[m // nq1], r1D[m % nq1]
+    wquad = w1D[m // nq1] * w1D[m % nq1]
+    e, zz = np.ones(nq1 * nq1), np.zeros(nq1 * nq1)
+    rd.rf = np.concatenate([-e, e, rquad, rquad, rquad, rquad])
+    rd.sf = np.concatenate([rquad, rquad, -e, e, squad, squad])
+    rd.tf = np.concatenate([squad, squad, squad, squad, -e, e])
+    rd.wf = np.tile(wquad, 6)
+    rd.nrJ = np.concatenate([-e, e, zz, zz, zz, zz])
+    rd.nsJ = np.concatenate([zz, zz, -e, e, zz, zz])
+    rd.ntJ = np.concatenate([zz, zz, zz, zz, -e, e])
+
+    q = np.arange(nq1 ** 3)
+    rd.sq, rd.rq, rd.tq = r1D[q % nq1], r1D[(q // nq1) % nq1], r1D[q // (nq1 * nq1)]
+    rd.wq = w1D[q % nq1] * w1D[(q // nq1) % nq1] * w1D[q // (nq1 * nq1)]
+    Iq = lagrange_interp_1D(x1, r1D)
+    Vq = _kron3(Iq, Iq, Iq)
+    M = Vq.T @ (rd.wq[:, None] * Vq)
+    Pq = np.linalg.solve(M, Vq.T * rd.wq[None, :])
+    Ls, Lr, Lt = lagrange_interp_1D(x1, rd.sf), lagrange_interp_1D(x1, rd.rf), lagrange_interp_1D(x1, rd.tf)
+    Vf = np.einsum("fk,fj,fi->fkji", Lt, Lr, Ls).reshape(rd.rf.size, n1 ** 3)
+    LIFT = np.linalg.solve(M, Vf.T * rd.wf[None, :])
+    rd.Vq, rd.M, rd.Pq = Vq, M, Pq
+    rd.Dr, rd.Ds, rd.Dt = _droptol(Dr, 1e-12), _droptol(Ds, 1e-12), _droptol(Dt, 1e-12)
+    rd.Vf, rd.LIFT = _droptol(Vf, 1e-12), _droptol(LIFT, 1e-12)
+    rd.r1D, rd.w1D = r1D, w1D
+    return rd
+
+
+def uniform_hex_mesh(Nx, Ny=None, Nz=None):
+    """Uniform Nx x Ny x Nz hex mesh of [-1,1]^3: VX, VY, VZ, EToV (K x 8, 1-based); vertices and elements both
+    numbered x fastest, then y, then z (src/UniformHexMesh.jl:25-80)."""
+    Ny = Nx if Ny is None else Ny
+    Nz = Nx if Nz is None else Nz
+    Nxp, Nyp, Nzp = Nx + 1, Ny + 1, Nz + 1
+    x1D, y1D, z1D = np.linspace(-1, 1, Nxp), np.linspace(-1, 1, Nyp), np.linspace(-1, 1, Nzp)
+    VX = np.tile(x1D, Nyp * Nzp)
+    VY = np.tile(np.repeat(y1D, Nxp), Nzp)
+    VZ = np.repeat(z1D, Nxp * Nyp)
+    e = np.arange(Nx * Ny * Nz, dtype=np.int64)
+    k = e // (Nx * Ny)
+    j = (e - k * Nx * Ny) // Nx
+    i = e % Nx
+    v0 = i + Nxp * j + Nxp * Nyp * k + 1
+    EToV = np.stack([v0, v0 + 1, v0 + Nxp, v0 + Nxp + 1, v0 + Nxp * Nyp, v0 + Nxp * Nyp + 1,
+                     v0 + Nxp * Nyp + Nxp, v0 + Nxp * Nyp + Nxp + 1], axis=1)
+    return VX, VY, VZ, EToV
+
+
+def geometric_factors_3d(x, y, z, Dr, Ds, Dt):
+    """Curl-conservative metric terms of src/geometric_factors.jl:34-67 -> rxJ,sxJ,txJ,ryJ,syJ,tyJ,rzJ,szJ,tzJ,J."""
+    def curl(a, b):
+        Fr, Fs, Ft = (Dr @ a) * b, (Ds @ a) * b, (Dt @ a) * b
+        return Dt @ Fs - Ds @ Ft, Dr @ Ft - Dt @ Fr, Ds @ Fr - Dr @ Fs
+    rxJ, sxJ, txJ = curl(y, z)
+    ryJ, syJ, tyJ = (-g for g in curl(x, z))
+    rzJ, szJ, tzJ = (-g for g in curl(y, x))
+    xr, xs, xt = Dr @ x, Ds @ x, Dt @ x
+    yr, ys, yt = Dr @ y, Ds @ y, Dt @ y
+    zr, zs, zt = Dr @ z, Ds @ z, Dt @ z
+    J = xr * (ys * zt - zs * yt) - yr * (xs * zt - zs * xt) + zr * (xs * yt - ys * xt)
+    return rxJ, sxJ, txJ, ryJ, syJ, tyJ, rzJ, szJ, tzJ, J
+
+
+def _match_face_nodes_nd(X1, X2, tol, chunk=32768):
+    """Like _match_face_nodes for faces with 2D node sets: identical ordering is tried first, the rest goes through
+    a chunked distance-matrix search (vectorised over faces)."""
+    nf, Nfp, _ = X1.shape
+    perm = np.tile(np.arange(Nfp, dtype=np.int64), (nf, 1))
+    matched = np.ones((nf, Nfp), dtype=bool)
+    ext = np.maximum(np.abs(X1.max(axis=1) - X2.min(axis=1)).sum(axis=1), np.abs(X2.max(axis=1) - X1.min(axis=1)).sum(axis=1))
+    ok_same = np.abs(X1 - X2).sum(axis=2).max(axis=1) < tol * ext
+    rest = np.nonzero(~ok_same)[0]
+    for c0 in range(0, rest.size, chunk):
+        f = rest[c0:c0 + chunk]
+        D = np.abs(X1[f][:, :, None, :] - X2[f][:, None, :, :]).sum(axis=3)
+        hit = D < tol * D.max(axis=(1, 2))[:, None, None]
+        matched[f] = hit.any(axis=2)
+        perm[f] = np.where(matched[f], hit.argmax(axis=2), np.arange(Nfp))
+    return perm, matched
+
+
+def _face_coords(rd, VXYZ, EToV, gfaces):
+    """physical coordinates of the face nodes of the global faces `gfaces` (0-based), straight from the vertices."""
+    Nfaces = rd.Nfaces
+    Nfp = rd.Vf.shape[0] // Nfaces
+    nv = EToV.shape[1]
+    VfV1 = (rd.Vf @ rd.V1).reshape(Nfaces, Nfp, nv)
+    en, fn = gfaces // Nfaces, gfaces % Nfaces
+    vn = EToV[en] - 1
+    W = VfV1[fn]
+    return np.stack([np.einsum("fpv,fv->fp", W, V[vn]) for V in VXYZ], axis=2)
+
+
+def init_mesh_3d(VXYZ, EToV, rd, elem_range=None):
+    """3D MeshData for elements [e0, e1) (default: all); md.mapP holds GLOBAL 1-based linear indices into
+    (Nfq x Kglobal).  Mirrors init_mesh((VX,VY,VZ),EToV,rd), src/SetupDG.jl:389-434."""
+    VX, VY, VZ = (np.asarray(v, dtype=float) for v in VXYZ)
+    EToV = np.asarray(EToV, dtype=np.int64)
+    Kg = EToV.shape[0]
+    e0, e1 = (0, Kg) if elem_range is None else elem_range
+    K = e1 - e0
+    md = MeshData()
+    Nfaces, Nfq = rd.Nfaces, rd.Vf.shape[0]
+    Nfp = Nfq // Nfaces
+    FToF = connect_mesh(EToV, rd.fv)
+    md.FToF_global, md.FToF = FToF, FToF[:, e0:e1]
+    md.K, md.Kglobal, md.elem_offset, md.dim = K, Kg, e0, 3
+    md.VX, md.VY, md.VZ, md.EToV = VX, VY, VZ, EToV
+    ev = EToV[e0:e1].T - 1
+    x, y, z = (np.asfortranarray(rd.V1 @ V[ev]) for V in (VX, VY, VZ))
+    md.x, md.y, md.z = x, y, z
+    md.xf, md.yf, md.zf = (np.asfortranarray(rd.Vf @ a) for a in (x, y, z))
+    f1 = np.arange(e0 * Nfaces, e1 * Nfaces, dtype=np.int64)
+    f2 = FToF.flatten(order="F")[f1] - 1
+    X1 = _face_coords(rd, (VX, VY, VZ), EToV, f1)
+    X2 = _face_coords(rd, (VX, VY, VZ), EToV, f2)
+    perm, matched = _match_face_nodes_nd(X1, X2, 1e-10)
+    mapM = (np.arange(e0 * Nfq, e1 * Nfq, dtype=np.int64) + 1).reshape(K * Nfaces, Nfp)
+    mapP = np.where(matched & (f2 != f1)[:, None], perm + (f2 * Nfp)[:, None] + 1, mapM)
+    md.mapM = np.asfortranarray(mapM.reshape(K, Nfq).T)
+    md.mapP = np.asfortranarray(mapP.reshape(K, Nfq).T)
+    md.mapB = md.mapM.flatten(order="F")[(md.mapM == md.mapP).flatten(order="F")]
+    geo = geometric_factors_3d(x, y, z, rd.Dr, rd.Ds, rd.Dt)
+    (md.rxJ, md.sxJ, md.txJ, md.ryJ, md.syJ, md.tyJ, md.rzJ, md.szJ, md.tzJ, md.J) = (np.asfortranarray(a) for a in geo)
+    md.xq, md.yq, md.zq = (np.asfortranarray(rd.Vq @ a) for a in (x, y, z))
+    md.wJq = np.asfortranarray(rd.wq[:, None] * (rd.Vq @ md.J))
+    _hex_normals(md, rd)
+    return md
+
+
+def _hex_normals(md, rd):
+    """nxJ = nrJ.*(Vf*rxJ) + nsJ.*(Vf*sxJ) + ntJ.*(Vf*txJ) ... (SetupDG.jl:424-431); needs nodal (Np x K) metrics."""
+    nr, ns, nt = rd.nrJ[:, None], rd.nsJ[:, None], rd.ntJ[:, None]
+    Vf = rd.Vf
+    md.nxJ = np.asfortranarray(nr * (Vf @ md.rxJ) + ns * (Vf @ md.sxJ) + nt * (Vf @ md.txJ))
+    md.nyJ = np.asfortranarray(nr * (Vf @ md.ryJ) + ns * (Vf @ md.syJ) + nt * (Vf @ md.tyJ))
+    md.nzJ = np.asfortranarray(nr * (Vf @ md.rzJ) + ns * (Vf @ md.szJ) + nt * (Vf @ md.tzJ))
+    md.sJ = np.asfortranarray(np.sqrt(md.nxJ ** 2 + md.nyJ ** 2 + md.nzJ ** 2))
+
+
+def build_periodic_boundary_maps_3d(md, rd, LX, LY, LZ):
+    """Periodic partner nodes of the local boundary nodes md.mapB (mapP[mapB] = mapPB), semantics of
+    src/node_map_functions.jl:139-213; boundary faces are paired globally by sorting their centroids
+    (O(Nb log Nb) instead of the reference's O(Nb^2) double loop)."""
+    VXYZ, EToV = (md.VX, md.VY, md.VZ), md.EToV
+    Nfaces, Nfq = rd.Nfaces, rd.Vf.shape[0]
+    Nfp = Nfq // Nfaces
+    NODETOL = 1e-12
+    L = (LX, LY, LZ)
+    FToFg = md.FToF_global.flatten(order="F")
+    bfaces = np.nonzero(FToFg == np.arange(1, FToFg.size + 1))[0]
+    Xb = _face_coords(rd, VXYZ, EToV, bfaces)                      # (Nb, Nfp, 3)
+    C = Xb.mean(axis=1)
+    partner = np.full(bfaces.size, -1, dtype=np.int64)
+    normal_dir = np.full(bfaces.size, -1, dtype=np.int64)
+    for d in range(3):
+        c = C[:, d]
+        lo = np.nonzero(np.abs(c - c.min()) < NODETOL * L[d])[0]
+        hi = np.nonzero(np.abs(c - c.max()) < NODETOL * L[d])[0]
+        a, b = [t for t in range(3) if t != d]
+        key = lambda s: np.lexsort((np.round(C[s, b] / L[b] * 1e9), np.round(C[s, a] / L[a] * 1e9)))
+        lo, hi = lo[key(lo)], hi[key(hi)]
+        if lo.size != hi.size or np.any(np.abs(C[lo][:, [a, b]] - C[hi][:, [a, b]]) >= 1e-9 * max(L)):
+            raise ValueError("periodic boundary faces do not pair up")
+        partner[lo], partner[hi] = hi, lo
+        normal_dir[lo] = normal_dir[hi] = d
+    if np.any(partner < 0):
+        raise ValueError("boundary face off the box")
+    tang = np.array([[1, 2], [0, 2], [0, 1]])[normal_dir]          # (Nb, 2)
+    T1 = np.take_along_axis(Xb, tang[:, None, :], axis=2)
+    T2 = np.take_along_axis(Xb[partner], tang[:, None, :], axis=2)
+    perm, matched = _match_face_nodes_nd(T1, T2, 1e-9)
+    if not matched.all():
+        raise ValueError("periodic node matching failed")
+    gmapP_b = perm + (bfaces[partner] * Nfp)[:, None] + 1
+    mapB = md.mapB
+    if not mapB.size:
+        return np.zeros(0, dtype=np.int64)
+    rows = np.searchsorted(bfaces, (mapB - 1) // Nfp)
+    return gmapP_b[rows, (mapB - 1) % Nfp]
+
+
+def make_periodic_3d(md, rd, LX=2.0, LY=2.0, LZ=2.0):
+    """examples/dg3D_euler_hex.jl:59-65."""
+    mapPB = build_periodic_boundary_maps_3d(md, rd, LX, LY, LZ)
+    mp = md.mapP.flatten(order="F")
+    mp[md.mapB - 1 - md.elem_offset * md.mapP.shape[0]] = mapPB
+    md.mapP = np.asfortranarray(mp.reshape(md.mapP.shape, order="F"))
+    return md
+
+
+def hex_ops(rd):
+    """Operators of examples/dg3D_euler_hex.jl:34-56, 92-98 as a dict: skew hybridized SBP matrices, Ef, and the
+    quadrature-basis Vh, Ph (= 2 W^-1 Vh', note the 2), Lf."""
+    M, Pq, Vf, wf, wq = rd.M, rd.Pq, rd.Vf, rd.wf, rd.wq
+    Ef = Vf @ Pq
+    out = {}
+    for name, D, n in (("Qrhskew", rd.Dr, rd.nrJ), ("Qshskew", rd.Ds, rd.nsJ), ("Qthskew", rd.Dt, rd.ntJ)):
+        Q = Pq.T @ M @ D @ Pq
+        B = np.diag(wf * n)
+        Qh = .5 * np.block([[Q - Q.T, Ef.T @ B], [-B @ Ef, B]])
+        out[name] = .5 * (Qh - Qh.T)
+    Vh = _droptol(np.vstack([np.eye(wq.size), Ef]), 1e-12)
+    out.update(Ef=Ef, Vh=Vh, Ph=_droptol(2 * Vh.T / wq[:, None], 1e-12), Lf=_droptol((Ef.T * wf[None, :]) / wq[:, None], 1e-12))
+    return out
+
+
+def hex_driver_geometry(md, rd, hybrid=True):
+    """dg3D_euler_hex.jl:88-98: metrics interpolated to the hybrid nodes ([Vq;Vf]*), J and wJq at the quadrature
+    nodes.  hybrid=False keeps one row per element instead of Nh (affine meshes; saves 9*Nh*K doubles of host memory
+    at scale -- esdg_hex_mesh_t.geo_ld says which)."""
+    Vhg = np.vstack([rd.Vq, rd.Vf])
+    for n in ("rxJ", "sxJ", "txJ", "ryJ", "syJ", "tyJ", "rzJ", "szJ", "tzJ"):
+        g = getattr(md, n)
+        setattr(md, n, np.asfortranarray(Vhg @ g) if hybrid else np.asfortranarray((rd.Vq[:1] @ g)))
+    md.J = np.asfortranarray(rd.Vq @ md.J)
+    md.wJq = np.asfortranarray(rd.wq[:, None] * md.J)
+    return md

@@ -49,7 +49,10 @@ typedef enum {
    * (:447-528) + rhs_viscous! (:749-849): state = nodal (LGL) coefficients, LF factor .25 (:508). */
   ESDG_CNS_MODAL = 1,
   /* rhs_inviscid! alone (same file), i.e. modal Euler. */
-  ESDG_EULER_MODAL = 2
+  ESDG_EULER_MODAL = 2,
+  /* `rhs` of examples/dg3D_euler_hex.jl:167-222 (hexahedra, 5 fields, state at the Gauss nodes, Ph includes
+   * the factor 2 (:96), LF factor `0*.25` (:193) -> esdg_phys_t.lf_scale).  Created with esdg_create_hex. */
+  ESDG_EULER_HEX_COLLOCATED = 3
 } esdg_formulation;
 
 /* Reference-element operators: fields of `rd::RefElemData` (src/SetupDG.jl:38-75) and of the
@@ -111,10 +114,41 @@ typedef struct {
   double Re, mu, lambda, Pr; /* cavity_optimized.jl:33-36; lambda as passed to init_visc_fxn (:646) */
 } esdg_phys_t;
 
+/* Hexahedral path: operators of examples/dg3D_euler_hex.jl:34-98 (quadrature basis) and the 3D MeshData
+ * fields the driver holds when it calls `rhs` (:167).  Same conventions as above. */
+typedef struct {
+  int32_t N;    /* polynomial degree, 1..3 (one 64-lane wavefront per element) */
+  int32_t Nq;   /* (N+1)^3 */
+  int32_t Nfq;  /* 6 (N+1)^2 */
+  const double *Qrhskew, *Qshskew, *Qthskew; /* (Nh x Nh), dg3D_euler_hex.jl:49-51 */
+  const double* Ph;  /* (Nq x Nh) 2 W^-1 Vh', :96 */
+  const double* Lf;  /* (Nq x Nfq) W^-1 Ef' Wf, :97 */
+  const double* Ef;  /* (Nfq x Nq) Vf*Pq, :39 */
+  const double *wq, *wf; /* may be NULL (not needed by the kernels) */
+} esdg_hex_ops_t;
+
+typedef struct {
+  int64_t K;
+  int32_t geo_ld;  /* rows of the metric arrays: Nh as stored by the driver (:88-90), or any >= 1 (affine: row 1 is used) */
+  const double *rxJ, *sxJ, *txJ, *ryJ, *syJ, *tyJ, *rzJ, *szJ, *tzJ; /* (geo_ld x K) */
+  const double* J;    /* (Nq x K) = Vq*J, :94 */
+  const double* wJq;  /* (Nq x K), diagnostics only, may be NULL */
+  const double *nxJ, *nyJ, *nzJ, *sJ; /* (Nfq x K), :81-86 */
+  const int64_t* mapP; /* (Nfq x K) 1-based GLOBAL linear index (periodic patch applied, :59-65) */
+  int64_t elem_offset, Kglobal;
+  int32_t nranks, rank;
+  const int64_t* rank_offsets;
+} esdg_hex_mesh_t;
+
 /* ---- life cycle ------------------------------------------------------------------------ */
 /* Copies operators/mesh to the device, derives the sparse collocated operators, converts
  * mapP to 0-based int32 with ghost slots for off-rank neighbours. */
 int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_t* phys, esdg_ctx** out);
+/* Hexahedral engine (replaces `rhs`, dg3D_euler_hex.jl:167-222).  The returned context is driven through the
+ * same entry points as the 2D ones (esdg_workspace_bytes .. esdg_rhs_lsrk, esdg_rhstest, esdg_halo_*); states are
+ * [5][K][Nq], two phases, one face-trace exchange (rho,u,v,w,beta). */
+int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, const esdg_phys_t* phys, esdg_ctx** out);
+int esdg_num_fields(const esdg_ctx* ctx);   /* 4 (2D) or 5 (hex) */
 int esdg_destroy(esdg_ctx* ctx);
 const char* esdg_last_error(void);
 const char* esdg_version(void);
@@ -127,7 +161,7 @@ int esdg_bind_workspace(esdg_ctx* ctx, void* dev_ptr, size_t bytes);
 /* ---- the hot path ------------------------------------------------------------------------
  * One RHS evaluation = phases 0..esdg_num_phases()-1; between phase p and p+1 the face traces
  * of off-rank neighbours must be exchanged (esdg_halo_segment).  With nranks==1 esdg_rhs()
- * runs all phases back to back.  Q_dev / rhs_dev: device buffers [4][K][Np].
+ * runs all phases back to back.  Q_dev / rhs_dev: device buffers [nfld][K][Np] (nfld = esdg_num_fields).
  * Replaces: rhs (euler_quad.jl:141), rhs_inviscid! / rhs_viscous! / rhsRK!
  * (cavity_optimized.jl:447, 749, 955).  All launches are asynchronous on `stream`. */
 int esdg_num_phases(const esdg_ctx* ctx);
@@ -154,7 +188,7 @@ int esdg_rhstest(esdg_ctx* ctx, const double* Q_dev, const double* rhs_dev, doub
 
 /* Literal drop-in with host arrays (Julia Matrix{Float64} per field): H2D, rhs, D2H.
  * PCIe-bound -- for validation, not for time stepping. nranks must be 1. */
-int esdg_rhs_host(esdg_ctx* ctx, const double* const Q[4], double* const rhs[4]);
+int esdg_rhs_host(esdg_ctx* ctx, const double* const* Q, double* const* rhs);  /* esdg_num_fields() pointers each */
 
 /* ---- halo exchange plan (element-index sharding) ---------------------------------------- */
 /* The reference's three x[mapP] gathers (QM/Uf+lam :496-511, VUf :776, sigma_f :813-814) become

@@ -39,6 +39,14 @@ class _CnsT(C.Structure):
                    ("inviscid_dissp", C.c_int), ("viscous_dissp", C.c_int)])
 
 
+class _HexT(C.Structure):
+    _fields_ = ([("K", C.c_int), ("Nq", C.c_int), ("Nfq", C.c_int)]
+                + [(n, _dp) for n in ("Ef", "Qr", "Qs", "Qt", "Ph", "Lf")]
+                + [("rowptr", _ip), ("colidx", _ip), ("vgeo", _dp * 9)]
+                + [(n, _dp) for n in ("J", "wJq", "nxJ", "nyJ", "nzJ", "sJ")]
+                + [("mapP", _lp), ("lf_scale", C.c_double)])
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -58,6 +66,13 @@ def lib():
         L.oracle_cns_rhs_viscous.restype = C.c_double
         L.oracle_cns_rhs_viscous.argtypes = [C.POINTER(_CnsT), _dp, _dp]
         L.oracle_cns_rhsRK.argtypes = [C.POINTER(_CnsT), _dp, _dp, C.c_int, _dp]
+        L.oracle_euler_fluxes_3d.argtypes = [_dp] * 7
+        L.oracle_v_ufun_3d.argtypes = [_dp, _dp]
+        L.oracle_u_vfun_3d.argtypes = [_dp, _dp]
+        L.oracle_betafun_3d.restype = C.c_double
+        L.oracle_betafun_3d.argtypes = [_dp]
+        L.oracle_hex_rhs.restype = C.c_double
+        L.oracle_hex_rhs.argtypes = [C.POINTER(_HexT), _dp, C.c_int, _dp]
         L.oracle_set_threads.argtypes = [C.c_int]
         L.oracle_get_max_threads.restype = C.c_int
         _LIB = L
@@ -113,6 +128,30 @@ def u_vfun(V):
     V = np.array(V, dtype=float)
     U = np.zeros(4)
     lib().oracle_u_vfun(_d(V), _d(U))
+    return U
+
+
+def euler_fluxes_3d(UL, UR):
+    UL = np.array(UL, dtype=float)
+    UR = np.array(UR, dtype=float)
+    lL = np.log(UL[[0, 4]])
+    lR = np.log(UR[[0, 4]])
+    Fx, Fy, Fz = np.zeros(5), np.zeros(5), np.zeros(5)
+    lib().oracle_euler_fluxes_3d(_d(UL), _d(UR), _d(lL), _d(lR), _d(Fx), _d(Fy), _d(Fz))
+    return Fx, Fy, Fz
+
+
+def v_ufun_3d(U):
+    U = np.array(U, dtype=float)
+    V = np.zeros(5)
+    lib().oracle_v_ufun_3d(_d(U), _d(V))
+    return V
+
+
+def u_vfun_3d(V):
+    V = np.array(V, dtype=float)
+    U = np.zeros(5)
+    lib().oracle_u_vfun_3d(_d(V), _d(U))
     return U
 
 
@@ -172,6 +211,32 @@ def build_cns_problem(N, Kx, Ky, bc="periodic", BCTYPE=1, Re=1000.0, Pr=.71):
         pr = (1 / (.3 ** 2 * ph.GAMMA)) * rho ** ph.GAMMA
     p.Q = [np.asfortranarray(q) for q in ph.primitive_to_conservative(rho, u, v, pr)]
     p.rd, p.md, p.ops, p.VX, p.VY, p.EToV, p.N = rd, md, ops, VX, VY, EToV, N
+    return p
+
+
+def hex_smooth_state(x, y, z):
+    """Deterministic smooth periodic state on [-1,1]^3 (the script's own initial condition is random,
+    dg3D_euler_hex.jl:101-108: `2 .+ .1*rand`, v=1, `p = 1 + .1*rand`)."""
+    rho = 2 + .5 * np.sin(np.pi * x) * np.cos(np.pi * y)
+    u = .3 * np.sin(np.pi * z + .2)      # phases keep u_n away from exact zeros at nodes: the LF wavespeed's
+    v = 1 + .1 * np.cos(np.pi * x)       # sqrt(|u_n|) (quirk Q1) turns 1e-17 noise there into 3e-9
+    w = .1 * np.sin(np.pi * (x + y) + .3)
+    p = 1 + .2 * np.cos(np.pi * z) * np.sin(np.pi * y)
+    return rho, u, v, w, p
+
+
+def build_hex_problem(N, Kx, Ky=None, Kz=None):
+    """examples/dg3D_euler_hex.jl:21-98: periodic box [-1,1]^3, Gauss collocation, a = 0 (affine)."""
+    Ky = Kx if Ky is None else Ky
+    Kz = Kx if Kz is None else Kz
+    p = Problem()
+    VX, VY, VZ, EToV = rs.uniform_hex_mesh(Kx, Ky, Kz)
+    rd = rs.init_reference_hex(N, rs.gauss_quad(0, 0, N))
+    md = rs.init_mesh_3D(VX, VY, VZ, EToV, rd)
+    rs.make_periodic_3D(md, rd)
+    ops = rs.hex_driver_setup(md, rd, a=0.0)
+    p.Q = [np.asfortranarray(q) for q in ph.primitive_to_conservative_3D(*hex_smooth_state(md.xq, md.yq, md.zq))]
+    p.rd, p.md, p.ops, p.VX, p.VY, p.VZ, p.EToV, p.N = rd, md, ops, VX, VY, VZ, EToV, N
     return p
 
 
@@ -263,3 +328,42 @@ class CnsOracle:
     def rhsRK(self, Q, compute_diag=True):
         out, diag = self.rhsRK_stacked(stack(Q), compute_diag)
         return unstack(out), diag[0], diag[1]
+
+
+class HexOracle:
+    """C restatement of `rhs` (examples/dg3D_euler_hex.jl:167-222) bound to one problem."""
+
+    def __init__(self, p, lf_scale=0.0):
+        md, ops = p.md, p.ops
+        c = np.ascontiguousarray
+        rowptr, col = [0], []
+        for ids in ops["Qnzids"]:
+            col += [i - 1 for i in ids]
+            rowptr.append(len(col))
+        self.keep = dict(Ef=c(ops["Ef"]), Qr=c(ops["Qrh_sparse"]), Qs=c(ops["Qsh_sparse"]), Qt=c(ops["Qth_sparse"]),
+                         Ph=c(ops["Ph"]), Lf=c(ops["Lf"]), J=ek(md.J), wJq=ek(md.wJq), nxJ=ek(md.nxJ), nyJ=ek(md.nyJ),
+                         nzJ=ek(md.nzJ), sJ=ek(md.sJ))
+        self.geo = [ek(getattr(md, n)) for n in ("rxJ", "sxJ", "txJ", "ryJ", "syJ", "tyJ", "rzJ", "szJ", "tzJ")]
+        self.rowptr = np.array(rowptr, dtype=np.int32)
+        self.col = np.array(col, dtype=np.int32)
+        self.mapP = np.ascontiguousarray(md.mapP.T.astype(np.int64))
+        t = _HexT()
+        t.K, t.Nq, t.Nfq = md.K, ops["Ph"].shape[0], ops["Lf"].shape[1]
+        for k, v in self.keep.items():
+            setattr(t, k, _d(v))
+        t.rowptr = self.rowptr.ctypes.data_as(_ip)
+        t.colidx = self.col.ctypes.data_as(_ip)
+        for m in range(9):
+            t.vgeo[m] = _d(self.geo[m])
+        t.mapP = self.mapP.ctypes.data_as(_lp)
+        t.lf_scale = float(lf_scale)
+        self.t = t
+
+    def rhs_stacked(self, Qs, compute_rhstest=False):
+        out = np.zeros_like(Qs)
+        rt = lib().oracle_hex_rhs(C.byref(self.t), _d(Qs), int(compute_rhstest), _d(out))
+        return out, rt
+
+    def rhs(self, Q, compute_rhstest=False):
+        out, rt = self.rhs_stacked(stack(Q), compute_rhstest)
+        return unstack(out), rt

@@ -647,3 +647,209 @@ void oracle_cns_rhsRK(const oracle_cns_t* c, const double* Q, double* rhs, int c
   }
   free(visc);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Euler, collocated hex:  examples/dg3D_euler_hex.jl:122-222 (3D physics: euler_fluxes.jl:51-89,
+ * euler_variables.jl with 3-component momentum).  The reference flags the driver broken (:1): the
+ * breakage is in hex_face_vertices (src/UniformHexMesh.jl:83-93), i.e. in the set-up, not in `rhs`;
+ * see oracle/ref_setup.py.  lf_scale replaces the literal 0*.25 of :193.
+ * ---------------------------------------------------------------------------------------- */
+/* euler_fluxes.jl:51-89; UL/UR = (rho,u,v,w,beta) */
+void oracle_euler_fluxes_3d(const double* UL, const double* UR, const double* logL, const double* logR,
+                            double* Fx, double* Fy, double* Fz) {
+  double rhoL = UL[0], uL = UL[1], vL = UL[2], wL = UL[3], betaL = UL[4];
+  double rhoR = UR[0], uR = UR[1], vR = UR[2], wR = UR[3], betaR = UR[4];
+  double rholog = oracle_logmean(rhoL, rhoR, logL[0], logR[0]);
+  double betalog = oracle_logmean(betaL, betaR, logL[1], logR[1]);
+  double rhoavg = .5 * (rhoL + rhoR);
+  double uavg = .5 * (uL + uR);
+  double vavg = .5 * (vL + vR);
+  double wavg = .5 * (wL + wR);
+  double unorm = uL * uR + vL * vR + wL * wR;
+  double pa = rhoavg / (betaL + betaR);
+  double E_plus_p = rholog / (2 * (GAMMA - 1) * betalog) + pa + .5 * rholog * unorm;
+  Fx[0] = rholog * uavg;
+  Fx[1] = Fx[0] * uavg + pa;
+  Fx[2] = Fx[0] * vavg;
+  Fx[3] = Fx[0] * wavg;
+  Fx[4] = E_plus_p * uavg;
+  Fy[0] = rholog * vavg;
+  Fy[1] = Fx[2];
+  Fy[2] = Fy[0] * vavg + pa;
+  Fy[3] = Fy[0] * wavg;
+  Fy[4] = E_plus_p * vavg;
+  Fz[0] = rholog * wavg;
+  Fz[1] = Fx[3];
+  Fz[2] = Fy[3];
+  Fz[3] = Fz[0] * wavg + pa;
+  Fz[4] = E_plus_p * wavg;
+}
+
+/* euler_variables.jl:79-92, 5 fields */
+void oracle_v_ufun_3d(const double* U, double* V) {
+  double rho = U[0], E = U[4];
+  double rhoe = E - .5 * (U[1] * U[1] + U[2] * U[2] + U[3] * U[3]) / rho;
+  double sU = log((GAMMA - 1) * rhoe / pow(rho, GAMMA));
+  V[0] = (-E + rhoe * (GAMMA + 1 - sU)) / rhoe;
+  V[1] = U[1] / rhoe;
+  V[2] = U[2] / rhoe;
+  V[3] = U[3] / rhoe;
+  V[4] = (-rho) / rhoe;
+}
+
+/* euler_variables.jl:95-120, 5 fields */
+void oracle_u_vfun_3d(const double* V, double* U) {
+  double v5 = V[4];
+  double vUnorm = V[1] * V[1] + V[2] * V[2] + V[3] * V[3];
+  double s = GAMMA - V[0] + vUnorm / (2 * v5);
+  double rhoeV = pow((GAMMA - 1) / pow(-v5, GAMMA), 1 / (GAMMA - 1)) * exp(-s / (GAMMA - 1));
+  U[0] = rhoeV * (-v5);
+  U[1] = rhoeV * V[1];
+  U[2] = rhoeV * V[2];
+  U[3] = rhoeV * V[3];
+  U[4] = rhoeV * (1 - vUnorm / (2 * v5));
+}
+
+/* euler_variables.jl:30-48, 5 fields */
+double oracle_betafun_3d(const double* U) {
+  double rhounorm = (U[1] * U[1] + U[2] * U[2] + U[3] * U[3]) / U[0];
+  double p = (GAMMA - 1) * (U[4] - .5 * rhounorm);
+  return U[0] / (2 * p);
+}
+
+typedef struct {
+  int K, Nq, Nfq;
+  const double *Ef /*Nfq x Nq*/, *Qr, *Qs, *Qt /*Nh x Nh droptol'd*/, *Ph /*Nq x Nh, includes the 2*/, *Lf /*Nq x Nfq*/;
+  const int *rowptr, *colidx; /* Qnzids, 0-based */
+  const double* vgeo[9];      /* rxJ,sxJ,txJ,ryJ,syJ,tyJ,rzJ,szJ,tzJ: [K][Nh] */
+  const double *J, *wJq;      /* [K][Nq] */
+  const double *nxJ, *nyJ, *nzJ, *sJ; /* [K][Nfq] */
+  const int64_t* mapP;        /* [K][Nfq] 1-based */
+  double lf_scale;
+} oracle_hex_t;
+
+/* sparse_hadamard_sum, dg3D_euler_hex.jl:122-164 (metric of a pair = average of the two nodes, :145-146) */
+static void sparse_hadamard_sum_hex(const oracle_hex_t* c, const double* Qhe /*[5][Nh]*/, const double* ge /*[9][Nh]*/,
+                                    double* out /*[5][Nh]*/) {
+  const int Nh = c->Nq + c->Nfq;
+  double lrho[512], lbeta[512];
+  for (int i = 0; i < Nh; ++i) {
+    lrho[i] = log(Qhe[i]);
+    lbeta[i] = log(Qhe[4 * Nh + i]);
+  }
+  for (int i = 0; i < Nh; ++i) {
+    double Qi[5], li[2] = {lrho[i], lbeta[i]}, rhsi[5] = {0, 0, 0, 0, 0};
+    for (int f = 0; f < 5; ++f) Qi[f] = Qhe[f * Nh + i];
+    for (int t = c->rowptr[i]; t < c->rowptr[i + 1]; ++t) {
+      const int j = c->colidx[t];
+      double Qj[5], lj[2] = {lrho[j], lbeta[j]}, g[9], Fx[5], Fy[5], Fz[5];
+      for (int f = 0; f < 5; ++f) Qj[f] = Qhe[f * Nh + j];
+      for (int m = 0; m < 9; ++m) g[m] = .5 * (ge[m * Nh + i] + ge[m * Nh + j]);
+      oracle_euler_fluxes_3d(Qi, Qj, li, lj, Fx, Fy, Fz);
+      for (int f = 0; f < 5; ++f) {
+        double Fr = g[0] * Fx[f] + g[3] * Fy[f] + g[6] * Fz[f];
+        double Fs = g[1] * Fx[f] + g[4] * Fy[f] + g[7] * Fz[f];
+        double Ft = g[2] * Fx[f] + g[5] * Fy[f] + g[8] * Fz[f];
+        rhsi[f] += c->Qr[i * Nh + j] * Fr + c->Qs[i * Nh + j] * Fs + c->Qt[i * Nh + j] * Ft;
+      }
+    }
+    for (int f = 0; f < 5; ++f) out[f * Nh + i] = rhsi[f];
+  }
+}
+
+/* rhs, dg3D_euler_hex.jl:167-222.  Q, rhs: [5][K][Nq].  Returns rhstest (0 unless compute_rhstest). */
+double oracle_hex_rhs(const oracle_hex_t* c, const double* Q, int compute_rhstest, double* rhs) {
+  const int K = c->K, Nq = c->Nq, Nfq = c->Nfq, Nh = Nq + Nfq;
+  const size_t KNq = (size_t)K * Nq, KNf = (size_t)K * Nfq, KNh = (size_t)K * Nh;
+  if (Nh > 512) return NAN;
+  double* VU = (double*)malloc(5 * KNq * sizeof(double));
+  double* VUf = (double*)malloc(5 * KNf * sizeof(double));
+  double* Uf = (double*)malloc(5 * KNf * sizeof(double));
+  double* Qh = (double*)malloc(5 * KNh * sizeof(double));
+  double* lam = (double*)malloc(KNf * sizeof(double));
+  double* flux = (double*)malloc(5 * KNf * sizeof(double));
+  /* :174-176 */
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (size_t n = 0; n < KNq; ++n) {
+    double U[5], V[5];
+    for (int f = 0; f < 5; ++f) U[f] = Q[f * KNq + n];
+    oracle_v_ufun_3d(U, V);
+    for (int f = 0; f < 5; ++f) VU[f * KNq + n] = V[f];
+  }
+  for (int f = 0; f < 5; ++f) matmul_elems(c->Ef, Nfq, Nq, VU + f * KNq, VUf + f * KNf, K);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (size_t n = 0; n < KNf; ++n) {
+    double V[5], U[5];
+    for (int f = 0; f < 5; ++f) V[f] = VUf[f * KNf + n];
+    oracle_u_vfun_3d(V, U);
+    for (int f = 0; f < 5; ++f) Uf[f * KNf + n] = U[f];
+  }
+  /* :177-182 Uh = vcat(Q,Uf); beta; Qh = (rho,u,v,w,beta) */
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (int e = 0; e < K; ++e)
+    for (int i = 0; i < Nh; ++i) {
+      double U[5];
+      for (int f = 0; f < 5; ++f)
+        U[f] = i < Nq ? Q[f * KNq + (size_t)e * Nq + i] : Uf[f * KNf + (size_t)e * Nfq + (i - Nq)];
+      size_t o = (size_t)e * Nh + i;
+      Qh[o] = U[0];
+      Qh[KNh + o] = U[1] / U[0];
+      Qh[2 * KNh + o] = U[2] / U[0];
+      Qh[3 * KNh + o] = U[3] / U[0];
+      Qh[4 * KNh + o] = oracle_betafun_3d(U);
+    }
+  /* :189-192 lam */
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (size_t n = 0; n < KNf; ++n) {
+    double rhoU_n = (Uf[KNf + n] * c->nxJ[n] + Uf[2 * KNf + n] * c->nyJ[n] + Uf[3 * KNf + n] * c->nzJ[n]) / c->sJ[n];
+    lam[n] = fabs(oracle_wavespeed(Uf[n], rhoU_n, Uf[4 * KNf + n]));
+  }
+  /* :185-198 QM/QP, LFc, surface flux */
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (int e = 0; e < K; ++e)
+    for (int i = 0; i < Nfq; ++i) {
+      size_t n = (size_t)e * Nfq + i;
+      size_t p = (size_t)(c->mapP[n] - 1);
+      size_t ep = p / Nfq, ip = p % Nfq;
+      size_t om = (size_t)e * Nh + Nq + i, op = ep * Nh + Nq + ip;
+      double QM[5], QP[5], Fx[5], Fy[5], Fz[5];
+      for (int f = 0; f < 5; ++f) {
+        QM[f] = Qh[f * KNh + om];
+        QP[f] = Qh[f * KNh + op];
+      }
+      double lM[2] = {log(QM[0]), log(QM[4])}, lP[2] = {log(QP[0]), log(QP[4])};
+      oracle_euler_fluxes_3d(QM, QP, lM, lP, Fx, Fy, Fz);
+      double LFc = c->lf_scale * fmax(lam[n], lam[p]) * c->sJ[n];
+      for (int f = 0; f < 5; ++f)
+        flux[f * KNf + n] = Fx[f] * c->nxJ[n] + Fy[f] * c->nyJ[n] + Fz[f] * c->nzJ[n] - LFc * (Uf[f * KNf + p] - Uf[f * KNf + n]);
+    }
+  for (int f = 0; f < 5; ++f) matmul_elems(c->Lf, Nq, Nfq, flux + f * KNf, rhs + f * KNq, K);
+  /* :200-210 volume loop */
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (int e = 0; e < K; ++e) {
+    double* Qhe = (double*)malloc((size_t)(5 + 9 + 5) * Nh * sizeof(double));
+    double* ge = Qhe + 5 * Nh;
+    double* QFe = ge + 9 * Nh;
+    for (int f = 0; f < 5; ++f)
+      for (int i = 0; i < Nh; ++i) Qhe[f * Nh + i] = Qh[f * KNh + (size_t)e * Nh + i];
+    for (int m = 0; m < 9; ++m)
+      for (int i = 0; i < Nh; ++i) ge[m * Nh + i] = c->vgeo[m][(size_t)e * Nh + i];
+    sparse_hadamard_sum_hex(c, Qhe, ge, QFe);
+    for (int f = 0; f < 5; ++f)
+      for (int i = 0; i < Nq; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < Nh; ++j) s += c->Ph[i * Nh + j] * QFe[f * Nh + j];
+        rhs[f * KNq + (size_t)e * Nq + i] += s;
+      }
+    free(Qhe);
+  }
+  /* :212 */
+  for (int f = 0; f < 5; ++f)
+    for (size_t n = 0; n < KNq; ++n) rhs[f * KNq + n] = -rhs[f * KNq + n] / c->J[n];
+  double rhstest = 0.0;
+  if (compute_rhstest)
+    for (int f = 0; f < 5; ++f)
+      for (size_t n = 0; n < KNq; ++n) rhstest += c->wJq[n] * VU[f * KNq + n] * rhs[f * KNq + n];
+  free(VU); free(VUf); free(Uf); free(Qh); free(lam); free(flux);
+  return rhstest;
+}

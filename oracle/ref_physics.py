@@ -118,3 +118,88 @@ def vortex(x, y, t, gamma=1.4):
     rho = rho ** (1 / (gamma - 1))
     p = rho ** gamma
     return rho, u, v, p
+
+
+# ----------------------------------------------------------------------------------
+# 3D members of the same module (used by examples/dg3D_euler_hex.jl)
+# ----------------------------------------------------------------------------------
+def euler_fluxes_3D(rhoL, uL, vL, wL, betaL, rhoR, uR, vR, wR, betaR, rhologL, betalogL, rhologR, betalogR):
+    """examples/EntropyStableEuler/euler_fluxes.jl:51-89."""
+    rholog = logmean(rhoL, rhoR, rhologL, rhologR)
+    betalog = logmean(betaL, betaR, betalogL, betalogR)
+    rhoavg = .5 * (rhoL + rhoR)
+    uavg = .5 * (uL + uR)
+    vavg = .5 * (vL + vR)
+    wavg = .5 * (wL + wR)
+    unorm = uL * uR + vL * vR + wL * wR
+    pa = rhoavg / (betaL + betaR)
+    E_plus_p = rholog / (2 * (GAMMA - 1) * betalog) + pa + .5 * rholog * unorm
+    FxS1 = rholog * uavg
+    FxS2 = FxS1 * uavg + pa
+    FxS3 = FxS1 * vavg
+    FxS4 = FxS1 * wavg
+    FxS5 = E_plus_p * uavg
+    FyS1 = rholog * vavg
+    FyS2 = FxS3
+    FyS3 = FyS1 * vavg + pa
+    FyS4 = FyS1 * wavg
+    FyS5 = E_plus_p * vavg
+    FzS1 = rholog * wavg
+    FzS2 = FxS4
+    FzS3 = FyS4
+    FzS4 = FzS1 * wavg + pa
+    FzS5 = E_plus_p * wavg
+    return (FxS1, FxS2, FxS3, FxS4, FxS5), (FyS1, FyS2, FyS3, FyS4, FyS5), (FzS1, FzS2, FzS3, FzS4, FzS5)
+
+
+def euler_fluxes_UL_UR_3D(UL, UR):
+    """euler_fluxes.jl:9-20 with 5-tuples (rho,u,v,w,beta): logs computed on the fly."""
+    return euler_fluxes_3D(*UL, *UR, np.log(UL[0]), np.log(UL[4]), np.log(UR[0]), np.log(UR[4]))
+
+
+def pfun_3D(rho, rhou, rhov, rhow, E):
+    """euler_variables.jl:42-48 with rhoU = (rhou,rhov,rhow)."""
+    rhounorm = (rhou ** 2 + rhov ** 2 + rhow ** 2) / rho
+    return (GAMMA - 1) * (E - .5 * rhounorm)
+
+
+def betafun_3D(rho, rhou, rhov, rhow, E):
+    """euler_variables.jl:30-39."""
+    return rho / (2 * pfun_3D(rho, rhou, rhov, rhow, E))
+
+
+def primitive_to_conservative_3D(rho, u, v, w, p):
+    """euler_variables.jl:15-27."""
+    unorm = u ** 2 + v ** 2 + w ** 2
+    return rho, rho * u, rho * v, rho * w, p / (GAMMA - 1) + .5 * rho * unorm
+
+
+def rhoefun_3D(rho, rhou, rhov, rhow, E):
+    """euler_variables.jl:59-62."""
+    return E - .5 * (rhou ** 2 + rhov ** 2 + rhow ** 2) / rho
+
+
+def sfun_3D(rho, rhou, rhov, rhow, E):
+    """euler_variables.jl:65-68."""
+    return np.log((GAMMA - 1) * rhoefun_3D(rho, rhou, rhov, rhow, E) / rho ** GAMMA)
+
+
+def Sfun_3D(rho, rhou, rhov, rhow, E):
+    """euler_variables.jl:74-76."""
+    return -rho * sfun_3D(rho, rhou, rhov, rhow, E)
+
+
+def v_ufun_3D(rho, rhou, rhov, rhow, E):
+    """euler_variables.jl:79-92."""
+    rhoe = rhoefun_3D(rho, rhou, rhov, rhow, E)
+    sU = sfun_3D(rho, rhou, rhov, rhow, E)
+    v1 = (-E + rhoe * (GAMMA + 1 - sU)) / rhoe
+    return v1, rhou / rhoe, rhov / rhoe, rhow / rhoe, (-rho) / rhoe
+
+
+def u_vfun_3D(v1, v2, v3, v4, v5):
+    """euler_variables.jl:95-120."""
+    vUnorm = v2 ** 2 + v3 ** 2 + v4 ** 2
+    s = GAMMA - v1 + vUnorm / (2 * v5)
+    rhoeV = ((GAMMA - 1) / ((-v5) ** GAMMA)) ** (1 / (GAMMA - 1)) * np.exp(-s / (GAMMA - 1))
+    return rhoeV * (-v5), rhoeV * v2, rhoeV * v3, rhoeV * v4, rhoeV * (1 - vUnorm / (2 * v5))

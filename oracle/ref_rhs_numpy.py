@@ -359,3 +359,62 @@ def rhsRK(Q, rd, md, ops, bc, Re, lam, mu, Pr, inviscid_dissp=True, viscous_diss
         rhstest_visc += np.sum(md.wJq * VUq[f] * (Vq @ visc[f]))
     rhstest_visc += visc_test
     return rhsQ, rhstest, rhstest_visc
+
+
+# ------------------------------------------------------------------------------------
+# Euler, collocated hex   (examples/dg3D_euler_hex.jl)
+# ------------------------------------------------------------------------------------
+def sparse_hadamard_sum_hex(Qh, Qr, Qs, Qt, Qnzids, vgeo):
+    """dg3D_euler_hex.jl:122-164, vectorised over elements.  vgeo: nine (Nh x K) arrays; the metric of a
+    pair is the average of the two nodes' values (:145-146)."""
+    rho, u, v, w, beta = Qh
+    lrho, lbeta = np.log(rho), np.log(beta)
+    nrows = Qr.shape[0]
+    out = [np.zeros_like(rho) for _ in range(5)]
+    for i in range(nrows):
+        acc = [np.zeros(rho.shape[1]) for _ in range(5)]
+        for j1 in Qnzids[i]:
+            j = j1 - 1
+            rxJa, sxJa, txJa, ryJa, syJa, tyJa, rzJa, szJa, tzJa = [.5 * (g[i] + g[j]) for g in vgeo]
+            Fx, Fy, Fz = ph.euler_fluxes_3D(rho[i], u[i], v[i], w[i], beta[i], rho[j], u[j], v[j], w[j], beta[j],
+                                            lrho[i], lbeta[i], lrho[j], lbeta[j])
+            for f in range(5):
+                Fr = rxJa * Fx[f] + ryJa * Fy[f] + rzJa * Fz[f]
+                Fs = sxJa * Fx[f] + syJa * Fy[f] + szJa * Fz[f]
+                Ft = txJa * Fx[f] + tyJa * Fy[f] + tzJa * Fz[f]
+                acc[f] = acc[f] + (Qr[i, j] * Fr + Qs[i, j] * Fs + Qt[i, j] * Ft)
+        for f in range(5):
+            out[f][i] = acc[f]
+    return out
+
+
+def hex_rhs(Q, md, ops, compute_rhstest=False, lf_scale=0.0):
+    """dg3D_euler_hex.jl:167-222.  lf_scale replaces the literal `0*.25` of :193 (SURVEY.md quirk Q2);
+    md must have been through ref_setup.hex_driver_setup (metrics at the hybrid nodes, J at quadrature nodes)."""
+    Ph, Lf, Ef = ops["Ph"], ops["Lf"], ops["Ef"]
+    Nq, Nh = Ph.shape
+    mapP = md.mapP
+    VU = ph.v_ufun_3D(*Q)
+    Uf = ph.u_vfun_3D(*[Ef @ v for v in VU])
+    rho, rhou, rhov, rhow, E = [np.vstack([q, uf]) for q, uf in zip(Q, Uf)]
+    beta = ph.betafun_3D(rho, rhou, rhov, rhow, E)
+    Qh = (rho, rhou / rho, rhov / rho, rhow / rho, beta)
+    QM = [x[Nq:, :] for x in Qh]
+    QP = [gather(x, mapP) for x in QM]
+    rhoM, rhouM, rhovM, rhowM, EM = Uf
+    rhoU_n = (rhouM * md.nxJ + rhovM * md.nyJ + rhowM * md.nzJ) / md.sJ
+    lam = np.abs(ph.wavespeed(rhoM, rhoU_n, EM))
+    LFc = lf_scale * np.maximum(lam, gather(lam, mapP)) * md.sJ
+    fSx, fSy, fSz = ph.euler_fluxes_UL_UR_3D(QM, QP)
+    flux = [fx * md.nxJ + fy * md.nyJ + fz * md.nzJ - LFc * (gather(uf, mapP) - uf)
+            for fx, fy, fz, uf in zip(fSx, fSy, fSz, Uf)]
+    rhsQ = [Lf @ f for f in flux]
+    vgeo = (md.rxJ, md.sxJ, md.txJ, md.ryJ, md.syJ, md.tyJ, md.rzJ, md.szJ, md.tzJ)
+    QF = sparse_hadamard_sum_hex(Qh, ops["Qrh_sparse"], ops["Qsh_sparse"], ops["Qth_sparse"], ops["Qnzids"], vgeo)
+    rhsQ = [r + Ph @ qf for r, qf in zip(rhsQ, QF)]               # Ph already holds the factor 2 (:96)
+    rhsQ = [-r / md.J for r in rhsQ]
+    rhstest = 0.0
+    if compute_rhstest:
+        for f in range(5):
+            rhstest += np.sum(md.wJq * VU[f] * rhsQ[f])
+    return rhsQ, rhstest

@@ -492,3 +492,282 @@ def cns_ops(rd):
     Ph = np.linalg.solve(rd.M, Vh.T)
     VhP = Vh @ rd.Pq
     return dict(Qrhskew=Qrhskew, Qshskew=Qshskew, VhP=VhP, Ph=Ph, LIFT=rd.LIFT, Vq=rd.Vq, Vh=Vh, Ef=Ef)
+
+
+# ==================================================================================
+# 3D hexahedra (examples/dg3D_euler_hex.jl and the src/ routines it calls)
+#
+# The reference flags this driver "TODO: FIX. Currently broken" (dg3D_euler_hex.jl:1).  What is
+# broken is src/UniformHexMesh.jl:83-93: `map(x->x[1], findall(...))` on 3-D arrays takes the first
+# component of each CartesianIndex{3} instead of the linear vertex id, so `fv` holds ids in {1,2}
+# and connect_mesh finds nonsense.  hex_face_vertices() below returns the INTENDED sets (the linear
+# ids of the vertices with r=-1, r=+1, s=-1, s=+1, t=-1, t=+1 in meshgrid order), as SURVEY.md
+# section 8 (cfg5) prescribes; everything else is restated as written.  Consequence kept on
+# purpose: with the reference's vertex order (meshgrid: s fastest) against EToV's (x fastest) the
+# element map is a reflection, J < 0 on every element.  -(.)/J still gives the right sign for the
+# volume and central surface terms; only an LF penalty would become anti-dissipative, and the
+# reference multiplies it by 0 (dg3D_euler_hex.jl:193).
+# ==================================================================================
+def meshgrid3(vx, vy, vz):
+    """VectorizedRoutines.Matlab.meshgrid, 3-argument form: X[i,j,k]=vx[j], Y[i,j,k]=vy[i], Z[i,j,k]=vz[k]."""
+    vx, vy, vz = (np.asarray(a, dtype=float) for a in (vx, vy, vz))
+    X = np.empty((vy.size, vx.size, vz.size))
+    Y = np.empty_like(X)
+    Z = np.empty_like(X)
+    X[:] = vx[None, :, None]
+    Y[:] = vy[:, None, None]
+    Z[:] = vz[None, None, :]
+    return X, Y, Z
+
+
+def vandermonde_3D(N, r, s, t):
+    """src/Basis3DHex.jl:24-39."""
+    r, s, t = (np.asarray(a, dtype=float).reshape(-1) for a in (r, s, t))
+    V = np.zeros((r.size, (N + 1) ** 3))
+    sk = 0
+    for i in range(N + 1):
+        for j in range(N + 1):
+            for k in range(N + 1):
+                V[:, sk] = jacobiP(r, 0, 0, i) * jacobiP(s, 0, 0, j) * jacobiP(t, 0, 0, k)
+                sk += 1
+    return V
+
+
+def grad_vandermonde_3D(N, r, s, t):
+    """src/Basis3DHex.jl:47-67."""
+    r, s, t = (np.asarray(a, dtype=float).reshape(-1) for a in (r, s, t))
+    Np = (N + 1) ** 3
+    Vr, Vs, Vt = np.zeros((r.size, Np)), np.zeros((r.size, Np)), np.zeros((r.size, Np))
+    sk = 0
+    for i in range(N + 1):
+        for j in range(N + 1):
+            for k in range(N + 1):
+                Vr[:, sk] = grad_jacobiP(r, 0, 0, i) * jacobiP(s, 0, 0, j) * jacobiP(t, 0, 0, k)
+                Vs[:, sk] = jacobiP(r, 0, 0, i) * grad_jacobiP(s, 0, 0, j) * jacobiP(t, 0, 0, k)
+                Vt[:, sk] = jacobiP(r, 0, 0, i) * jacobiP(s, 0, 0, j) * grad_jacobiP(t, 0, 0, k)
+                sk += 1
+    return Vr, Vs, Vt
+
+
+def nodes_3D(N):
+    """src/Basis3DHex.jl:79-82."""
+    r1D, _ = gauss_lobatto_quad(0, 0, N)
+    return tuple(vec(a) for a in meshgrid3(r1D, r1D, r1D))
+
+
+def uniform_hex_mesh(Nx, Ny, Nz):
+    """src/UniformHexMesh.jl:25-76.  Returns VX, VY, VZ and 1-based EToV (K x 8); vertices x fastest."""
+    Nxp, Nyp, Nzp = Nx + 1, Ny + 1, Nz + 1
+    K = Nx * Ny * Nz
+    x1D, y1D, z1D = np.linspace(-1, 1, Nxp), np.linspace(-1, 1, Nyp), np.linspace(-1, 1, Nzp)
+    x = np.zeros(Nxp * Nyp * Nzp)
+    y = np.zeros_like(x)
+    z = np.zeros_like(x)
+    sk = 0
+    for k in range(Nzp):
+        for j in range(Nyp):
+            for i in range(Nxp):
+                x[sk], y[sk], z[sk] = x1D[i], y1D[j], z1D[k]
+                sk += 1
+    EToV = np.zeros((K, 8), dtype=np.int64)
+    for e in range(1, K + 1):
+        em = e - 1
+        k = em // (Nx * Ny)
+        j = (em - k * Nx * Ny) // Nx
+        i = em % Nx
+        for c, (di, dj, dk) in enumerate([(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (0, 0, 1), (1, 0, 1), (0, 1, 1), (1, 1, 1)]):
+            EToV[e - 1, c] = (i + di) + Nxp * (j + dj) + Nxp * Nyp * (k + dk)
+    return x, y, z, EToV + 1
+
+
+def hex_face_vertices():
+    """INTENDED result of src/UniformHexMesh.jl:83-93 (see the section header): 1-based linear ids, in the
+    2x2x2 meshgrid ordering (s fastest, then r, then t), of the vertices on r=-1, r=+1, s=-1, s=+1, t=-1, t=+1."""
+    x1D = np.array([-1.0, 1.0])
+    r, s, t = (vec(a) for a in meshgrid3(x1D, x1D, x1D))
+    return tuple([int(i) + 1 for i in np.nonzero(np.abs(c - v) < 1e-10)[0]]
+                 for c, v in ((r, -1), (r, 1), (s, -1), (s, 1), (t, -1), (t, 1)))
+
+
+def geometric_factors_3D(x, y, z, Dr, Ds, Dt):
+    """src/geometric_factors.jl:34-67 (curl-conservative form, identity filters)."""
+    xr, xs, xt = Dr @ x, Ds @ x, Dt @ x
+    yr, ys, yt = Dr @ y, Ds @ y, Dt @ y
+    zr, zs, zt = Dr @ z, Ds @ z, Dt @ z
+    Fr, Fs, Ft = (Dr @ y) * z, (Ds @ y) * z, (Dt @ y) * z
+    rxJ = Dt @ Fs - Ds @ Ft
+    sxJ = Dr @ Ft - Dt @ Fr
+    txJ = Ds @ Fr - Dr @ Fs
+    Fr, Fs, Ft = (Dr @ x) * z, (Ds @ x) * z, (Dt @ x) * z
+    ryJ = -(Dt @ Fs - Ds @ Ft)
+    syJ = -(Dr @ Ft - Dt @ Fr)
+    tyJ = -(Ds @ Fr - Dr @ Fs)
+    Fr, Fs, Ft = (Dr @ y) * x, (Ds @ y) * x, (Dt @ y) * x
+    rzJ = -(Dt @ Fs - Ds @ Ft)
+    szJ = -(Dr @ Ft - Dt @ Fr)
+    tzJ = -(Ds @ Fr - Dr @ Fs)
+    J = xr * (ys * zt - zs * yt) - yr * (xs * zt - zs * xt) + zr * (xs * yt - ys * xt)
+    return rxJ, sxJ, txJ, ryJ, syJ, tyJ, rzJ, szJ, tzJ, J
+
+
+def build_periodic_boundary_maps_3D(xf, yf, zf, LX, LY, LZ, NfacesTotal, mapM, mapP, mapB):
+    """src/node_map_functions.jl:139-213."""
+    xfl, yfl, zfl = vec(xf), vec(yf), vec(zf)
+    mapMl, mapPl = vec(mapM), vec(mapP)
+    Nfp = xfl.size // NfacesTotal
+    Nbfaces = mapB.size // Nfp
+    xb, yb, zb = (a[mapB - 1].reshape((Nfp, Nbfaces), order="F") for a in (xfl, yfl, zfl))
+    xc, yc, zc = xb.sum(axis=0) / Nfp, yb.sum(axis=0) / Nfp, zb.sum(axis=0) / Nfp
+    mapMB = mapMl[mapB - 1].reshape((Nfp, Nbfaces), order="F")
+    mapPB = mapPl[mapB - 1].reshape((Nfp, Nbfaces), order="F").copy(order="F")
+    NODETOL = 1e-12
+    on = lambda c, L: np.nonzero((np.abs(c - c.max()) < NODETOL * L) | (np.abs(c - c.min()) < NODETOL * L))[0]
+    xfaces, yfaces, zfaces = on(xc, LX), on(yc, LY), on(zc, LZ)
+
+    def match(faces, cn, Ln, ca, La, cb, Lb, na, nb, tol_len):
+        # faces matched across direction n; tangential coordinates a, b
+        for i in faces:
+            for j in faces:
+                if i != j:
+                    if abs(ca[i] - ca[j]) < NODETOL * La and abs(cb[i] - cb[j]) < NODETOL * Lb and \
+                            abs(abs(cn[i] - cn[j]) - Ln) < NODETOL * Ln:
+                        Aa, Ab = meshgrid(na[:, i], na[:, j])
+                        Ba, Bb = meshgrid(nb[:, i], nb[:, j])
+                        D = np.abs(Aa - Ab) + np.abs(Ba - Bb)
+                        cols, rows = np.nonzero((D < NODETOL * tol_len).T)   # column-major findall, x[1] = row
+                        mapPB[:, i] = mapMB[rows, j]
+
+    match(xfaces, xc, LX, yc, LY, zc, LZ, yb, zb, LY)   # :165-177
+    match(yfaces, yc, LY, xc, LX, zc, LZ, xb, zb, LX)   # :180-192
+    match(zfaces, zc, LZ, xc, LX, yc, LY, xb, yb, LX)   # :195-207
+    return vec(mapPB)
+
+
+def init_reference_hex(N, quad_nodes_1D=None):
+    """src/SetupDG.jl:323-387."""
+    if quad_nodes_1D is None:
+        quad_nodes_1D = gauss_quad(0, 0, N)
+    rd = RefElemData()
+    rd.N = N
+    rd.fv = hex_face_vertices()
+    rd.Nfaces = len(rd.fv)
+    r, s, t = nodes_3D(N)
+    VDM = vandermonde_3D(N, r, s, t)
+    Vr, Vs, Vt = grad_vandermonde_3D(N, r, s, t)
+    Dr, Ds, Dt = rdiv(Vr, VDM), rdiv(Vs, VDM), rdiv(Vt, VDM)
+    rd.r, rd.s, rd.t, rd.VDM = r, s, t, VDM
+    r1, s1, t1 = nodes_3D(1)
+    rd.V1 = rdiv(vandermonde_3D(1, r, s, t), vandermonde_3D(1, r1, s1, t1))
+
+    r1D, w1D = (np.asarray(a, dtype=float) for a in quad_nodes_1D)
+    rquad, squad = (vec(a) for a in meshgrid(r1D, r1D))
+    wr, ws = (vec(a) for a in meshgrid(w1D, w1D))
+    wquad = wr * ws
+    e = np.ones(rquad.size)
+    zz = np.zeros(rquad.size)
+    rd.rf = np.concatenate([-e, e, rquad, rquad, rquad, rquad])
+    rd.sf = np.concatenate([rquad, rquad, -e, e, squad, squad])
+    rd.tf = np.concatenate([squad, squad, squad, squad, -e, e])
+    rd.wf = np.tile(wquad, rd.Nfaces)
+    rd.nrJ = np.concatenate([-e, e, zz, zz, zz, zz])
+    rd.nsJ = np.concatenate([zz, zz, -e, e, zz, zz])
+    rd.ntJ = np.concatenate([zz, zz, zz, zz, -e, e])
+
+    rq, sq, tq = (vec(a) for a in meshgrid3(r1D, r1D, r1D))
+    wr, ws, wt = (vec(a) for a in meshgrid3(w1D, w1D, w1D))
+    wq = wr * ws * wt
+    Vq = rdiv(vandermonde_3D(N, rq, sq, tq), VDM)
+    M = Vq.T @ np.diag(wq) @ Vq
+    Pq = np.linalg.solve(M, Vq.T @ np.diag(wq))
+    rd.rq, rd.sq, rd.tq, rd.wq, rd.Vq, rd.M, rd.Pq = rq, sq, tq, wq, Vq, M, Pq
+
+    Vf = rdiv(vandermonde_3D(N, rd.rf, rd.sf, rd.tf), VDM)
+    LIFT = np.linalg.solve(M, Vf.T @ np.diag(rd.wf))
+    rd.Dr, rd.Ds, rd.Dt = droptol(Dr, 1e-12), droptol(Ds, 1e-12), droptol(Dt, 1e-12)
+    rd.Vf = droptol(Vf, 1e-12)
+    rd.LIFT = droptol(LIFT, 1e-12)
+    return rd
+
+
+def init_mesh_3D(VX, VY, VZ, EToV, rd):
+    """src/SetupDG.jl:389-434."""
+    md = MeshData()
+    FToF = connect_mesh(EToV, rd.fv)
+    Nfaces, K = FToF.shape
+    md.FToF, md.K, md.VX, md.VY, md.VZ, md.EToV = FToF, K, VX, VY, VZ, EToV
+    x, y, z = (np.asfortranarray(rd.V1 @ V[EToV.T - 1]) for V in (VX, VY, VZ))
+    md.x, md.y, md.z = x, y, z
+    xf, yf, zf = (np.asfortranarray(rd.Vf @ a) for a in (x, y, z))
+    mapM, mapP, mapB = build_node_maps((xf, yf, zf), FToF)
+    Nfp = rd.Vf.shape[0] // Nfaces
+    md.mapM = mapM.reshape((Nfp * Nfaces, K), order="F")
+    md.mapP = mapP.reshape((Nfp * Nfaces, K), order="F")
+    md.mapB = mapB
+    md.xf, md.yf, md.zf = xf, yf, zf
+    geo = geometric_factors_3D(x, y, z, rd.Dr, rd.Ds, rd.Dt)
+    (md.rxJ, md.sxJ, md.txJ, md.ryJ, md.syJ, md.tyJ, md.rzJ, md.szJ, md.tzJ, md.J) = (np.asfortranarray(a) for a in geo)
+    md.xq, md.yq, md.zq = (np.asfortranarray(rd.Vq @ a) for a in (x, y, z))
+    md.wJq = np.asfortranarray(np.diag(rd.wq) @ (rd.Vq @ md.J))
+    _hex_normals(md, rd, geo)
+    return md
+
+
+def _hex_normals(md, rd, geo):
+    """src/SetupDG.jl:424-431 == dg3D_euler_hex.jl:81-86."""
+    rxJ, sxJ, txJ, ryJ, syJ, tyJ, rzJ, szJ, tzJ = geo[:9]
+    nr, ns, nt = rd.nrJ[:, None], rd.nsJ[:, None], rd.ntJ[:, None]
+    Vf = rd.Vf
+    md.nxJ = np.asfortranarray(nr * (Vf @ rxJ) + ns * (Vf @ sxJ) + nt * (Vf @ txJ))
+    md.nyJ = np.asfortranarray(nr * (Vf @ ryJ) + ns * (Vf @ syJ) + nt * (Vf @ tyJ))
+    md.nzJ = np.asfortranarray(nr * (Vf @ rzJ) + ns * (Vf @ szJ) + nt * (Vf @ tzJ))
+    md.sJ = np.asfortranarray(np.sqrt(md.nxJ ** 2 + md.nyJ ** 2 + md.nzJ ** 2))
+
+
+def make_periodic_3D(md, rd, LX=2.0, LY=2.0, LZ=2.0):
+    """examples/dg3D_euler_hex.jl:59-65 (LX=LY=LZ=2 literals for the [-1,1]^3 box)."""
+    mapPB = build_periodic_boundary_maps_3D(md.xf, md.yf, md.zf, LX, LY, LZ, rd.Nfaces * md.K, md.mapM, md.mapP, md.mapB)
+    mapPl = vec(md.mapP)
+    mapPl[md.mapB - 1] = mapPB
+    md.mapP = mapPl.reshape(md.mapP.shape, order="F")
+    return md
+
+
+def hex_driver_setup(md, rd, a=0.0):
+    """examples/dg3D_euler_hex.jl:34-98: hybridized SBP operators in the quadrature basis, the (optionally curved)
+    geometry re-computation, metrics interpolated to the hybrid nodes, J and wJq at the quadrature nodes.
+    Mutates md like the script does and returns the `ops` dictionary."""
+    M, Dr, Ds, Dt, Pq, Vq, Vf, wf = rd.M, rd.Dr, rd.Ds, rd.Dt, rd.Pq, rd.Vq, rd.Vf, rd.wf
+    Qr, Qs, Qt = Pq.T @ M @ Dr @ Pq, Pq.T @ M @ Ds @ Pq, Pq.T @ M @ Dt @ Pq
+    Ef = Vf @ Pq
+    sk = []
+    for Q, n in ((Qr, rd.nrJ), (Qs, rd.nsJ), (Qt, rd.ntJ)):
+        B = np.diag(wf * n)
+        Qh = .5 * np.block([[Q - Q.T, Ef.T @ B], [-B @ Ef, B]])
+        sk.append(.5 * (Qh - Qh.T))
+    Qrhskew, Qshskew, Qthskew = sk
+    Qrs, Qss, Qts = (droptol(A, 1e-12) for A in sk)
+    Qnzids = []
+    for i in range(Qrhskew.shape[0]):
+        ids = []
+        for A in (Qrs, Qss, Qts):
+            for c in np.nonzero(A[i, :])[0] + 1:
+                if c not in ids:
+                    ids.append(int(c))
+        Qnzids.append(ids)
+    # curved mapping (:67-73) and geometry re-computation (:75-90)
+    x, y, z = md.x, md.y, md.z
+    dx = (x - 1) * (x + 1) * (y - 1) * (y + 1) * (z - 1) * (z + 1)
+    x, y, z = x + a * dx, y + a * dx, z + a * dx
+    md.xq, md.yq, md.zq = (np.asfortranarray(Vq @ c) for c in (x, y, z))
+    vgeo = geometric_factors_3D(x, y, z, Dr, Ds, Dt)
+    _hex_normals(md, rd, vgeo)
+    Vhg = np.vstack([Vq, Vf])
+    (md.rxJ, md.sxJ, md.txJ, md.ryJ, md.syJ, md.tyJ, md.rzJ, md.szJ, md.tzJ) = (np.asfortranarray(Vhg @ g) for g in vgeo[:9])
+    wq = rd.wq
+    Vh = droptol(np.vstack([np.eye(wq.size), Ef]), 1e-12)
+    Ph = droptol(2 * np.diag(1.0 / wq) @ Vh.T, 1e-12)              # note the factor 2 (:96, quirk Q9)
+    Lf = droptol(np.diag(1.0 / wq) @ (Ef.T @ np.diag(wf)), 1e-12)
+    md.J = np.asfortranarray(Vq @ vgeo[9])
+    md.wJq = np.asfortranarray(np.diag(wq) @ md.J)
+    return dict(Qrhskew=Qrhskew, Qshskew=Qshskew, Qthskew=Qthskew, Qrh_sparse=Qrs, Qsh_sparse=Qss, Qth_sparse=Qts,
+                Qnzids=Qnzids, Ph=Ph, Lf=Lf, Ef=Ef, Vh=Vh)

@@ -95,3 +95,54 @@ def steep_state(x, y, LX=15.0, LY=10.0):
     u = 0.3 + 0.25 * xs - 0.1 * ys
     v = -0.2 + 0.15 * xs + 0.3 * ys
     return [np.asfortranarray(q) for q in ph.primitive_to_conservative(rho, u, v, p)]
+
+
+# ---- hexahedra (examples/dg3D_euler_hex.jl) ---------------------------------------------------------------
+def hex_smooth_state(x, y, z):
+    """Same formula as oracle.hex_smooth_state (the reference script's own IC is random, dg3D_euler_hex.jl:101-108)."""
+    rho = 2 + .5 * np.sin(np.pi * x) * np.cos(np.pi * y)
+    u = .3 * np.sin(np.pi * z + .2)      # phases keep u_n away from exact zeros at nodes: the LF wavespeed's
+    v = 1 + .1 * np.cos(np.pi * x)       # sqrt(|u_n|) (quirk Q1) turns 1e-17 noise there into 3e-9
+    w = .1 * np.sin(np.pi * (x + y) + .3)
+    p = 1 + .2 * np.cos(np.pi * z) * np.sin(np.pi * y)
+    return [np.asfortranarray(q) for q in ph.primitive_to_conservative_3d(rho, u, v, w, p)]
+
+
+def hex_steep_state(x, y, z):
+    """3D analogue of steep_state: monotone exponential profiles on [-1,1]^3 (discontinuous across the periodic
+    wrap), every coupled node pair far from logmean's ill-conditioned |f| ~ 1e-4 window."""
+    rho = np.exp(0.3 * x + 0.21 * y - 0.15 * z)
+    p = np.exp(-0.165 * x + 0.135 * y + 0.18 * z)
+    u = 0.3 + 0.12 * x - 0.05 * y + 0.08 * z
+    v = -0.2 + 0.07 * x + 0.15 * y - 0.1 * z
+    w = 0.1 - 0.09 * x + 0.06 * y + 0.11 * z
+    return [np.asfortranarray(q) for q in ph.primitive_to_conservative_3d(rho, u, v, w, p)]
+
+
+def hex_random_state(shape, seed=20250117, vel=(0.0, 1.0, 0.0)):
+    """The script's own kind of initial condition (:101-108): rho = 2 + .1 rand, (u,v,w) = (0,1,0), p = 1 + .1 rand.
+    With the LF term switched on (the script has it multiplied by 0) pass a velocity without exact zeros: the
+    wavespeed's sqrt(|u_n|) (quirk Q1) turns the 1e-17 round-off of a tangential normal component into 3e-9."""
+    rng = np.random.default_rng(seed)
+    rho = 2 + .1 * rng.random(shape)
+    p = 1 + .1 * rng.random(shape)
+    z = np.zeros(shape)
+    return [np.asfortranarray(q) for q in ph.primitive_to_conservative_3d(rho, z + vel[0], z + vel[1], z + vel[2], p)]
+
+
+def product_hex_problem(N, Kx, Ky=None, Kz=None, elem_range=None, hybrid=True):
+    VX, VY, VZ, EToV = sd.uniform_hex_mesh(Kx, Ky, Kz)
+    rd = sd.init_reference_hex(N, sd.gauss_quad(0, 0, N))
+    md = sd.init_mesh_3d((VX, VY, VZ), EToV, rd, elem_range=elem_range)
+    sd.make_periodic_3d(md, rd)
+    ops = sd.hex_ops(rd)
+    sd.hex_driver_geometry(md, rd, hybrid=hybrid)
+    return rd, md, ops, hex_smooth_state(md.xq, md.yq, md.zq)
+
+
+def perturb_hex(Q, seed=20250117, amp=0.01):
+    rng = np.random.default_rng(seed)
+    out = [q.copy() for q in Q]
+    out[0] *= 1 + amp * (2 * rng.random(Q[0].shape) - 1)
+    out[4] *= 1 + amp * (2 * rng.random(Q[0].shape) - 1)
+    return out

@@ -1,0 +1,124 @@
+"""GPU parity of the hexahedral path (esdg_create_hex; `rhs` of examples/dg3D_euler_hex.jl:167-222) against the
+CPU oracle (oracle_hex_rhs), through the C ABI.  Tolerance policy as in test_gpu_parity.py: relative L2 per field
+<= max(1e-12, 4 x the oracle's own one-ulp noise floor), and the strict 1e-12 on the well-conditioned state."""
+import numpy as np
+import pytest
+
+from common import (hex_random_state, hex_steep_state, noise_floor, perturb_hex, product_hex_problem, rel_l2)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def eng_mod():
+    from esdg_cns_amd import engine
+    return engine
+
+
+def _gpu_rhs(eng, Q):
+    return eng.download(eng.rhs(eng.upload(Q)))
+
+
+@pytest.mark.parametrize("N,K3", [(3, (4, 4, 4)), (3, (5, 3, 2)), (2, (3, 4, 5)), (1, (4, 3, 3))])
+@pytest.mark.parametrize("lf", [0.0, 0.25])
+def test_hex_matches_oracle(eng_mod, oracle_lib, N, K3, lf):
+    from oracle import oracle as orc
+    p = orc.build_hex_problem(N, *K3)
+    ho = orc.HexOracle(p, lf)
+    rd, md, ops, Q = product_hex_problem(N, *K3)
+    eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.EULER_HEX_COLLOCATED, lf_scale=lf)
+    assert np.array_equal(md.mapP, p.md.mapP)
+    for name, state in (("smooth", Q), ("steep", hex_steep_state(md.xq, md.yq, md.zq)), ("random", hex_random_state(Q[0].shape, vel=(0, 1, 0) if lf == 0 else (.13, 1, -.07)))):
+        ref = ho.rhs(state)[0]
+        err = rel_l2(_gpu_rhs(eng, state), ref)
+        floor = noise_floor(lambda q: ho.rhs(q)[0], state)
+        print(f"hex N={N} {K3} lf={lf} {name}: err={err:.2e} oracle-noise-floor={floor:.2e}")
+        assert err <= max(TOL, 4 * floor), (name, err, floor)
+        if name == "steep" and N >= 2:
+            assert err <= TOL, err
+
+
+def test_hex_rhstest_entropy_conservation(eng_mod, oracle_lib):
+    """The script's own check (`@show rhstest`, :224-226, "for testing EC"): with the LF term off the discrete
+    entropy production sum(wJq v.rhs) vanishes to round-off; it matches the oracle's value with LF on."""
+    from oracle import oracle as orc
+    rd, md, ops, Q = product_hex_problem(3, 4, 4, 4)
+    Qr = hex_random_state(Q[0].shape, vel=(.13, 1, -.07))
+    eng0 = eng_mod.RhsEngine(rd, md, ops, eng_mod.EULER_HEX_COLLOCATED, lf_scale=0.0)
+    Qd = eng0.upload(Qr)
+    r = eng0.rhs(Qd)
+    rt = eng0.rhstest(Qd, r)
+    scale = float(np.sum(np.abs(md.wJq)) * max(np.abs(x).max() for x in eng0.download(r)))
+    print("hex rhstest (LF off)", rt, "scale", scale)
+    assert abs(rt) < 1e-12 * scale
+    p = orc.build_hex_problem(3, 4, 4, 4)
+    ho = orc.HexOracle(p, 0.25)
+    eng1 = eng_mod.RhsEngine(rd, md, ops, eng_mod.EULER_HEX_COLLOCATED, lf_scale=0.25)
+    Qd = eng1.upload(Qr)
+    r = eng1.rhs(Qd)
+    rt1 = eng1.rhstest(Qd, r)
+    _, rto = ho.rhs(Qr, True)
+    print("hex rhstest (LF .25)", rt1, rto)
+    assert abs(rt1 - rto) < 1e-10 * max(1.0, abs(rto))
+
+
+def test_hex_invariants_shards_and_fused_rk(eng_mod):
+    """Free-stream preservation, conservation, two shards on one GPU == one engine bit for bit, bitwise
+    reproducibility, host drop-in entry point, fused LSRK stage == unfused."""
+    import torch
+    from esdg_cns_amd import setup_dg as sd
+    N, K3 = 3, (6, 4, 4)
+    rd, md, ops, Q = product_hex_problem(N, *K3)
+    eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.EULER_HEX_COLLOCATED, lf_scale=0.25)
+    # free stream
+    c = [np.full_like(Q[0], v) for v in (1.3, 0.4, -0.3, 0.2, 2.9)]
+    r = _gpu_rhs(eng, c)
+    assert max(np.abs(x).max() for x in r) < 1e-11
+    # conservation on a perturbed state
+    Qp = perturb_hex(Q)
+    Qd = eng.upload(Qp)
+    rd_ = eng.rhs(Qd)
+    r = eng.download(rd_)
+    for f in range(5):
+        assert abs(np.sum(md.wJq * r[f])) < 1e-11 * np.sum(np.abs(md.wJq * r[f]))
+    # reproducibility
+    assert torch.equal(rd_, eng.rhs(Qd))
+    # host entry point
+    rh = eng.rhs_host(Qp)
+    assert all(np.array_equal(a, b) for a, b in zip(rh, r))
+    # two z-slab shards on one GPU, traces exchanged by device copies
+    Kg = md.K
+    cut = (K3[0] * K3[1]) * 2
+    offs = [0, cut, Kg]
+    engs, mds = [], []
+    for rk in range(2):
+        _, mdl, _, _ = product_hex_problem(N, *K3, elem_range=(offs[rk], offs[rk + 1]))
+        mds.append(mdl)
+        engs.append(eng_mod.RhsEngine(rd, mdl, ops, eng_mod.EULER_HEX_COLLOCATED, lf_scale=0.25, rank=rk, nranks=2,
+                                      rank_offsets=offs))
+    Qs = [engs[rk].upload([q[:, offs[rk]:offs[rk + 1]] for q in Qp]) for rk in range(2)]
+    outs = [torch.empty_like(q) for q in Qs]
+    import ctypes as C
+    for ph in range(2):
+        for rk in range(2):
+            e = engs[rk]
+            e.L.esdg_rhs_phase(e.ctx, ph, C.c_void_p(Qs[rk].data_ptr()), C.c_void_p(outs[rk].data_ptr()), e._stream())
+        if ph == 0:
+            torch.cuda.synchronize()
+            for rk in range(2):
+                for peer, so, sb, ro, rb in engs[rk].halo.segments[0]:
+                    src = engs[peer]
+                    seg = [s for s in src.halo.segments[0] if s[0] == rk][0]
+                    assert seg[2] == rb
+                    engs[rk].ws[ro:ro + rb].copy_(src.ws[seg[1]:seg[1] + seg[2]])
+            torch.cuda.synchronize()
+    full = torch.cat(outs, dim=1)
+    assert torch.equal(full, rd_)
+    # fused low-storage RK stage
+    a, b, dt = -0.4178904745, 0.3792103130, 1e-3
+    Q1, res1 = Qd.clone(), torch.full_like(Qd, 0.01)
+    Q2, res2 = Q1.clone(), res1.clone()
+    eng.rhs_lsrk_fused(Q1, res1, a, b, dt)
+    eng.lsrk_update(Q2, res2, eng.rhs(Q2), a, b, dt)
+    assert torch.equal(Q1, Q2) and torch.equal(res1, res2)
