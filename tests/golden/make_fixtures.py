@@ -33,3 +33,17 @@ p = orc.build_cns_problem(2, 3, 3, bc="periodic")
 out, rt, rtv = orc.CnsOracle(p).rhsRK(p.Q)
 np.savez(os.path.join(HERE, "rhs_cns_N2_3x3.npz"), Q=np.stack(p.Q), rhs=np.stack(out), rhstest=rt, rhstest_visc=rtv)
 print("fixtures written")
+
+# ---- hexahedra (examples/dg3D_euler_hex.jl) ---------------------------------------------------------------
+VX, VY, VZ, EToV = rs.uniform_hex_mesh(2, 2, 2)
+rd = rs.init_reference_hex(1)
+md = rs.init_mesh_3D(VX, VY, VZ, EToV, rd)
+mapP0 = md.mapP.copy()
+rs.make_periodic_3D(md, rd)
+np.savez(os.path.join(HERE, "maps_hex_2x2x2_N1.npz"), EToV=EToV, FToF=md.FToF, mapM=md.mapM, mapP_walls=mapP0,
+         mapP_periodic=md.mapP, mapB=md.mapB)
+p = orc.build_hex_problem(2, 2, 2, 2)
+for lf, tag in ((0.0, "lf0"), (0.25, "lf025")):
+    out, rt = orc.HexOracle(p, lf).rhs(p.Q, True)
+    np.savez(os.path.join(HERE, f"rhs_hex_N2_2x2x2_{tag}.npz"), Q=np.stack(p.Q), rhs=np.stack(out), rhstest=rt)
+print("hex fixtures written")
