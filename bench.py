@@ -10,6 +10,9 @@ periodic isentropic-vortex box, Re=1000, both dissipations on.  For N>1 GPUs the
 (512 x 512N elements, one horizontal strip of 512x512 per rank = weak scaling) and the three face-trace
 exchanges per RHS go over RCCL (torch.distributed "nccl").
 
+--formulation hex runs BASELINE.json configs[4] per GPU instead: 3D hexahedral Euler, N=3, 128x128x16 elements per
+GPU (z-slabs of the 128^3 box; `rhs` of examples/dg3D_euler_hex.jl, LF factor 0 as in the reference unless --lf).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -49,6 +52,48 @@ def build_problem(N, Kx, Ky_total, e0, e1, formulation):
     return rd, md, ops, Q
 
 
+def build_hex_problem(N, Kx, Ky, Kz_total, e0, e1):
+    from esdg_cns_amd import physics as ph
+    from esdg_cns_amd import setup_dg as sd
+    VX, VY, VZ, EToV = sd.uniform_hex_mesh(Kx, Ky, Kz_total)
+    rd = sd.init_reference_hex(N, sd.gauss_quad(0, 0, N))
+    md = sd.init_mesh_3d((VX, VY, VZ), EToV, rd, elem_range=(e0, e1))
+    sd.make_periodic_3d(md, rd)
+    ops = sd.hex_ops(rd)
+    sd.hex_driver_geometry(md, rd, hybrid=False)      # affine: one metric row per element (geo_ld = 1)
+    x, y, z = md.xq, md.yq, md.zq
+    rho = 2 + .5 * np.sin(np.pi * x) * np.cos(np.pi * y)
+    u, v, w = .3 * np.sin(np.pi * z + .2), 1 + .1 * np.cos(np.pi * x), .1 * np.sin(np.pi * (x + y) + .3)
+    p = 1 + .2 * np.cos(np.pi * z) * np.sin(np.pi * y)
+    Q = [np.asfortranarray(q) for q in ph.primitive_to_conservative_3d(rho, u, v, w, p)]
+    return rd, md, ops, Q
+
+
+def cpu_baseline_hex(N, lf, budget_s=15.0):
+    """oracle_hex_rhs (C restatement of dg3D_euler_hex.jl:122-222: 1344 flux evaluations per element at N=3), one
+    thread, on a 12^3 sample of the same periodic box."""
+    from oracle import oracle as orc
+    Ks = 12
+    p = orc.build_hex_problem(N, Ks)
+    orc.lib().oracle_set_threads(1)
+    o = orc.HexOracle(p, lf)
+    Qs = orc.stack(p.Q)
+    o.rhs_stacked(Qs)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        o.rhs_stacked(Qs)
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 50:
+            break
+    dt = (time.perf_counter() - t0) / n
+    K, Np = p.md.K, (N + 1) ** 3
+    return {"value": K * Np / dt, "unit": "DOF updates/s", "cores": 1, "kind": "port",
+            "sample": f"hex N={N} {Ks}^3 periodic box, {n} RHS evals of oracle/oracle_rhs.c:oracle_hex_rhs "
+                      f"(C restatement of the Julia reference, 1 thread), {dt * 1e3:.1f} ms/eval",
+            "rhs_evals_per_s_at_sample": 1.0 / dt}
+
+
 def cpu_baseline(N, formulation, budget_s=15.0):
     """Reference algorithm restated in C (oracle/oracle_rhs.c, the reference's loop structure: 825
     visited pairs/element in flux_differencing!), timed single-threaded like the Julia reference, on a
@@ -86,10 +131,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--N", type=int, default=4)
-    ap.add_argument("--kx", type=int, default=512, help="elements in x")
-    ap.add_argument("--ky-per-gpu", type=int, default=512, help="element rows per GPU (weak scaling)")
-    ap.add_argument("--formulation", choices=["cns", "euler"], default="cns")
+    ap.add_argument("--N", type=int, default=None, help="degree (default 4; 3 for hex)")
+    ap.add_argument("--kx", type=int, default=None, help="elements in x (default 512; 128 for hex, also used for y)")
+    ap.add_argument("--ky-per-gpu", type=int, default=512, help="element rows per GPU (weak scaling, 2D)")
+    ap.add_argument("--kz-per-gpu", type=int, default=16, help="element layers per GPU (weak scaling, hex)")
+    ap.add_argument("--lf", type=float, default=0.0, help="hex: LF factor (the reference has 0*.25)")
+    ap.add_argument("--formulation", choices=["cns", "euler", "hex"], default="cns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -109,18 +156,31 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    N, Kx = args.N, args.kx
-    Ky_total = args.ky_per_gpu * world
-    rows = [args.ky_per_gpu * r for r in range(world + 1)]
-    rank_offsets = np.array([Kx * r for r in rows], dtype=np.int64)   # elements are numbered x-fastest
-    e0, e1 = int(rank_offsets[rank]), int(rank_offsets[rank + 1])
-    rd, md, ops, Q = build_problem(N, Kx, Ky_total, e0, e1, args.formulation)
-    form = engine.CNS_MODAL if args.formulation == "cns" else engine.EULER_COLLOCATED
-    eng = engine.RhsEngine(rd, md, ops, form, rank=rank, nranks=world, rank_offsets=rank_offsets)
+    hexw = args.formulation == "hex"
+    N = args.N if args.N is not None else (3 if hexw else 4)
+    Kx = args.kx if args.kx is not None else (128 if hexw else 512)
+    if hexw:
+        Kz_total = args.kz_per_gpu * world
+        rank_offsets = np.array([Kx * Kx * args.kz_per_gpu * r for r in range(world + 1)], dtype=np.int64)   # z-slabs
+        e0, e1 = int(rank_offsets[rank]), int(rank_offsets[rank + 1])
+        rd, md, ops, Q = build_hex_problem(N, Kx, Kx, Kz_total, e0, e1)
+        eng = engine.RhsEngine(rd, md, ops, engine.EULER_HEX_COLLOCATED, lf_scale=args.lf, rank=rank, nranks=world,
+                               rank_offsets=rank_offsets)
+        K_total = Kx * Kx * Kz_total
+    else:
+        Ky_total = args.ky_per_gpu * world
+        rows = [args.ky_per_gpu * r for r in range(world + 1)]
+        rank_offsets = np.array([Kx * r for r in rows], dtype=np.int64)   # elements are numbered x-fastest
+        e0, e1 = int(rank_offsets[rank]), int(rank_offsets[rank + 1])
+        rd, md, ops, Q = build_problem(N, Kx, Ky_total, e0, e1, args.formulation)
+        form = engine.CNS_MODAL if args.formulation == "cns" else engine.EULER_COLLOCATED
+        eng = engine.RhsEngine(rd, md, ops, form, rank=rank, nranks=world, rank_offsets=rank_offsets)
+        K_total = Kx * Ky_total
     Qd = eng.upload(Q)
     out = eng.new_state()
     Np = eng.Np
-    K_local, K_total = eng.K, Kx * Ky_total
+    K_local = eng.K
+    nfld = eng.nfld
 
     def sync_all():
         torch.cuda.synchronize()
@@ -158,34 +218,41 @@ def main():
         b.record(stream)
     torch.cuda.synchronize()
     kdur_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-    alg_bytes = 16.0 * 4 * Np * K_local          # read state once + write rhs once
+    alg_bytes = 16.0 * nfld * Np * K_local       # read state once + write rhs once
     achieved = alg_bytes / (kdur_ms * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(f"{args.formulation}_N{N}_{Kx}x{args.ky_per_gpu}", {}).get("k_rhs_hbm_bytes_per_launch")
+            key = f"hex_N{N}_{Kx}x{Kx}x{args.kz_per_gpu}" if hexw else f"{args.formulation}_N{N}_{Kx}x{args.ky_per_gpu}"
+            traffic = json.load(open(pmc)).get(key, {}).get("k_rhs_hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_rhs (last phase: flux differencing + viscous divergence)",
+    roofline = {"bound": "hbm", "kernel": "kh_rhs (last phase: surface flux + flux differencing + lift)" if hexw else
+                "k_rhs (last phase: flux differencing + viscous divergence)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "kernel_ms": kdur_ms,
                 "whole_rhs_frac": (alg_bytes * evals_per_s / 1e9) / HBM_PEAK_GBS}
 
+    if hexw:
+        workload = f"euler3d_hex_N{N}_{Kx}x{Kx}x{Kz_total}_periodic_box_lf{args.lf:g}"
+    else:
+        workload = (f"{args.formulation}2d_N{N}_{Kx}x{Ky_total}_quads_periodic_vortex"
+                    + ("_Re1000_inviscid+viscous_dissipation" if args.formulation == "cns" else ""))
     result = {
-        "metric": "element-DOF updates/sec (RHS evals/s) at N=4, 2D CNS quad mesh",
+        "metric": "element-DOF updates/sec (RHS evals/s) at N=4, 2D CNS quad mesh" if not hexw else
+                  "element-DOF updates/sec (RHS evals/s) at N=3, 3D hex Euler",
         "value": value, "unit": "DOF updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.formulation}2d_N{N}_{Kx}x{Ky_total}_quads_periodic_vortex"
-                               + ("_Re1000_inviscid+viscous_dissipation" if args.formulation == "cns" else ""),
-                   "elements": K_total, "elements_per_gpu": K_local, "Np": Np, "nfields": 4,
-                   "parallelism": f"element-strips x{world}"},
+        "config": {"workload": workload,
+                   "elements": K_total, "elements_per_gpu": K_local, "Np": Np, "nfields": nfld,
+                   "parallelism": f"element-{'slabs' if hexw else 'strips'} x{world}"},
         "rhs_evals_per_s": evals_per_s, "elements_per_s": K_total * evals_per_s,
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(N, args.formulation)
+        result["cpu_baseline"] = cpu_baseline_hex(N, args.lf) if hexw else cpu_baseline(N, args.formulation)
     elif rank == 0:
         result["cpu_baseline"] = None
     if rank == 0:

@@ -214,12 +214,12 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
                                                      double* __restrict__ rhs, LsrkFuse lf) {
   constexpr HexLayout L(N1);
   constexpr int Nq = HCfg<N1>::Nq, Nfq = HCfg<N1>::Nfq, NIT = HCfg<N1>::NIT, NN = N1 * N1;
-  constexpr int SP = 7 * HW > HEX_NFLD * Nfq ? 7 * HW : HEX_NFLD * Nfq;   // sP doubles (sG aliases it)
   __shared__ double sTab[L.NDBL];
   __shared__ int sInt[L.NINT];
   __shared__ double sGeo[HNWV][HEX_GEO_STRIDE + 2];
-  __shared__ double sPs[HNWV][SP];
+  __shared__ double sPs[HNWV][7 * HW];
   __shared__ double sAccs[HNWV][HEX_NFLD * HW];
+  __shared__ double sGs[HNWV][HEX_NFLD * Nfq];
   const int64_t nblk = (M.K + HNWV - 1) / HNWV;
   const int64_t blk = block_of(nblk, remap != 0);
   if (blk < 0) return;
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
   const bool vin = lane < Nq;
   double* sP = sPs[wv];
   double* sAcc = sAccs[wv];
+  double* sG = sGs[wv];
   const double* geo = sGeo[wv];
 
   // ---- issue the global loads ---------------------------------------------------------------------
@@ -238,17 +239,17 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
 #pragma unroll
     for (int c = 0; c < HEX_NFLD; ++c) U[c] = Q[(int64_t)c * M.K * Nq + ec * Nq + lane];
   }
-  double qm[NIT][7], qp[NIT][7];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int f = lane + HW * it;
-    const int fc = f < Nfq ? f : Nfq - 1;
+  // raw traces of the first face-node round (own + neighbour through mapP); later rounds are prefetched one
+  // round ahead inside the face loop
+  double rm[HEX_AU_NC], rp[HEX_AU_NC];
+  {
+    const int fc = lane < Nfq ? lane : Nfq - 1;
     const int64_t nm = ec * Nfq + fc;
     const int64_t np = M.mapP[nm];
 #pragma unroll
     for (int c = 0; c < HEX_AU_NC; ++c) {
-      qm[it][c] = A_U[nm * HEX_AU_NC + c];
-      qp[it][c] = A_U[np * HEX_AU_NC + c];
+      rm[c] = A_U[nm * HEX_AU_NC + c];
+      rp[c] = A_U[np * HEX_AU_NC + c];
     }
   }
   if (lane < HEX_GEO_STRIDE) sGeo[wv][lane] = M.geo[ec * HEX_GEO_STRIDE + lane];
@@ -257,46 +258,92 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
   for (int c = 0; c < HEX_NFLD; ++c) sAcc[c * HW + lane] = 0.0;
 
   // ---- pointwise: primitives + logs ------------------------------------------------------------------
-  double qv[7];
-  prim_logs3(U, qv);
-#pragma unroll
-  for (int c = 0; c < 7; ++c) sP[c * HW + lane] = qv[c];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    qm[it][5] = log_pos(qm[it][0]);
-    qm[it][6] = log_pos(qm[it][4]);
-    qp[it][5] = log_pos(qp[it][0]);
-    qp[it][6] = log_pos(qp[it][4]);
-  }
-  __syncthreads();
-
+  double acc[HEX_NFLD] = {0.0, 0.0, 0.0, 0.0, 0.0};
   const int lq = vin ? lane : 0;
   const int i0 = lq % N1, i1 = (lq / N1) % N1, i2 = lq / NN;
-  double acc[HEX_NFLD] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  double G[NIT][HEX_NFLD];
+  {
+    double qv[7];
+    prim_logs3(U, qv);
+#pragma unroll
+    for (int c = 0; c < 7; ++c) sP[c * HW + lane] = qv[c];
+    __syncthreads();
+
+    // ---- volume lanes: circulant line schedule, each unordered pair once -------------------------------
+#pragma unroll 1
+    for (int d = 0; d < 3; ++d) {
+      const int opd = d == 0 ? HT.op[0] : (d == 1 ? HT.op[1] : HT.op[2]);
+      const double gx = geo[opd], gy = geo[3 + opd], gz = geo[6 + opd];
+      const int id = d == 0 ? i0 : (d == 1 ? i1 : i2);
+      const int o = d == 0 ? i1 + N1 * i2 : (d == 1 ? i0 + N1 * i2 : i0 + N1 * i1);
+      const int stride = d == 0 ? 1 : (d == 1 ? N1 : NN);
+      const double wt = sTab[L.WT + d * NN + o];
+#pragma unroll
+      for (int m = 1; m <= N1 / 2; ++m) {
+        int j = id + m;
+        j = j >= N1 ? j - N1 : j;
+        const bool half = (N1 % 2 == 0) && (m == N1 / 2);
+        const bool act = vin && (!half || id < N1 / 2);
+        const int node = act ? lane + (j - id) * stride : lane;
+        double qn[7], F[HEX_NFLD];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) qn[c] = sP[c * HW + node];
+        const double W = sTab[L.S + (d * N1 + id) * N1 + j] * wt;
+        ec_flux_dir(qv, qn, gx, gy, gz, F);
+        if (act) {
+#pragma unroll
+          for (int c = 0; c < HEX_NFLD; ++c) {
+            const double wf = W * F[c];
+            acc[c] += wf;
+            lds_add(&sAcc[c * HW + node], -wf);
+          }
+        }
+      }
+    }
+  }
 
   // ---- face lanes: surface flux (:185-198) and the four volume partners of every face node -----------
-#pragma unroll
+#pragma unroll 1
   for (int it = 0; it < NIT; ++it) {
     const int f = lane + HW * it;
     const bool fin = f < Nfq;
     const int fc = fin ? f : Nfq - 1;
+    double qm[7], qp[7];
+#pragma unroll
+    for (int c = 0; c < HEX_AU_NC; ++c) {
+      qm[c] = rm[c];
+      qp[c] = rp[c];
+    }
+    if (it + 1 < NIT) {   // prefetch the next round
+      const int f2 = f + HW;
+      const int fc2 = f2 < Nfq ? f2 : Nfq - 1;
+      const int64_t nm = ec * Nfq + fc2;
+      const int64_t np = M.mapP[nm];
+#pragma unroll
+      for (int c = 0; c < HEX_AU_NC; ++c) {
+        rm[c] = A_U[nm * HEX_AU_NC + c];
+        rp[c] = A_U[np * HEX_AU_NC + c];
+      }
+    }
+    qm[5] = log_pos(qm[0]);
+    qm[6] = log_pos(qm[4]);
+    qp[5] = log_pos(qp[0]);
+    qp[6] = log_pos(qp[4]);
     const int face = fc / NN;
     const double nx = geo[10 + 4 * face], ny = geo[11 + 4 * face], nz = geo[12 + 4 * face], sJ = geo[13 + 4 * face];
-    double fs[HEX_NFLD];
-    ec_flux_dir(qm[it], qp[it], nx, ny, nz, fs);
+    double G[HEX_NFLD];
+    ec_flux_dir(qm, qp, nx, ny, nz, G);
     if (ph.lf_scale != 0.0) {
       double UM[HEX_NFLD], UP[HEX_NFLD];
       const double isJ = rcp_refined(sJ);
-      const double lM = lf_lambda3(qm[it], nx, ny, nz, isJ, UM);
-      const double lP = lf_lambda3(qp[it], nx, ny, nz, isJ, UP);
+      const double lM = lf_lambda3(qm, nx, ny, nz, isJ, UM);
+      const double lP = lf_lambda3(qp, nx, ny, nz, isJ, UP);
       const double LFc = ph.lf_scale * fmax(lM, lP) * sJ;
 #pragma unroll
-      for (int c = 0; c < HEX_NFLD; ++c) fs[c] -= LFc * (UP[c] - UM[c]);
+      for (int c = 0; c < HEX_NFLD; ++c) G[c] -= LFc * (UP[c] - UM[c]);
     }
     const double wfac = sTab[L.WFAC + fc];
 #pragma unroll
-    for (int c = 0; c < HEX_NFLD; ++c) G[it][c] = wfac * fs[c];
+    for (int c = 0; c < HEX_NFLD; ++c) G[c] *= wfac;
 
     const int code = sInt[L.FINV + fc];
     const int d = code & 3, t = (code >> 2) & 1, o = code >> 3;
@@ -306,64 +353,25 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
     const double gx = geo[opd], gy = geo[3 + opd], gz = geo[6 + opd];
     const double wtf = sTab[L.WTF + (d * 2 + t) * NN + o];
     int ii = t ? (N1 + 1) / 2 : 0;
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < N1; ++i) {
       const int node = base + ii * stride;
       double qn[7], F[HEX_NFLD];
 #pragma unroll
       for (int c = 0; c < 7; ++c) qn[c] = sP[c * HW + node];
       const double W = sTab[L.SF + (d * 2 + t) * N1 + ii] * wtf;
-      ec_flux_dir(qn, qm[it], gx, gy, gz, F);
+      ec_flux_dir(qn, qm, gx, gy, gz, F);
 #pragma unroll
       for (int c = 0; c < HEX_NFLD; ++c) {
         const double wf = W * F[c];
-        G[it][c] -= wf;
+        G[c] -= wf;
         if (fin) lds_add(&sAcc[c * HW + node], wf);
       }
       ii = ii + 1 == N1 ? 0 : ii + 1;
     }
-  }
-
-  // ---- volume lanes: circulant line schedule, each unordered pair once ---------------------------------
+    if (fin) {
 #pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const int opd = HT.op[d];
-    const double gx = geo[opd], gy = geo[3 + opd], gz = geo[6 + opd];
-    const int id = d == 0 ? i0 : (d == 1 ? i1 : i2);
-    const int o = d == 0 ? i1 + N1 * i2 : (d == 1 ? i0 + N1 * i2 : i0 + N1 * i1);
-    const int stride = d == 0 ? 1 : (d == 1 ? N1 : NN);
-    const double wt = sTab[L.WT + d * NN + o];
-#pragma unroll
-    for (int m = 1; m <= N1 / 2; ++m) {
-      int j = id + m;
-      j = j >= N1 ? j - N1 : j;
-      const bool half = (N1 % 2 == 0) && (m == N1 / 2);
-      const bool act = vin && (!half || id < N1 / 2);
-      const int node = act ? lane + (j - id) * stride : lane;
-      double qn[7], F[HEX_NFLD];
-#pragma unroll
-      for (int c = 0; c < 7; ++c) qn[c] = sP[c * HW + node];
-      const double W = sTab[L.S + (d * N1 + id) * N1 + j] * wt;
-      ec_flux_dir(qv, qn, gx, gy, gz, F);
-      if (act) {
-#pragma unroll
-        for (int c = 0; c < HEX_NFLD; ++c) {
-          const double wf = W * F[c];
-          acc[c] += wf;
-          lds_add(&sAcc[c * HW + node], -wf);
-        }
-      }
-    }
-  }
-  __syncthreads();   // all pair work done: sP is dead and becomes sG
-
-  double* sG = sP;
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int f = lane + HW * it;
-    if (f < Nfq) {
-#pragma unroll
-      for (int c = 0; c < HEX_NFLD; ++c) sG[c * Nfq + f] = G[it][c];
+      for (int c = 0; c < HEX_NFLD; ++c) sG[c * Nfq + f] = G[c];
     }
   }
   __syncthreads();
