@@ -72,3 +72,18 @@ def test_cavity_driver_runs_all_wall_types():
         Q, integ = drv.run("cavity", N=2, K1D=6, T=0.02, BCTYPE=bct, verbose=False)
         assert integ.t >= 0.02 and all(np.isfinite(q).all() for q in Q)
         assert np.abs(Q[1]).max() > 0 if bct != 3 else True      # the lid drags the fluid (no-slip types)
+
+
+def test_hex_driver_rhstest_and_density_wave_convergence():
+    """examples/dg3D_euler_hex.py: the script's own diagnostic (`@show rhstest`, dg3D_euler_hex.jl:224-226: entropy
+    conservative with the LF term at factor 0) and its commented-out LSRK45 loop (:228-262) on an exact density wave."""
+    import dg3D_euler_hex as drv
+    rt = drv.run_rhstest(N=2, K1D=4, verbose=False)
+    assert abs(rt) < 1e-11
+    N = 2
+    e1, _ = drv.run_wave(N=N, K1D=4, T=0.25, verbose=False)
+    e2, rt2 = drv.run_wave(N=N, K1D=8, T=0.25, verbose=False)
+    rate = math.log2(e1 / e2)
+    print(f"hex density wave L2 error N={N}: K1D=4 {e1:.3e}, K1D=8 {e2:.3e}, rate {rate:.2f}; rhstest {rt2:.2e}")
+    assert e2 < e1 and rate > N
+    assert abs(rt2) < 1e-10
