@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--lf", type=float, default=0.0, help="hex: LF factor (the reference has 0*.25)")
     ap.add_argument("--formulation", choices=["cns", "euler", "hex"], default="cns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
+                    "rehearse the multi-rank logic on one GPU: traces are staged through the host)")
     args = ap.parse_args()
 
     import torch
@@ -151,10 +153,14 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % max(ndev, 1))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     hexw = args.formulation == "hex"
     N = args.N if args.N is not None else (3 if hexw else 4)

@@ -31,27 +31,44 @@ def _dp(a):
 
 class HaloExchanger:
     """Face-trace halo exchange over torch.distributed (backend "nccl" == RCCL over xGMI on ROCm;
-    "gloo" in the CPU tests).  Works on any 1-D uint8 workspace tensor: segments are byte ranges."""
+    "gloo" in the CPU tests).  Works on any 1-D uint8 workspace tensor: segments are byte ranges.
+    With a device workspace on the gloo backend (rehearsals of the multi-rank path on a box without enough GPUs
+    for RCCL) the segments are staged through host memory; RCCL sends/receives the device ranges directly."""
 
     def __init__(self, segments, group=None):
         # segments[xch] = list of (peer, send_off, send_bytes, recv_off, recv_bytes)
         self.segments = segments
         self.group = group
+        self._backend = None
 
     def start(self, ws_bytes, xch):
         import torch.distributed as dist
-        ops = []
+        if self._backend is None:
+            self._backend = dist.get_backend(self.group)
+        staged = ws_bytes.is_cuda and self._backend == "gloo"
+        if staged:
+            torch.cuda.current_stream(ws_bytes.device).synchronize()
+        ops, copies = [], []
         for peer, so, sb, ro, rb in self.segments[xch]:
             if rb:
-                ops.append(dist.P2POp(dist.irecv, ws_bytes[ro:ro + rb], peer, self.group))
+                dst = ws_bytes[ro:ro + rb]
+                buf = torch.empty(rb, dtype=torch.uint8) if staged else dst
+                if staged:
+                    copies.append((dst, buf))
+                ops.append(dist.P2POp(dist.irecv, buf, peer, self.group))
             if sb:
-                ops.append(dist.P2POp(dist.isend, ws_bytes[so:so + sb], peer, self.group))
-        return dist.batch_isend_irecv(ops) if ops else []
+                src = ws_bytes[so:so + sb]
+                ops.append(dist.P2POp(dist.isend, src.cpu() if staged else src, peer, self.group))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return (works, copies)
 
     @staticmethod
-    def wait(works):
+    def wait(pending):
+        works, copies = pending
         for w in works:
             w.wait()
+        for dst, buf in copies:
+            dst.copy_(buf)
 
 
 class RhsEngine:
