@@ -380,11 +380,11 @@ __global__ __launch_bounds__(TW * NWV) void kt_project(TensorTables TT, MeshDev 
 // ---------------------------------------------------------------------------------------------
 // face lanes: projected entropy variables at the face node, exterior state (neighbour, or the wall
 // boundary condition of impose_BCs_entropyvars!, cavity :178-216), half jump, penalty tau*[[v]] (:817-837)
-//   bc: 0 interior/periodic, 1 wall, 2 lid;  gn = (nxJ, nyJ, sJ) of the face;  sPn may be null (phase 1)
+//   bc: 0 interior/periodic, 1 wall, 2 lid;  gn = (nxJ, nyJ, sJ) of the face;  pn_out (registers) may be null (phase 1)
 template <int N1>
 __device__ __forceinline__ void visc_face_jumps(const Lane<N1>& ln, const double* sTab, const int* sInt,
                                                 const double* sVn, const double* vPin, int bc, const double* gn,
-                                                const Phys& ph, double* sDv, double* sPn) {
+                                                const Phys& ph, double* sDv, double* pn_out) {
   constexpr int Nq = N1 * N1, Nfq = 4 * N1;
   constexpr TensorLayout L(N1);
   int d, t, o;
@@ -425,7 +425,7 @@ __device__ __forceinline__ void visc_face_jumps(const Lane<N1>& ln, const double
     dV[c] = vP[c] - vf[c];
     sDv[(ln.ef * 3 + c) * Nfq + ln.fn] = .5 * dV[c];
   }
-  if (sPn) {
+  if (pn_out) {
     const double iv4 = rcp_refined(vf[2]);
     const double tau = -iv4 / ph.Re;
     double pn[3] = {tau * dV[0], tau * dV[1], tau * dV[2]};
@@ -436,7 +436,7 @@ __device__ __forceinline__ void visc_face_jumps(const Lane<N1>& ln, const double
       pn[2] = -tau * s * iv4;
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) sPn[(ln.ef * 3 + c) * Nfq + ln.fn] = pn[c];
+    for (int c = 0; c < 3; ++c) pn_out[c] = pn[c];
   }
 }
 
@@ -583,12 +583,12 @@ struct RhsLds {
   static constexpr int Nq = N1 * N1, Nfq = 4 * N1, Nh = Nq + Nfq, E = TCfg<N1>::E;
   static constexpr int nQh = E * Nh * 6;                 // prims+logs of all hybrid nodes; also interp scratch
   static constexpr int nFlux = E * (4 * Nq + 4 * Nfq);   // sAcc + sG
-  static constexpr int nVisc = VISC ? E * (9 * Nfq + 6 * Nq) : 0;  // sDv(3) + sPn(3) + sSj(3) per face node, sS(6) per node
+  static constexpr int nVisc = VISC ? E * (6 * Nfq + 6 * Nq) : 0;  // sDv(3) + sSj(3) per face node, sS(6) per node
   static constexpr int nR2 = nFlux > nVisc ? nFlux : nVisc;
   static_assert(8 * Nq <= 6 * Nh, "interp scratch must fit in the sQh region");
 };
 
-template <int N1, bool MODAL, bool VISC>
+template <int N1, bool MODAL, bool VISC, bool WALLS>
 __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, Phys ph, const double* Q,
                                              const double* __restrict__ A_U, const double* __restrict__ A_v,
                                              const double* __restrict__ B, double* rhs, LsrkFuse lf) {
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
   if (factive) {
     const int64_t n = (e0 + ln.ef) * Nfq + ln.fn;
     const int64_t mp = M.mapP[n];
-    if (M.bc) bcf = M.bc[n];
+    if (WALLS) bcf = M.bc[n];   // WALLS <=> M.bc != null (periodic meshes compile the wall branches away)
     const double2* aM = reinterpret_cast<const double2*>(A_U + n * FAU_NC);
     const double2* aP = reinterpret_cast<const double2*>(A_U + mp * FAU_NC);
 #pragma unroll
@@ -783,8 +783,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     __syncthreads();   // sAcc / sG are dead; sR2 becomes the viscous scratch
     double* sVn = sQh;                       // [E][3][Nq]  (v2,v3,v4): primitives no longer needed
     double* sDv = sR2;                       // [E][3][Nfq]
-    double* sPn = sDv + E * 3 * Nfq;         // [E][3][Nfq]  penalty tau*[[v]]
-    double* sSj = sPn + E * 3 * Nfq;         // [E][3][Nfq]
+    double* sSj = sDv + E * 3 * Nfq;         // [E][3][Nfq]  stress jump (+ J * penalty, see below)
     double* sS = sSj + E * 3 * Nfq;          // [E][Nq][6]
     if (ln.vin) {
       double V[4];
@@ -793,9 +792,10 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
       for (int c = 0; c < 3; ++c) sVn[(ln.ev * 3 + c) * Nq + ln.q] = V[c + 1];
     }
     __syncthreads();
+    double pnr[3] = {0, 0, 0};               // penalty tau*[[v]] of this face node (:817-837)
     if (ln.fin)
       visc_face_jumps<N1>(ln, sTab, sInt, sVn, vPn, bcf, M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1),
-                          ph, sDv, sPn);
+                          ph, sDv, pnr);
     __syncthreads();
     if (ln.vin) {
       double sgx[3], sgy[3];
@@ -829,22 +829,25 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
           sj[2] = -sn[2];
         }
       }
+      // the penalty is lifted WITHOUT the 1/J of the divergence (:839-845, quirk Q3): fold it into the stress jump
+      // as J*pn so one lifted array serves both (J*(1/J) differs from 1 by one rounding of the penalty only)
+      const double Jf = ph.viscous_dissp ? M.geo[(e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 4] : 0.0;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) sSj[(ln.ef * 3 + c) * Nfq + ln.fn] = sj[c];
+      for (int c = 0; c < 3; ++c) sSj[(ln.ef * 3 + c) * Nfq + ln.fn] = sj[c] + Jf * pnr[c];
     }
     __syncthreads();
     // divergence + penalty (dg_div! :590-611, penalty :817-845: NOT scaled by 1/J, quirk Q3)
     if (ln.vin) {
-      double dv[3] = {0, 0, 0}, pn[3] = {0, 0, 0};
+      double dv[3] = {0, 0, 0};
 #pragma unroll 1
       for (int d = 0; d < 2; ++d) {
         const int op = d == 0 ? TT.op0 : TT.op1;
         const double gx = g[op], gy = g[2 + op];
         const int pos = ln.pos(d), oth = ln.oth(d);
-#pragma unroll
+#pragma unroll 1
         for (int j = 0; j < N1; ++j) {
           const double w = sTab[L.DG + (d * N1 + pos) * N1 + j];
-          const double2* r = reinterpret_cast<const double2*>(sS + (ln.ev * Nq + node_of<N1>(d, j, oth)) * 6);
+          const double2* r = reinterpret_cast<const double2*>(sS + (ln.ev * Nq + (d == 0 ? j + N1 * oth : oth + N1 * j)) * 6);
           const double2 s0 = r[0], s1 = r[1], s2 = r[2];
           const double wx = w * gx, wy = w * gy;
           dv[0] += wx * s0.x + wy * s1.y;
@@ -856,18 +859,11 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
           const int f = sInt[L.FN + (d * 2 + t) * N1 + oth];
           const double lw = sTab[L.PF + (d * 2 + t) * N1 + pos] * sTab[L.PTF + (d * 2 + t) * N1 + oth] * sTab[L.WFAC + f];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            dv[c] += lw * sSj[(ln.ev * 3 + c) * Nfq + f];
-            pn[c] += lw * sPn[(ln.ev * 3 + c) * Nfq + f];
-          }
+          for (int c = 0; c < 3; ++c) dv[c] += lw * sSj[(ln.ev * 3 + c) * Nfq + f];
         }
       }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        double r = dv[c] * iJ;
-        if (ph.viscous_dissp) r += pn[c];
-        R[c + 1] += r;
-      }
+      for (int c = 0; c < 3; ++c) R[c + 1] += dv[c] * iJ;
     }
   }
   __syncthreads();   // sQh is dead: it becomes the Pq scratch
@@ -935,12 +931,17 @@ int launch_rhs_tensor(int N1v, const TensorTables& TT, const MeshDev& M, const P
   ESDG_DISPATCH_N1(N1v, {
     constexpr int E = TCfg<N1>::E;
     const int nb = (int)((M.K + (int64_t)E * NWV - 1) / ((int64_t)E * NWV));
+    const bool walls = M.bc != nullptr;
     if (!modal)
-      hipLaunchKernelGGL((kt_rhs<N1, false, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs, lf);
+      hipLaunchKernelGGL((kt_rhs<N1, false, false, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs, lf);
+    else if (visc && walls)
+      hipLaunchKernelGGL((kt_rhs<N1, true, true, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs, lf);
     else if (visc)
-      hipLaunchKernelGGL((kt_rhs<N1, true, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs, lf);
+      hipLaunchKernelGGL((kt_rhs<N1, true, true, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs, lf);
+    else if (walls)
+      hipLaunchKernelGGL((kt_rhs<N1, true, false, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs, lf);
     else
-      hipLaunchKernelGGL((kt_rhs<N1, true, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs, lf);
+      hipLaunchKernelGGL((kt_rhs<N1, true, false, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs, lf);
   });
   return (int)hipGetLastError();
 }
