@@ -64,6 +64,8 @@ SYMBOLS = {
     "esdg_rhs_lsrk": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp]),
     "esdg_rhs_phase_lsrk": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp]),
     "esdg_rhstest": (C.c_int, [_vp, _vp, _vp, c_double_p, _vp]),
+    "esdg_set_parts": (C.c_int, [_vp, C.c_int]),
+    "esdg_viscous_entropy_test": (C.c_int, [_vp, _vp, c_double_p, _vp]),
     "esdg_rhs_host": (C.c_int, [_vp, C.POINTER(c_double_p), C.POINTER(c_double_p)]),
     "esdg_halo_num_neighbors": (C.c_int, [_vp]),
     "esdg_num_exchanges": (C.c_int, [_vp]),

@@ -519,6 +519,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   c->ph.BCTYPE = phys->BCTYPE;
   c->ph.Re = phys->Re; c->ph.mu = phys->mu; c->ph.lambda = phys->lambda; c->ph.Pr = phys->Pr;
   c->nphases = visc ? 3 : 2;
+  c->ph.parts = 3;
   c->ph.dbg = 0;
   if (const char* env = getenv("ESDG_DBG")) c->ph.dbg = atoi(env);
 
@@ -760,6 +761,7 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
   c->ph.inviscid_dissp = 1; c->ph.viscous_dissp = 0; c->ph.BCTYPE = 0;
   c->ph.Re = c->ph.mu = c->ph.lambda = c->ph.Pr = 0.0;
   c->ph.dbg = 0;
+  c->ph.parts = 3;
   if (const char* env = getenv("ESDG_DBG")) c->ph.dbg = atoi(env);
   c->nphases = 2;
   c->use_fast = true;
@@ -899,7 +901,7 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
       if (!rc && visc) rc = launch_pack(A_v, AV_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[1].send_off), s);
     }
   } else if (visc && phase == 1) {
-    rc = ctx->use_fast ? launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_v, B, s)
+    rc = ctx->use_fast ? launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_v, B, nullptr, s)
                        : launch_sigma(ctx->T, ctx->M, ctx->ph, Q, A_v, B, s);
     if (!rc && ctx->nsend) rc = launch_pack(B, B_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[2].send_off), s);
   } else {
@@ -960,6 +962,40 @@ int esdg_rhstest(esdg_ctx* ctx, const double* Q, const double* rhs, double* diag
   for (double v : h) t += v;
   diag[0] = t;
   diag[1] = 0.0;
+  return ESDG_OK;
+}
+
+int esdg_set_parts(esdg_ctx* ctx, int parts) {
+  if (!ctx) return fail(ESDG_ERR_ARG, "null ctx");
+  if (parts < 1 || parts > 3) return fail(ESDG_ERR_ARG, "parts must be 1 (inviscid), 2 (viscous) or 3 (both)");
+  if (parts != 3 && (ctx->dim != 2 || ctx->nphases != 3 || !ctx->use_fast))
+    return fail(ESDG_ERR_STATE, "the inviscid/viscous split needs a CNS context on the tensor kernels");
+  ctx->ph.parts = parts;
+  return ESDG_OK;
+}
+
+int esdg_viscous_entropy_test(esdg_ctx* ctx, const double* Q, double* out, void* stream) {
+  if (!ctx || !Q || !out) return fail(ESDG_ERR_ARG, "null argument");
+  if (ctx->dim != 2 || ctx->nphases != 3 || !ctx->use_fast) return fail(ESDG_ERR_STATE, "needs a CNS context on the tensor kernels");
+  if (ctx->nghost) return fail(ESDG_ERR_STATE, "esdg_viscous_entropy_test needs an unsharded mesh");
+  if (!ctx->M.wJq) return fail(ESDG_ERR_STATE, "wJq was not supplied at esdg_create");
+  if (!ctx->ws) return fail(ESDG_ERR_STATE, "workspace not bound (esdg_bind_workspace)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = esdg_rhs_phase(ctx, 0, Q, nullptr, stream);
+  if (rc) return rc;
+  const int nb = sigma_tensor_blocks(ctx->T.N1, ctx->K);
+  DevBuf part;
+  if ((rc = part.alloc(sizeof(double) * (size_t)nb)) != 0) return rc;
+  double* A_v = reinterpret_cast<double*>(ctx->ws + ctx->off_Av);
+  double* B = reinterpret_cast<double*>(ctx->ws + ctx->off_B);
+  rc = launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_v, B, static_cast<double*>(part.p), s);
+  if (rc) return fail(ESDG_ERR_NO_DEVICE, "kt_sigma launch: %s", hipGetErrorString((hipError_t)rc));
+  std::vector<double> h((size_t)nb);
+  HIP_TRY(hipMemcpyAsync(h.data(), part.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  double t = 0.0;
+  for (double v : h) t += v;
+  *out = t;
   return ESDG_OK;
 }
 

@@ -49,7 +49,8 @@ struct Phys;
 int launch_project_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
                           double* A_U, double* A_v, hipStream_t s);
 int launch_sigma_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
-                        const double* A_v, double* B, hipStream_t s);
+                        const double* A_v, double* B, double* visc_test_partial, hipStream_t s);
+int sigma_tensor_blocks(int N1, int64_t K);
 struct LsrkFuse;
 int launch_rhs_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
                       const double* A_U, const double* A_v, const double* B, double* rhs, const LsrkFuse& lf,
@@ -78,6 +79,7 @@ struct Phys {
   int inviscid_dissp, viscous_dissp, BCTYPE;
   double Re, mu, lambda, Pr;
   int dbg;  // timing-ablation mask from ESDG_DBG (diagnostic builds only; 0 in normal use)
+  int parts;  // bit 0: inviscid terms (rhs_inviscid!), bit 1: viscous terms (rhs_viscous!); 3 = rhsRK!
 };
 
 // kernel launchers (esdg_kernels.hip); return hipError_t as int

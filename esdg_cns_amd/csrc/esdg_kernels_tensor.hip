@@ -444,7 +444,8 @@ __device__ __forceinline__ void visc_face_jumps(const Lane<N1>& ln, const double
 template <int N1>
 __device__ __forceinline__ void visc_sigma(const Lane<N1>& ln, const double* sTab, const int* sInt,
                                            const TensorTables& TT, const Phys& ph, const double* g,
-                                           const double* sVn, const double* sDv, double* sgx, double* sgy) {
+                                           const double* sVn, const double* sDv, double* sgx, double* sgy,
+                                           double* gradx = nullptr, double* grady = nullptr) {
   constexpr int Nq = N1 * N1, Nfq = 4 * N1;
   constexpr TensorLayout L(N1);
   double tx[3] = {0, 0, 0}, ty[3] = {0, 0, 0};
@@ -485,6 +486,10 @@ __device__ __forceinline__ void visc_sigma(const Lane<N1>& ln, const double* sTa
   const double* r = sVn + ln.ev * 3 * Nq + ln.q;
   const double v[3] = {r[0], r[Nq], r[2 * Nq]};
   viscous_stress(v, tx, ty, -ph.lambda, ph.mu, 1.4 * ph.mu / ph.Pr, sgx, sgy);
+  if (gradx) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { gradx[c] = tx[c]; grady[c] = ty[c]; }
+  }
 }
 
 // face lanes: own normal stress (Ef*sigma_x)*nxJ + (Ef*sigma_y)*nyJ;  sS: [E][Nq][6]
@@ -513,9 +518,11 @@ __device__ __forceinline__ void face_normal_stress(const Lane<N1>& ln, const dou
 // ---------------------------------------------------------------------------------------------
 // phase 1 (CNS): sigma = K(v) grad v, normal stress traces -> B
 // ---------------------------------------------------------------------------------------------
-template <int N1>
+// DIAG: also reduce visc_test = sum(wJq .* (VUx .* sigma_x + VUy .* sigma_y)) (rhs_viscous! :802-806) per workgroup
+template <int N1, bool DIAG>
 __global__ __launch_bounds__(TW * NWV) void kt_sigma(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
-                                               const double* __restrict__ A_v, double* __restrict__ B) {
+                                               const double* __restrict__ A_v, double* __restrict__ B,
+                                               double* __restrict__ vt_partial) {
   constexpr int Nq = N1 * N1, Nfq = 4 * N1, E = TCfg<N1>::E;
   constexpr TensorLayout L(N1);
   __shared__ double sTab[L.NDBL];
@@ -557,13 +564,17 @@ __global__ __launch_bounds__(TW * NWV) void kt_sigma(TensorTables TT, MeshDev M,
     visc_face_jumps<N1>(ln, sTab, sInt, sA, vP, bc, M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1), ph, sDv, nullptr);
   }
   __syncthreads();
+  double vt = 0.0;
   if (ln.vin) {
-    double sgx[3], sgy[3];
-    visc_sigma<N1>(ln, sTab, sInt, TT, ph, M.geo + (e0 + (vactive ? ln.ev : 0)) * GEO_STRIDE, sA, sDv, sgx, sgy);
+    double sgx[3], sgy[3], gx[3], gy[3];
+    visc_sigma<N1>(ln, sTab, sInt, TT, ph, M.geo + (e0 + (vactive ? ln.ev : 0)) * GEO_STRIDE, sA, sDv, sgx, sgy,
+                   DIAG ? gx : nullptr, DIAG ? gy : nullptr);
     double2* r = reinterpret_cast<double2*>(sB + (ln.ev * Nq + ln.q) * 6);
     r[0] = make_double2(sgx[0], sgx[1]);
     r[1] = make_double2(sgx[2], sgy[0]);
     r[2] = make_double2(sgy[1], sgy[2]);
+    if (DIAG && vactive)
+      vt = M.wJq[(e0 + ln.ev) * Nq + ln.q] * (gx[0] * sgx[0] + gx[1] * sgx[1] + gx[2] * sgx[2] + gy[0] * sgy[0] + gy[1] * sgy[1] + gy[2] * sgy[2]);
   }
   __syncthreads();
   if (factive) {
@@ -572,6 +583,17 @@ __global__ __launch_bounds__(TW * NWV) void kt_sigma(TensorTables TT, MeshDev M,
     face_normal_stress<N1>(ln, sTab, sInt, sB, gn[0], gn[1], sn, fx, fy);
     double* bb = B + ((e0 + ln.ef) * Nfq + ln.fn) * B_NC;
     bb[0] = sn[0]; bb[1] = sn[1]; bb[2] = sn[2];
+  }
+  if (DIAG) {   // fixed-order tree reduction over the workgroup
+    __syncthreads();
+    double* red = sB_;
+    red[threadIdx.x] = vt;
+    __syncthreads();
+    for (int w = TW * NWV / 2; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) vt_partial[blockIdx.x] = red[0];
   }
 }
 
@@ -650,6 +672,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
   }
   // ---- face lanes: interface flux (euler_quad.jl:158-169 / update_flux! :308-324), kept in registers
   double flx[4] = {0, 0, 0, 0};
+  const bool inviscid = (ph.parts & 1) != 0;
   if (ln.fin) {
     double2* dq = reinterpret_cast<double2*>(sQh + (ln.ef * Nh + Nq + ln.fn) * 6);
     dq[0] = make_double2(qM[0], qM[1]);
@@ -674,7 +697,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     double dU[4] = {qP[0] - qM[0], qP[0] * qP[1] - qM[0] * qM[1], qP[0] * qP[2] - qM[0] * qM[2], qP[7] - qM[7]};
     if (bcf) { dU[0] = 0.0; dU[1] = 0.0; dU[2] = 0.0; dU[3] = 0.0; }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) flx[c] = Fx[c] * gn[0] + Fy[c] * gn[1] - LFc * dU[c];
+    for (int c = 0; c < 4; ++c) flx[c] = inviscid ? Fx[c] * gn[0] + Fy[c] * gn[1] - LFc * dU[c] : 0.0;
   }
   // neighbour traces of the viscous part: issued now, consumed after the flux phase
   if (VISC && factive) {
@@ -687,7 +710,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
 
   // ---- flux differencing along the tensor lines (sparse_hadamard_sum :102-138 / flux_differencing! :326-348)
   double acc[4] = {0, 0, 0, 0};
-  if (ln.vin && !(ph.dbg & 1)) {
+  if (ln.vin && inviscid && !(ph.dbg & 1)) {
 #pragma unroll 1
     for (int d = 0; d < 2; ++d) {
       const int op = d == 0 ? TT.op0 : TT.op1;
@@ -779,7 +802,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     for (int c = 0; c < 4; ++c) R[c] = -r[c] * iJ;
   }
   // ---- viscous terms (rhs_viscous! :749-849 in collocated form) ------------------------------------
-  if (VISC && !(ph.dbg & 2)) {
+  if (VISC && (ph.parts & 2) && !(ph.dbg & 2)) {
     __syncthreads();   // sAcc / sG are dead; sR2 becomes the viscous scratch
     double* sVn = sQh;                       // [E][3][Nq]  (v2,v3,v4): primitives no longer needed
     double* sDv = sR2;                       // [E][3][Nfq]
@@ -912,13 +935,24 @@ int launch_project_tensor(int N1v, const TensorTables& TT, const MeshDev& M, con
   return (int)hipGetLastError();
 }
 
+int sigma_tensor_blocks(int N1v, int64_t K) {
+  ESDG_DISPATCH_N1(N1v, {
+    constexpr int E = TCfg<N1>::E;
+    return (int)((K + (int64_t)E * NWV - 1) / ((int64_t)E * NWV));
+  });
+  return 0;
+}
+
 int launch_sigma_tensor(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
-                        const double* A_v, double* B, hipStream_t s) {
+                        const double* A_v, double* B, double* vt_partial, hipStream_t s) {
   if (M.K == 0) return 0;
   ESDG_DISPATCH_N1(N1v, {
     constexpr int E = TCfg<N1>::E;
     const int nb = (int)((M.K + (int64_t)E * NWV - 1) / ((int64_t)E * NWV));
-    hipLaunchKernelGGL((kt_sigma<N1>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_v, B);
+    if (vt_partial)
+      hipLaunchKernelGGL((kt_sigma<N1, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_v, B, vt_partial);
+    else
+      hipLaunchKernelGGL((kt_sigma<N1, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_v, B, vt_partial);
   });
   return (int)hipGetLastError();
 }

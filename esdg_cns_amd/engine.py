@@ -273,6 +273,24 @@ class RhsEngine:
         check(self.L.esdg_rhstest(self.ctx, C.c_void_p(Qd.data_ptr()), C.c_void_p(rhsd.data_ptr()), diag, self._stream()))
         return diag[0]
 
+    def set_parts(self, parts):
+        """1 = rhs_inviscid! only, 2 = rhs_viscous! only, 3 = rhsRK! (default)."""
+        check(self.L.esdg_set_parts(self.ctx, int(parts)))
+
+    def rhsRK_diagnostics(self, Qd, rhsd=None):
+        """(rhstest, rhstest_visc) of rhsRK! (cavity_optimized.jl:958-969) for the state Qd."""
+        if rhsd is None:
+            rhsd = self.rhs(Qd)
+        rt = self.rhstest(Qd, rhsd)
+        self.set_parts(2)
+        try:
+            visc = self.rhs(Qd)
+        finally:
+            self.set_parts(3)
+        vt = C.c_double(0.0)
+        check(self.L.esdg_viscous_entropy_test(self.ctx, C.c_void_p(Qd.data_ptr()), C.byref(vt), self._stream()))
+        return rt, self.rhstest(Qd, visc) + vt.value
+
     def rhs_host(self, Q):
         """Literal drop-in on host arrays through esdg_rhs_host (H2D + rhs + D2H)."""
         Qh = [_f(q) for q in Q]
@@ -351,9 +369,10 @@ def rhs_hex(Q, md, ops, flux_fun=None, compute_rhstest=False, rd=None, lf_scale=
 
 def rhsRK(Q, rd, md, ops, Re=1000.0, lam=None, mu=None, Pr=.71, inviscid_dissp=True, viscous_dissp=True, BCTYPE=1):
     """Drop-in for `rhsRK!` of dg2D_CNS_cavity_optimized.jl:955 on quad elements: Q = 4 (Np x K)
-    nodal coefficient matrices; returns (rhsQ, rhstest).  (rhstest_visc is not produced yet.)"""
+    nodal coefficient matrices; returns (rhsQ, rhstest, rhstest_visc)."""
     eng = _engine_for(md, rd, ops, CNS_MODAL, Re=Re, lam=lam, mu=mu, Pr=Pr, inviscid_dissp=inviscid_dissp,
                       viscous_dissp=viscous_dissp, BCTYPE=BCTYPE)
     Qd = eng.upload(Q)
     r = eng.rhs(Qd)
-    return tuple(eng.download(r)), eng.rhstest(Qd, r)
+    rt, rtv = eng.rhsRK_diagnostics(Qd, r)
+    return tuple(eng.download(r)), rt, rtv

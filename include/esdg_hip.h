@@ -186,6 +186,15 @@ int esdg_rhs_phase_lsrk(esdg_ctx* ctx, int phase, double* Q_dev, double* resQ_de
  * is the caller's job). */
 int esdg_rhstest(esdg_ctx* ctx, const double* Q_dev, const double* rhs_dev, double* diag, void* stream);
 
+/* rhsRK! = rhs_inviscid! + rhs_viscous! (cavity_optimized.jl:955-957).  esdg_set_parts selects which of the two a
+ * CNS context evaluates in the following esdg_rhs* calls: 1 = rhs_inviscid! (:447), 2 = rhs_viscous! (:749), 3 = both
+ * (default).  esdg_viscous_entropy_test returns the second value of rhs_viscous!,
+ *   visc_test = sum(wJq .* (VUx .* sigma_x + VUy .* sigma_y))   (:802-806),
+ * so that rhsRK!'s third return is  rhstest_visc = esdg_rhstest(Q, rhs_viscous) + visc_test  (:962-969).
+ * (Runs phases 0 and 1 itself; unsharded meshes; synchronises `stream`.) */
+int esdg_set_parts(esdg_ctx* ctx, int parts);
+int esdg_viscous_entropy_test(esdg_ctx* ctx, const double* Q_dev, double* visc_test, void* stream);
+
 /* Literal drop-in with host arrays (Julia Matrix{Float64} per field): H2D, rhs, D2H.
  * PCIe-bound -- for validation, not for time stepping. nranks must be 1. */
 int esdg_rhs_host(esdg_ctx* ctx, const double* const* Q, double* const* rhs);  /* esdg_num_fields() pointers each */

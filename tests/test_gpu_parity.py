@@ -108,3 +108,36 @@ def test_cns_wall_boundary_conditions_match_oracle(eng_mod, oracle_lib, BCTYPE, 
     ev = rel_l2(gv[1:], rv[1:])
     print(f"cavity BCTYPE={BCTYPE} viscous part: err={ev:.2e}")
     assert ev <= 1e-9
+
+
+@pytest.mark.parametrize("bc,BCTYPE", [("periodic", 1), ("cavity", 1), ("cavity", 3)])
+def test_rhs_inviscid_viscous_split_and_rhsRK_diagnostics(eng_mod, oracle_lib, bc, BCTYPE):
+    """esdg_set_parts: 1 = rhs_inviscid! (:447), 2 = rhs_viscous! (:749) against the oracle's separate restatements, and
+    the three returns of rhsRK! (:955-972): rhsQ, rhstest, rhstest_visc (visc_test from esdg_viscous_entropy_test)."""
+    from oracle import oracle as orc
+    N, Kx, Ky = 3, 6, 5
+    p = orc.build_cns_problem(N, Kx, Ky, bc=bc, BCTYPE=BCTYPE)
+    co = orc.CnsOracle(p)
+    rd, md, ops, Q = (product_cns_problem if bc == "periodic" else product_cavity_problem)(N, Kx, Ky)
+    eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, BCTYPE=BCTYPE)
+    Qd = eng.upload(Q)
+    tot = eng.rhs(Qd)
+    eng.set_parts(1)
+    inv = eng.download(eng.rhs(Qd))
+    eng.set_parts(2)
+    vis = eng.download(eng.rhs(Qd))
+    eng.set_parts(3)
+    ref_i = co.rhs_inviscid(p.Q)
+    ref_v, visc_test = co.rhs_viscous(p.Q)
+    fl = noise_floor(lambda q: co.rhs_inviscid(q), p.Q)
+    assert rel_l2(inv, ref_i) <= max(TOL, 4 * fl), (rel_l2(inv, ref_i), fl)
+    assert rel_l2(vis[1:], ref_v[1:]) <= 1e-11 and np.abs(vis[0]).max() == 0.0
+    assert rel_l2([a + b for a, b in zip(inv, vis)], eng.download(tot)) <= 1e-13
+    ref, rt_ref, rtv_ref = co.rhsRK(p.Q)
+    rt, rtv = eng.rhsRK_diagnostics(Qd, tot)
+    print(f"{bc} BCTYPE={BCTYPE}: rhstest {rt:.6e} (oracle {rt_ref:.6e})  rhstest_visc {rtv:.6e} (oracle {rtv_ref:.6e}) visc_test {visc_test:.6e}")
+    scale = max(abs(rt_ref), abs(rtv_ref), abs(visc_test), 1e-6)
+    assert abs(rt - rt_ref) <= 1e-9 * scale and abs(rtv - rtv_ref) <= 1e-9 * scale
+    # the reference-signature wrapper returns the same triple
+    out, rt2, rtv2 = eng_mod.rhsRK(Q, rd, md, ops, BCTYPE=BCTYPE)
+    assert rt2 == rt and rtv2 == rtv and rel_l2(out, ref) <= max(TOL, 4 * noise_floor(lambda q: co.rhsRK(q, False)[0], p.Q))
