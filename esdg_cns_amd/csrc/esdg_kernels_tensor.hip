@@ -83,6 +83,39 @@ __device__ __forceinline__ void ec_flux(const double* qL, const double* qR, doub
   Fy[3] = f4aux * vavg;
 }
 
+// (gx,gy) . (Fx,Fy) of the same flux: what flux differencing and the interface flux actually need (the weight
+// or normal is folded into g), 10 multiply-adds fewer than forming Fx and Fy and contracting them afterwards
+template <bool MODAL>
+__device__ __forceinline__ void ec_flux_dir(const double* qL, const double* qR, double gx, double gy, double* F) {
+  constexpr double GM1 = Gas<MODAL>::GM1;
+  const double dr = qR[0] - qL[0], ravg = .5 * (qR[0] + qL[0]);
+  const double db = qR[3] - qL[3], bavg = .5 * (qR[3] + qL[3]);
+  const double A = qL[4] - qR[4], B = qL[5] - qR[5];
+  const bool ser_r = fabs(dr) < 1e-4 * ravg, ser_b = fabs(db) < 1e-4 * bavg;
+  const double yr = ser_r ? ravg : A;
+  const double yb = ser_b ? bavg : db;
+  const double yp = qL[3] + qR[3];
+  const double ybp = yb * yp;
+  const double R = rcp_refined(yr * ybp);
+  const double ir = R * ybp;
+  const double ryr = R * yr;
+  const double ib = ryr * yp;
+  const double ip = ryr * yb;
+  const double fr = dr * ir, vr = fr * fr;
+  const double rholog = ser_r ? ravg * (1 + vr * (-.2 - vr * (.0512 - vr * 0.026038857142857))) : -fr;
+  const double fb = db * ib, vb = fb * fb;
+  const double ibetalog = ser_b ? ib * (1 + vb * (.2 + vb * .0912)) : -(B * ib);
+  const double uavg = .5 * (qL[1] + qR[1]), vavg = .5 * (qL[2] + qR[2]);
+  const double unorm = qL[1] * qR[1] + qL[2] * qR[2];
+  const double pa = ravg * ip;
+  const double f4aux = rholog * ibetalog * (1.0 / (2 * GM1)) + pa + .5 * rholog * unorm;
+  const double un = gx * uavg + gy * vavg;
+  F[0] = rholog * un;
+  F[1] = F[0] * uavg + pa * gx;
+  F[2] = F[0] * vavg + pa * gy;
+  F[3] = f4aux * un;
+}
+
 // conservative -> (rho,u,v,beta,log rho,log beta)  (betafun euler_variables.jl:30-48 / cavity :484);
 // 1/rho and 1/rhoe from one reciprocal
 template <bool MODAL>
@@ -690,14 +723,14 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
       qP[1] = qM[1] - 2 * un * nx;
       qP[2] = qM[2] - 2 * un * ny;
     }
-    double Fx[4], Fy[4];
-    ec_flux<MODAL>(qM, qP, Fx, Fy);
+    double Fn[4];
+    ec_flux_dir<MODAL>(qM, qP, gn[0], gn[1], Fn);
     const double LFc = ph.inviscid_dissp ? ph.lf_scale * fmax(qM[6], qP[6]) * gn[2] : 0.0;
     // LF jump uses Uf[mapP] - Uf, which vanishes at walls (mapP = self), cavity :511-513
     double dU[4] = {qP[0] - qM[0], qP[0] * qP[1] - qM[0] * qM[1], qP[0] * qP[2] - qM[0] * qM[2], qP[7] - qM[7]};
     if (bcf) { dU[0] = 0.0; dU[1] = 0.0; dU[2] = 0.0; dU[3] = 0.0; }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) flx[c] = inviscid ? Fx[c] * gn[0] + Fy[c] * gn[1] - LFc * dU[c] : 0.0;
+    for (int c = 0; c < 4; ++c) flx[c] = inviscid ? Fn[c] - LFc * dU[c] : 0.0;
   }
   // neighbour traces of the viscous part: issued now, consumed after the flux phase
   if (VISC && factive) {
@@ -731,15 +764,13 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
           const double2* pr = reinterpret_cast<const double2*>(sQh + (ln.ev * Nh + pid) * 6);
           const double2 p0 = pr[0], p1 = pr[1], p2 = pr[2];
           const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
-          double Fx[4], Fy[4];
-          ec_flux<MODAL>(qh, qj, Fx, Fy);
-          const double cx = cw * gx, cy = cw * gy;
+          double Fd[4];
+          ec_flux_dir<MODAL>(qh, qj, cw * gx, cw * gy, Fd);
           double* tgt = sAcc + ln.ev * 4 * Nq + pid;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const double v = cx * Fx[c] + cy * Fy[c];
-            acc[c] += v;
-            lds_add(tgt + c * Nq, -v);
+            acc[c] += Fd[c];
+            lds_add(tgt + c * Nq, -Fd[c]);
           }
         }
       }
@@ -750,16 +781,11 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
         const double2* pr = reinterpret_cast<const double2*>(sQh + (ln.ev * Nh + Nq + f) * 6);
         const double2 p0 = pr[0], p1 = pr[1], p2 = pr[2];
         const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
-        double Fx[4], Fy[4];
-        ec_flux<MODAL>(qh, qj, Fx, Fy);
-        const double cx = cw * gx, cy = cw * gy;
-        double* tgt = sG + ln.ev * 4 * Nfq + f;
         double vv[4];
+        ec_flux_dir<MODAL>(qh, qj, cw * gx, cw * gy, vv);
+        double* tgt = sG + ln.ev * 4 * Nfq + f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          vv[c] = cx * Fx[c] + cy * Fy[c];
-          acc[c] += vv[c];
-        }
+        for (int c = 0; c < 4; ++c) acc[c] += vv[c];
         // all N1 lanes of the line add into the same face node: rotate the field order by the lane's
         // position so that one ds_add_f64 instruction hits (almost) distinct addresses instead of N1 equal ones
         const int rot = pos & 3;
