@@ -704,15 +704,12 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     for (int c = 0; c < 4; ++c) sAcc[(ln.ev * 4 + c) * Nq + ln.q] = 0.0;
   }
   // ---- face lanes: interface flux (euler_quad.jl:158-169 / update_flux! :308-324), kept in registers
-  double flx[4] = {0, 0, 0, 0};
   const bool inviscid = (ph.parts & 1) != 0;
   if (ln.fin) {
     double2* dq = reinterpret_cast<double2*>(sQh + (ln.ef * Nh + Nq + ln.fn) * 6);
     dq[0] = make_double2(qM[0], qM[1]);
     dq[1] = make_double2(qM[2], qM[3]);
     dq[2] = make_double2(qM[4], qM[5]);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) sG[(ln.ef * 4 + c) * Nfq + ln.fn] = 0.0;
     const double* gn = M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
     if (bcf) {   // wall: mirror state rho+ = rho, beta+ = beta, u+ = u - 2 (u.n) n  (impose_BCs_inviscid! :157-176)
       const double is = rcp_refined(gn[2]);
@@ -729,8 +726,11 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     // LF jump uses Uf[mapP] - Uf, which vanishes at walls (mapP = self), cavity :511-513
     double dU[4] = {qP[0] - qM[0], qP[0] * qP[1] - qM[0] * qM[1], qP[0] * qP[2] - qM[0] * qM[2], qP[7] - qM[7]};
     if (bcf) { dU[0] = 0.0; dU[1] = 0.0; dU[2] = 0.0; dU[3] = 0.0; }
+    // the face accumulator starts from the lifted interface flux: G_f = wfac_f * flux_f + QF_f (QF_f is added by
+    // the volume lanes below)
+    const double wf = inviscid ? sTab[L.WFAC + ln.fn] : 0.0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) flx[c] = inviscid ? Fn[c] - LFc * dU[c] : 0.0;
+    for (int c = 0; c < 4; ++c) sG[(ln.ef * 4 + c) * Nfq + ln.fn] = wf * (Fn[c] - LFc * dU[c]);
   }
   // neighbour traces of the viscous part: issued now, consumed after the flux phase
   if (VISC && factive) {
@@ -796,13 +796,6 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
         }
       }
     }
-  }
-  __syncthreads();
-  // face lanes: G_f = QF_f + wfac_f * flux_f
-  if (ln.fin) {
-    const double wf = sTab[L.WFAC + ln.fn];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) sG[(ln.ef * 4 + c) * Nfq + ln.fn] += wf * flx[c];
   }
   __syncthreads();
   // ---- collocated rhs: -(Ph*QF + Lf*flux)/J  (euler_quad.jl:170-184 / cavity :514-518) -------
