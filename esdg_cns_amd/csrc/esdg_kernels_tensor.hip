@@ -536,7 +536,7 @@ __device__ __forceinline__ void face_normal_stress(const Lane<N1>& ln, const dou
   face_dto(sInt, L.FINV, ln.fn, d, t, o);
 #pragma unroll
   for (int c = 0; c < 3; ++c) { fx[c] = 0.0; fy[c] = 0.0; }
-#pragma unroll
+#pragma unroll 1
   for (int j = 0; j < N1; ++j) {
     const double w = sTab[L.EE + (d * 2 + t) * N1 + j];
     const double2* r = reinterpret_cast<const double2*>(sS + (ln.ef * Nq + node_of<N1>(d, j, o)) * 6);
@@ -732,13 +732,6 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
 #pragma unroll
     for (int c = 0; c < 4; ++c) sG[(ln.ef * 4 + c) * Nfq + ln.fn] = wf * (Fn[c] - LFc * dU[c]);
   }
-  // neighbour traces of the viscous part: issued now, consumed after the flux phase
-  if (VISC && factive) {
-    const double* vp = A_v + mpk * AV_NC;
-    const double* bp = B + mpk * B_NC;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { vPn[c] = vp[c]; bPn[c] = bp[c]; }
-  }
   __syncthreads();
 
   // ---- flux differencing along the tensor lines (sparse_hadamard_sum :102-138 / flux_differencing! :326-348)
@@ -823,6 +816,12 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
   // ---- viscous terms (rhs_viscous! :749-849 in collocated form) ------------------------------------
   if (VISC && (ph.parts & 2) && !(ph.dbg & 2)) {
     __syncthreads();   // sAcc / sG are dead; sR2 becomes the viscous scratch
+    if (factive) {   // neighbour traces of the viscous part
+      const double* vp = A_v + mpk * AV_NC;
+      const double* bp = B + mpk * B_NC;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { vPn[c] = vp[c]; bPn[c] = bp[c]; }
+    }
     double* sVn = sQh;                       // [E][3][Nq]  (v2,v3,v4): primitives no longer needed
     double* sDv = sR2;                       // [E][3][Nfq]
     double* sSj = sDv + E * 3 * Nfq;         // [E][3][Nfq]  stress jump (+ J * penalty, see below)
