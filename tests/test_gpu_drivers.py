@@ -87,3 +87,32 @@ def test_hex_driver_rhstest_and_density_wave_convergence():
     print(f"hex density wave L2 error N={N}: K1D=4 {e1:.3e}, K1D=8 {e2:.3e}, rate {rate:.2f}; rhstest {rt2:.2e}")
     assert e2 < e1 and rate > N
     assert abs(rt2) < 1e-10
+
+
+def test_lsrk45_hip_graph_replay_is_bitwise_equal_and_faster_on_cfg1():
+    """BASELINE cfg1 (Euler N=3, 16x16): the LSRK45 loop replayed from one captured HIP graph per step gives the same
+    bits as the stage-by-stage loop; wall time per step is reported."""
+    import time
+    import torch
+    from common import product_euler_problem
+    from esdg_cns_amd import engine, timestep
+    rd, md, ops, Q = product_euler_problem(3, 16, 16)
+    eng = engine.RhsEngine(rd, md, ops, engine.EULER_COLLOCATED)
+    dt, nsteps = 0.025, 40
+    Q1, Q2 = eng.upload(Q), eng.upload(Q)
+    timestep.lsrk45_run(eng, Q1.clone(), dt, 2)          # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    timestep.lsrk45_run(eng, Q1, dt, nsteps)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    g = timestep.lsrk45_run_graph(eng, Q2, dt, 0)        # capture only
+    torch.cuda.synchronize()
+    t1b = time.perf_counter()
+    for _ in range(nsteps):
+        g.replay()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"cfg1 LSRK45: {1e6 * (t1 - t0) / nsteps:.1f} us/step stage-by-stage, {1e6 * (t2 - t1b) / nsteps:.1f} us/step graph replay "
+          f"(capture {1e3 * (t1b - t1):.1f} ms once)")
+    assert torch.equal(Q1, Q2)
