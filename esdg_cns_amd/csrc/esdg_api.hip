@@ -712,19 +712,23 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   const size_t nodes = (size_t)(K * Nfq + c->nghost);
   size_t off = 0;
   c->off_AU = off; off = align(off + nodes * c->au_nc * sizeof(double));
+  const bool need_Av = visc && !use_fast;   // the tensor kernels rebuild the neighbour's (v2,v3,v4) from its A_U record
   if (visc) {
-    c->off_Av = off; off = align(off + nodes * AV_NC * sizeof(double));
+    if (need_Av) { c->off_Av = off; off = align(off + nodes * AV_NC * sizeof(double)); }
     c->off_B = off; off = align(off + nodes * B_NC * sizeof(double));
   }
-  Exchange x0{0, c->nphases - 1, c->au_nc, c->off_AU, off};
+  // exchange 0 (A_U): produced by phase 0; needed by the last phase, and already by phase 1 on the tensor CNS path
+  Exchange x0{0, (visc && use_fast) ? 1 : c->nphases - 1, c->au_nc, c->off_AU, off};
   off = align(off + (size_t)c->nsend * c->au_nc * sizeof(double));
   c->xch.push_back(x0);
-  if (visc) {
+  if (need_Av) {
     Exchange x1{0, 1, AV_NC, c->off_Av, off};
     off = align(off + (size_t)c->nsend * AV_NC * sizeof(double));
+    c->xch.push_back(x1);
+  }
+  if (visc) {
     Exchange x2{1, 2, B_NC, c->off_B, off};
     off = align(off + (size_t)c->nsend * B_NC * sizeof(double));
-    c->xch.push_back(x1);
     c->xch.push_back(x2);
   }
   c->ws_bytes = off;
@@ -880,7 +884,8 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
   hipStream_t s = static_cast<hipStream_t>(stream);
   double* A_U = reinterpret_cast<double*>(ctx->ws + ctx->off_AU);
   const bool visc = ctx->nphases == 3;
-  double* A_v = visc ? reinterpret_cast<double*>(ctx->ws + ctx->off_Av) : nullptr;
+  const bool need_Av = visc && !ctx->use_fast;
+  double* A_v = need_Av ? reinterpret_cast<double*>(ctx->ws + ctx->off_Av) : nullptr;
   double* B = visc ? reinterpret_cast<double*>(ctx->ws + ctx->off_B) : nullptr;
   int rc = 0;
   const int32_t* sl = ctx->d_sendlist.as<int32_t>();
@@ -898,12 +903,12 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
                        : launch_project(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, s);
     if (!rc && ctx->nsend) {
       rc = launch_pack(A_U, ctx->au_nc, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[0].send_off), s);
-      if (!rc && visc) rc = launch_pack(A_v, AV_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[1].send_off), s);
+      if (!rc && need_Av) rc = launch_pack(A_v, AV_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[1].send_off), s);
     }
   } else if (visc && phase == 1) {
-    rc = ctx->use_fast ? launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_v, B, nullptr, s)
+    rc = ctx->use_fast ? launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, nullptr, s)
                        : launch_sigma(ctx->T, ctx->M, ctx->ph, Q, A_v, B, s);
-    if (!rc && ctx->nsend) rc = launch_pack(B, B_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[2].send_off), s);
+    if (!rc && ctx->nsend) rc = launch_pack(B, B_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch.back().send_off), s);
   } else {
     if (!rhs && !lf.Qw) return fail(ESDG_ERR_ARG, "rhs output is null");
     if (lf.Qw && !ctx->use_fast) return fail(ESDG_ERR_STATE, "the fused RK update needs the tensor kernels");
@@ -986,9 +991,9 @@ int esdg_viscous_entropy_test(esdg_ctx* ctx, const double* Q, double* out, void*
   const int nb = sigma_tensor_blocks(ctx->T.N1, ctx->K);
   DevBuf part;
   if ((rc = part.alloc(sizeof(double) * (size_t)nb)) != 0) return rc;
-  double* A_v = reinterpret_cast<double*>(ctx->ws + ctx->off_Av);
+  double* A_U = reinterpret_cast<double*>(ctx->ws + ctx->off_AU);
   double* B = reinterpret_cast<double*>(ctx->ws + ctx->off_B);
-  rc = launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_v, B, static_cast<double*>(part.p), s);
+  rc = launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, static_cast<double*>(part.p), s);
   if (rc) return fail(ESDG_ERR_NO_DEVICE, "kt_sigma launch: %s", hipGetErrorString((hipError_t)rc));
   std::vector<double> h((size_t)nb);
   HIP_TRY(hipMemcpyAsync(h.data(), part.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));

@@ -346,7 +346,10 @@ __device__ __forceinline__ void face_dto(const int* sInt, int finv_off, int fn, 
 using namespace tdev;
 
 // ---------------------------------------------------------------------------------------------
-// phase 0: entropy projection to the faces -> A_U (rho,u,v,beta,lrho,lbeta,lam,E), A_v (v2..v4)
+// phase 0: entropy projection to the faces -> A_U (rho,u,v,beta,lrho,lbeta,lam,E).
+// The viscous path needs the neighbour's projected entropy variables Vf*VU = Ef*v(u_q) (rhs_viscous! :771-776):
+// they are the entropy variables OF this trace state (u_f = u(Ef v)), so consumers rebuild (v2,v3,v4) =
+// (b u, b v, -b), b = 2 (gamma-1) beta, from the A_U record instead of reading a second trace buffer.
 // ---------------------------------------------------------------------------------------------
 template <int N1, bool MODAL, bool VISC>
 __global__ __launch_bounds__(TW * NWV) void kt_project(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
@@ -401,11 +404,8 @@ __global__ __launch_bounds__(TW * NWV) void kt_project(TensorTables TT, MeshDev 
     a[1] = make_double2(qf[2], qf[3]);
     a[2] = make_double2(qf[4], qf[5]);
     a[3] = make_double2(lam, Uf[3]);
-    if (VISC) {
-      double* bb = A_v + n * AV_NC;
-      bb[0] = Vf[1]; bb[1] = Vf[2]; bb[2] = Vf[3];
-    }
   }
+  (void)A_v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -554,7 +554,7 @@ __device__ __forceinline__ void face_normal_stress(const Lane<N1>& ln, const dou
 // DIAG: also reduce visc_test = sum(wJq .* (VUx .* sigma_x + VUy .* sigma_y)) (rhs_viscous! :802-806) per workgroup
 template <int N1, bool DIAG>
 __global__ __launch_bounds__(TW * NWV) void kt_sigma(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
-                                               const double* __restrict__ A_v, double* __restrict__ B,
+                                               const double* __restrict__ A_U, double* __restrict__ B,
                                                double* __restrict__ vt_partial) {
   constexpr int Nq = N1 * N1, Nfq = 4 * N1, E = TCfg<N1>::E;
   constexpr TensorLayout L(N1);
@@ -577,8 +577,9 @@ __global__ __launch_bounds__(TW * NWV) void kt_sigma(TensorTables TT, MeshDev M,
   issue_state_loads<N1>(Q, M.K, e0, vactive, x);
   double vP[3] = {0, 0, 0};
   if (factive) {
-    const double* vp = A_v + (int64_t)M.mapP[(e0 + ln.ef) * Nfq + ln.fn] * AV_NC;
-    vP[0] = vp[0]; vP[1] = vp[1]; vP[2] = vp[2];
+    const double* up = A_U + (int64_t)M.mapP[(e0 + ln.ef) * Nfq + ln.fn] * FAU_NC;   // (rho,u,v,beta,...)
+    const double b2 = 2 * Gas<true>::GM1 * up[3];
+    vP[0] = b2 * up[1]; vP[1] = b2 * up[2]; vP[2] = -b2;
   }
   double U[4];
   state_at_quad<N1, true>(ln, sTab, sA, sB, x, U);
@@ -720,6 +721,10 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
       qP[1] = qM[1] - 2 * un * nx;
       qP[2] = qM[2] - 2 * un * ny;
     }
+    if (VISC) {   // neighbour's projected entropy variables (v2,v3,v4), rebuilt from its trace record (see kt_project)
+      const double b2 = 2 * Gas<MODAL>::GM1 * qP[3];
+      vPn[0] = b2 * qP[1]; vPn[1] = b2 * qP[2]; vPn[2] = -b2;
+    }
     double Fn[4];
     ec_flux_dir<MODAL>(qM, qP, gn[0], gn[1], Fn);
     const double LFc = ph.inviscid_dissp ? ph.lf_scale * fmax(qM[6], qP[6]) * gn[2] : 0.0;
@@ -817,10 +822,9 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
   if (VISC && (ph.parts & 2) && !(ph.dbg & 2)) {
     __syncthreads();   // sAcc / sG are dead; sR2 becomes the viscous scratch
     if (factive) {   // neighbour traces of the viscous part
-      const double* vp = A_v + mpk * AV_NC;
       const double* bp = B + mpk * B_NC;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { vPn[c] = vp[c]; bPn[c] = bp[c]; }
+      for (int c = 0; c < 3; ++c) bPn[c] = bp[c];
     }
     double* sVn = sQh;                       // [E][3][Nq]  (v2,v3,v4): primitives no longer needed
     double* sDv = sR2;                       // [E][3][Nfq]
@@ -962,15 +966,15 @@ int sigma_tensor_blocks(int N1v, int64_t K) {
 }
 
 int launch_sigma_tensor(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
-                        const double* A_v, double* B, double* vt_partial, hipStream_t s) {
+                        const double* A_U, double* B, double* vt_partial, hipStream_t s) {
   if (M.K == 0) return 0;
   ESDG_DISPATCH_N1(N1v, {
     constexpr int E = TCfg<N1>::E;
     const int nb = (int)((M.K + (int64_t)E * NWV - 1) / ((int64_t)E * NWV));
     if (vt_partial)
-      hipLaunchKernelGGL((kt_sigma<N1, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_v, B, vt_partial);
+      hipLaunchKernelGGL((kt_sigma<N1, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, B, vt_partial);
     else
-      hipLaunchKernelGGL((kt_sigma<N1, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_v, B, vt_partial);
+      hipLaunchKernelGGL((kt_sigma<N1, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, B, vt_partial);
   });
   return (int)hipGetLastError();
 }

@@ -200,10 +200,11 @@ int esdg_viscous_entropy_test(esdg_ctx* ctx, const double* Q_dev, double* visc_t
 int esdg_rhs_host(esdg_ctx* ctx, const double* const* Q, double* const* rhs);  /* esdg_num_fields() pointers each */
 
 /* ---- halo exchange plan (element-index sharding) ---------------------------------------- */
-/* The reference's three x[mapP] gathers (QM/Uf+lam :496-511, VUf :776, sigma_f :813-814) become
- * up to three face-trace exchanges: 0 = A_U (rho,rhou,rhov,E,lam), 1 = A_v (v2..v4), 2 = B (normal
- * viscous stress).  Exchange x is produced (and packed) by phase `after_phase` and must have
- * landed before phase `before_phase` starts, so x=0 can overlap phase 1 of the CNS path. */
+/* The reference's three x[mapP] gathers (QM/Uf+lam :496-511, VUf :776, sigma_f :813-814) become face-trace
+ * exchanges: A_U (entropy-projected face state + lam) and B (normal viscous stress); the tensor kernels rebuild the
+ * neighbour's projected entropy variables VUf[mapP] from its A_U record, the generic kernels exchange them as a
+ * third buffer A_v.  esdg_num_exchanges / esdg_exchange_info enumerate them: exchange x is produced (and packed) by
+ * phase `after_phase` and must have landed before phase `before_phase` starts. */
 int esdg_halo_num_neighbors(const esdg_ctx* ctx);
 int esdg_num_exchanges(const esdg_ctx* ctx);
 int esdg_exchange_info(const esdg_ctx* ctx, int xch, int32_t* after_phase, int32_t* before_phase, int32_t* ncomp);
