@@ -467,7 +467,7 @@ struct esdg_ctx {
   // workspace
   size_t ws_bytes = 0;
   char* ws = nullptr;
-  size_t off_AU = 0, off_Av = 0, off_B = 0;
+  size_t off_AU = 0, off_Av = 0, off_B = 0, off_S = 0;
   static constexpr int NPARTIAL = 1024;
 };
 
@@ -716,6 +716,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   if (visc) {
     if (need_Av) { c->off_Av = off; off = align(off + nodes * AV_NC * sizeof(double)); }
     c->off_B = off; off = align(off + nodes * B_NC * sizeof(double));
+    if (use_fast) { c->off_S = off; off = align(off + (size_t)K * Nq * 6 * sizeof(double)); }   // sigma at the Gauss nodes
   }
   // exchange 0 (A_U): produced by phase 0; needed by the last phase, and already by phase 1 on the tensor CNS path
   Exchange x0{0, (visc && use_fast) ? 1 : c->nphases - 1, c->au_nc, c->off_AU, off};
@@ -887,6 +888,7 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
   const bool need_Av = visc && !ctx->use_fast;
   double* A_v = need_Av ? reinterpret_cast<double*>(ctx->ws + ctx->off_Av) : nullptr;
   double* B = visc ? reinterpret_cast<double*>(ctx->ws + ctx->off_B) : nullptr;
+  double* SG = (visc && ctx->use_fast) ? reinterpret_cast<double*>(ctx->ws + ctx->off_S) : nullptr;
   int rc = 0;
   const int32_t* sl = ctx->d_sendlist.as<int32_t>();
   if (ctx->dim == 3) {
@@ -906,13 +908,13 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
       if (!rc && need_Av) rc = launch_pack(A_v, AV_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[1].send_off), s);
     }
   } else if (visc && phase == 1) {
-    rc = ctx->use_fast ? launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, nullptr, s)
+    rc = ctx->use_fast ? launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, SG, nullptr, s)
                        : launch_sigma(ctx->T, ctx->M, ctx->ph, Q, A_v, B, s);
     if (!rc && ctx->nsend) rc = launch_pack(B, B_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch.back().send_off), s);
   } else {
     if (!rhs && !lf.Qw) return fail(ESDG_ERR_ARG, "rhs output is null");
     if (lf.Qw && !ctx->use_fast) return fail(ESDG_ERR_STATE, "the fused RK update needs the tensor kernels");
-    rc = ctx->use_fast ? launch_rhs_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, A_v, B, rhs, lf, s)
+    rc = ctx->use_fast ? launch_rhs_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s)
                        : launch_rhs(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, B, rhs, s);
   }
   if (rc) return fail(ESDG_ERR_NO_DEVICE, "kernel launch failed in phase %d: %s", phase, hipGetErrorString((hipError_t)rc));
@@ -993,7 +995,8 @@ int esdg_viscous_entropy_test(esdg_ctx* ctx, const double* Q, double* out, void*
   if ((rc = part.alloc(sizeof(double) * (size_t)nb)) != 0) return rc;
   double* A_U = reinterpret_cast<double*>(ctx->ws + ctx->off_AU);
   double* B = reinterpret_cast<double*>(ctx->ws + ctx->off_B);
-  rc = launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, static_cast<double*>(part.p), s);
+  rc = launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, reinterpret_cast<double*>(ctx->ws + ctx->off_S),
+                           static_cast<double*>(part.p), s);
   if (rc) return fail(ESDG_ERR_NO_DEVICE, "kt_sigma launch: %s", hipGetErrorString((hipError_t)rc));
   std::vector<double> h((size_t)nb);
   HIP_TRY(hipMemcpyAsync(h.data(), part.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));

@@ -49,11 +49,11 @@ struct Phys;
 int launch_project_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
                           double* A_U, double* A_v, hipStream_t s);
 int launch_sigma_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
-                        const double* A_U, double* B, double* visc_test_partial, hipStream_t s);
+                        const double* A_U, double* B, double* SG, double* visc_test_partial, hipStream_t s);
 int sigma_tensor_blocks(int N1, int64_t K);
 struct LsrkFuse;
 int launch_rhs_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
-                      const double* A_U, const double* A_v, const double* B, double* rhs, const LsrkFuse& lf,
+                      const double* A_U, const double* SG, const double* B, double* rhs, const LsrkFuse& lf,
                       hipStream_t s);
 
 struct MeshDev {

@@ -456,7 +456,7 @@ __device__ __forceinline__ void visc_face_jumps(const Lane<N1>& ln, const double
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     dV[c] = vP[c] - vf[c];
-    sDv[(ln.ef * 3 + c) * Nfq + ln.fn] = .5 * dV[c];
+    if (sDv) sDv[(ln.ef * 3 + c) * Nfq + ln.fn] = .5 * dV[c];
   }
   if (pn_out) {
     const double iv4 = rcp_refined(vf[2]);
@@ -555,7 +555,7 @@ __device__ __forceinline__ void face_normal_stress(const Lane<N1>& ln, const dou
 template <int N1, bool DIAG>
 __global__ __launch_bounds__(TW * NWV) void kt_sigma(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                const double* __restrict__ A_U, double* __restrict__ B,
-                                               double* __restrict__ vt_partial) {
+                                               double* __restrict__ SG, double* __restrict__ vt_partial) {
   constexpr int Nq = N1 * N1, Nfq = 4 * N1, E = TCfg<N1>::E;
   constexpr TensorLayout L(N1);
   __shared__ double sTab[L.NDBL];
@@ -607,6 +607,11 @@ __global__ __launch_bounds__(TW * NWV) void kt_sigma(TensorTables TT, MeshDev M,
     r[0] = make_double2(sgx[0], sgx[1]);
     r[1] = make_double2(sgx[2], sgy[0]);
     r[2] = make_double2(sgy[1], sgy[2]);
+    if (vactive) {   // sigma at the Gauss nodes, kept for the divergence in the last phase: SG[6][K][Nq], coalesced
+      const int64_t n = e0 * Nq + ln.tid, KN = M.K * Nq;
+      SG[n] = sgx[0]; SG[KN + n] = sgx[1]; SG[2 * KN + n] = sgx[2];
+      SG[3 * KN + n] = sgy[0]; SG[4 * KN + n] = sgy[1]; SG[5 * KN + n] = sgy[2];
+    }
     if (DIAG && vactive)
       vt = M.wJq[(e0 + ln.ev) * Nq + ln.q] * (gx[0] * sgx[0] + gx[1] * sgx[1] + gx[2] * sgx[2] + gy[0] * sgy[0] + gy[1] * sgy[1] + gy[2] * sgy[2]);
   }
@@ -639,14 +644,15 @@ struct RhsLds {
   static constexpr int Nq = N1 * N1, Nfq = 4 * N1, Nh = Nq + Nfq, E = TCfg<N1>::E;
   static constexpr int nQh = E * Nh * 6;                 // prims+logs of all hybrid nodes; also interp scratch
   static constexpr int nFlux = E * (4 * Nq + 4 * Nfq);   // sAcc + sG
-  static constexpr int nVisc = VISC ? E * (6 * Nfq + 6 * Nq) : 0;  // sDv(3) + sSj(3) per face node, sS(6) per node
+  static constexpr int nVisc = VISC ? E * 3 * Nfq : 0;   // sSj(3) per face node (sVn and sS live in the sQh region)
+  static_assert(!VISC || 9 * Nq <= 6 * Nh, "sVn + sS must fit in the sQh region");
   static constexpr int nR2 = nFlux > nVisc ? nFlux : nVisc;
   static_assert(8 * Nq <= 6 * Nh, "interp scratch must fit in the sQh region");
 };
 
 template <int N1, bool MODAL, bool VISC, bool WALLS>
 __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, Phys ph, const double* Q,
-                                             const double* __restrict__ A_U, const double* __restrict__ A_v,
+                                             const double* __restrict__ A_U, const double* __restrict__ SG,
                                              const double* __restrict__ B, double* rhs, LsrkFuse lf) {
   using LD = RhsLds<N1, VISC>;
   constexpr int Nq = LD::Nq, Nfq = LD::Nfq, Nh = LD::Nh, E = LD::E, NF = N1 / 2;
@@ -826,31 +832,34 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
 #pragma unroll
       for (int c = 0; c < 3; ++c) bPn[c] = bp[c];
     }
+    // sigma = K(v) grad v at the Gauss nodes was computed (and its face traces exchanged) by phase 1: reload it
+    // instead of recomputing gradient and stress (HBM has headroom here, the LDS does not)
     double* sVn = sQh;                       // [E][3][Nq]  (v2,v3,v4): primitives no longer needed
-    double* sDv = sR2;                       // [E][3][Nfq]
-    double* sSj = sDv + E * 3 * Nfq;         // [E][3][Nfq]  stress jump (+ J * penalty, see below)
-    double* sS = sSj + E * 3 * Nfq;          // [E][Nq][6]
-    if (ln.vin) {
+    double* sSj = sR2;                       // [E][3][Nfq]  stress jump (+ J * penalty, see below)
+    double* sS = sQh + E * 3 * Nq;           // [E][Nq][6]   behind sVn in the dead primitive region
+    double2 sg0 = make_double2(0, 0), sg1 = sg0, sg2 = sg0;
+    if (vactive) {
+      const int64_t n = e0 * Nq + ln.tid, KN = M.K * Nq;
+      sg0 = make_double2(SG[n], SG[KN + n]);
+      sg1 = make_double2(SG[2 * KN + n], SG[3 * KN + n]);
+      sg2 = make_double2(SG[4 * KN + n], SG[5 * KN + n]);
+    }
+    const bool pen = ph.viscous_dissp != 0;
+    if (ln.vin && pen) {
       double V[4];
       v_of_prim<MODAL>(qh, V);
 #pragma unroll
       for (int c = 0; c < 3; ++c) sVn[(ln.ev * 3 + c) * Nq + ln.q] = V[c + 1];
     }
-    __syncthreads();
-    double pnr[3] = {0, 0, 0};               // penalty tau*[[v]] of this face node (:817-837)
-    if (ln.fin)
-      visc_face_jumps<N1>(ln, sTab, sInt, sVn, vPn, bcf, M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1),
-                          ph, sDv, pnr);
-    __syncthreads();
     if (ln.vin) {
-      double sgx[3], sgy[3];
-      visc_sigma<N1>(ln, sTab, sInt, TT, ph, g, sVn, sDv, sgx, sgy);
       double2* r = reinterpret_cast<double2*>(sS + (ln.ev * Nq + ln.q) * 6);
-      r[0] = make_double2(sgx[0], sgx[1]);
-      r[1] = make_double2(sgx[2], sgy[0]);
-      r[2] = make_double2(sgy[1], sgy[2]);
+      r[0] = sg0; r[1] = sg1; r[2] = sg2;
     }
     __syncthreads();
+    double pnr[3] = {0, 0, 0};               // penalty tau*[[v]] of this face node (:817-837)
+    if (ln.fin && pen)
+      visc_face_jumps<N1>(ln, sTab, sInt, sVn, vPn, bcf, M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1),
+                          ph, nullptr, pnr);
     // stress jumps .5*((sxP-sxf)*nxJ + (syP-syf)*nyJ): the neighbour's normal stress from B carries
     // its own outward normal = minus ours (dg_div! :606)
     if (ln.fin) {
@@ -966,21 +975,21 @@ int sigma_tensor_blocks(int N1v, int64_t K) {
 }
 
 int launch_sigma_tensor(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
-                        const double* A_U, double* B, double* vt_partial, hipStream_t s) {
+                        const double* A_U, double* B, double* SG, double* vt_partial, hipStream_t s) {
   if (M.K == 0) return 0;
   ESDG_DISPATCH_N1(N1v, {
     constexpr int E = TCfg<N1>::E;
     const int nb = (int)((M.K + (int64_t)E * NWV - 1) / ((int64_t)E * NWV));
     if (vt_partial)
-      hipLaunchKernelGGL((kt_sigma<N1, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, B, vt_partial);
+      hipLaunchKernelGGL((kt_sigma<N1, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, B, SG, vt_partial);
     else
-      hipLaunchKernelGGL((kt_sigma<N1, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, B, vt_partial);
+      hipLaunchKernelGGL((kt_sigma<N1, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, B, SG, vt_partial);
   });
   return (int)hipGetLastError();
 }
 
 int launch_rhs_tensor(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
-                      const double* A_U, const double* A_v, const double* B, double* rhs, const LsrkFuse& lf,
+                      const double* A_U, const double* SG, const double* B, double* rhs, const LsrkFuse& lf,
                       hipStream_t s) {
   if (M.K == 0) return 0;
   const bool modal = ph.formulation != 0, visc = ph.formulation == 1;
@@ -989,15 +998,15 @@ int launch_rhs_tensor(int N1v, const TensorTables& TT, const MeshDev& M, const P
     const int nb = (int)((M.K + (int64_t)E * NWV - 1) / ((int64_t)E * NWV));
     const bool walls = M.bc != nullptr;
     if (!modal)
-      hipLaunchKernelGGL((kt_rhs<N1, false, false, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs, lf);
+      hipLaunchKernelGGL((kt_rhs<N1, false, false, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
     else if (visc && walls)
-      hipLaunchKernelGGL((kt_rhs<N1, true, true, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs, lf);
+      hipLaunchKernelGGL((kt_rhs<N1, true, true, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
     else if (visc)
-      hipLaunchKernelGGL((kt_rhs<N1, true, true, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs, lf);
+      hipLaunchKernelGGL((kt_rhs<N1, true, true, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
     else if (walls)
-      hipLaunchKernelGGL((kt_rhs<N1, true, false, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs, lf);
+      hipLaunchKernelGGL((kt_rhs<N1, true, false, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
     else
-      hipLaunchKernelGGL((kt_rhs<N1, true, false, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v, B, rhs, lf);
+      hipLaunchKernelGGL((kt_rhs<N1, true, false, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
   });
   return (int)hipGetLastError();
 }
