@@ -41,7 +41,8 @@ class esdg_hex_mesh_t(C.Structure):
 class esdg_phys_t(C.Structure):
     _fields_ = [("formulation", C.c_int32), ("lf_scale", C.c_double), ("inviscid_dissp", C.c_int32),
                 ("viscous_dissp", C.c_int32), ("BCTYPE", C.c_int32), ("Re", C.c_double), ("mu", C.c_double),
-                ("lambda_", C.c_double), ("Pr", C.c_double)]
+                ("lambda_", C.c_double), ("Pr", C.c_double),
+                ("inflow_rho", C.c_double), ("inflow_u", C.c_double), ("inflow_v", C.c_double), ("inflow_p", C.c_double)]
 
 
 # every symbol include/esdg_hip.h declares: (restype, argtypes)

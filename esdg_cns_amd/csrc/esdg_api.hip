@@ -501,7 +501,11 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
       !mesh->sJ || !mesh->mapP)
     return fail(ESDG_ERR_ARG, "mesh arrays missing");
   if (mesh->NmapB > 0 && !mesh->mapB) return fail(ESDG_ERR_ARG, "NmapB>0 but mapB is null");
-  if (mesh->NmapB > 0 && (phys->BCTYPE < 1 || phys->BCTYPE > 3)) return fail(ESDG_ERR_ARG, "BCTYPE must be 1, 2 or 3 with wall boundaries");
+  if (mesh->NmapB > 0 && (phys->BCTYPE < 1 || phys->BCTYPE > 4)) return fail(ESDG_ERR_ARG, "BCTYPE must be 1..4 with boundary nodes");
+  if (mesh->NmapB > 0 && phys->BCTYPE == 4) {
+    if (phys->viscous_dissp) return fail(ESDG_ERR_ARG, "BCTYPE 4 (shock-tube closures) has no penalty term: viscous_dissp must be 0");
+    if (!(phys->inflow_rho > 0) || !(phys->inflow_p > 0)) return fail(ESDG_ERR_ARG, "BCTYPE 4 needs a positive inflow density and pressure");
+  }
   if ((int64_t)mesh->K * Nfq > (int64_t)2000000000) return fail(ESDG_ERR_ARG, "too many local face nodes for int32 maps");
   if (esdg_device_count() < 1) return fail(ESDG_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
 
@@ -518,6 +522,19 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   c->ph.viscous_dissp = phys->viscous_dissp;
   c->ph.BCTYPE = phys->BCTYPE;
   c->ph.Re = phys->Re; c->ph.mu = phys->mu; c->ph.lambda = phys->lambda; c->ph.Pr = phys->Pr;
+  for (double& x : c->ph.inflow_q) x = 1.0;
+  for (double& x : c->ph.inflow_vv) x = 0.0;
+  if (phys->BCTYPE == 4 && mesh->NmapB > 0) {   // Dirichlet state and VL = v_ufun(rhoL, rhoL uL, rhoL vL, EL) (modalESDG.jl:187-188)
+    const double g = 1.4, rho = phys->inflow_rho, u = phys->inflow_u, v = phys->inflow_v, p = phys->inflow_p;
+    const double beta = rho / (2 * p);
+    const double q[6] = {rho, u, v, beta, std::log(rho), std::log(beta)};
+    for (int i = 0; i < 6; ++i) c->ph.inflow_q[i] = q[i];
+    const double E = p / (g - 1) + .5 * rho * (u * u + v * v);
+    const double rhoe = E - .5 * (rho * u * rho * u + rho * v * rho * v) / rho;
+    c->ph.inflow_vv[0] = rho * u / rhoe;
+    c->ph.inflow_vv[1] = rho * v / rhoe;
+    c->ph.inflow_vv[2] = -rho / rhoe;
+  }
   c->nphases = visc ? 3 : 2;
   c->ph.parts = 3;
   c->ph.dbg = 0;
@@ -669,6 +686,10 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
     for (int64_t i = 0; i < mesh->NmapB; ++i) {
       const int64_t l = mesh->mapB[i] - 1 - mesh->elem_offset * Nfq;
       if (l < 0 || l >= K * Nfq) continue;   // boundary node of another rank
+      if (phys->BCTYPE == 4) {   // 3 = Dirichlet inflow, 4 = copy; mapP may hold the periodic partner
+        bcflag[l] = (uint8_t)((mesh->bkind && mesh->bkind[i] != 0) ? 3 : 4);
+        continue;
+      }
       if (mapP[l] != l) return fail(ESDG_ERR_ARG, "mapB[%lld] is not a boundary node (mapP != mapM)", (long long)i);
       bcflag[l] = (uint8_t)(1 + (mesh->bkind ? (mesh->bkind[i] != 0) : 0));
     }

@@ -60,7 +60,7 @@ struct MeshDev {
   int64_t K;               // local elements
   const double* geo;       // [K][GEO_STRIDE]
   const int32_t* mapP;     // [K][Nfq]  local face-node index, or ghost slot >= K*Nfq
-  const uint8_t* bc;       // [K][Nfq]  0 interior/periodic, 1 wall, 2 lid; may be null (no walls)
+  const uint8_t* bc;       // [K][Nfq]  0 interior/periodic, 1 wall, 2 lid, 3 Dirichlet inflow, 4 copy; may be null
   const double* wJq;       // [K][Nq] (diagnostics) may be null
   unsigned long long* stamps;  // diagnostic builds only (ESDG_DBG & 8): [4096][16] s_memtime deltas
 };
@@ -79,6 +79,8 @@ struct Phys {
   int inviscid_dissp, viscous_dissp, BCTYPE;
   double Re, mu, lambda, Pr;
   int dbg;  // timing-ablation mask from ESDG_DBG (diagnostic builds only; 0 in normal use)
+  double inflow_q[6];   // BCTYPE 4: Dirichlet state as a trace record (rho,u,v,beta,log rho,log beta)
+  double inflow_vv[3];  //           and its entropy variables (v2,v3,v4) = v_ufun(...)[2:4]
   int parts;  // bit 0: inviscid terms (rhs_inviscid!), bit 1: viscous terms (rhs_viscous!); 3 = rhsRK!
 };
 

@@ -432,7 +432,10 @@ __device__ __forceinline__ void visc_face_jumps(const Lane<N1>& ln, const double
     vf[2] += w * r[2 * Nq];
   }
   double vP[3] = {vPin[0], vPin[1], vPin[2]};
-  if (bc) {
+  if (bc >= 3) {                                          // shock-tube closures, dg2D_CNS_modalESDG.jl:187-203
+#pragma unroll
+    for (int c = 0; c < 3; ++c) vP[c] = bc == 3 ? ph.inflow_vv[c] : vf[c];
+  } else if (bc) {
     const double vlid = 1.0;                              // cavity :148
     if (ph.BCTYPE == 1) {                                 // adiabatic no-slip
       vP[0] = bc == 2 ? -vf[0] - 2 * vlid * vf[2] : -vf[0];
@@ -718,7 +721,11 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     dq[1] = make_double2(qM[2], qM[3]);
     dq[2] = make_double2(qM[4], qM[5]);
     const double* gn = M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
-    if (bcf) {   // wall: mirror state rho+ = rho, beta+ = beta, u+ = u - 2 (u.n) n  (impose_BCs_inviscid! :157-176)
+    if (bcf >= 3) {   // shock-tube closures (dg2D_CNS_modalESDG.jl:168-185): Dirichlet state / copy, lam = lamP = 0
+#pragma unroll
+      for (int c = 0; c < 6; ++c) qP[c] = bcf == 3 ? ph.inflow_q[c] : qM[c];
+      qM[6] = 0.0; qP[6] = 0.0;
+    } else if (bcf) {   // wall: mirror state rho+ = rho, beta+ = beta, u+ = u - 2 (u.n) n  (impose_BCs_inviscid! :157-176)
       const double is = rcp_refined(gn[2]);
       const double nx = gn[0] * is, ny = gn[1] * is;
       const double un = qM[1] * nx + qM[2] * ny;
@@ -868,7 +875,9 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
       face_normal_stress<N1>(ln, sTab, sInt, sS, gn[0], gn[1], sn, fx, fy);
 #pragma unroll
       for (int c = 0; c < 3; ++c) sj[c] = .5 * (-bPn[c] - sn[c]);
-      if (bcf) {   // impose_BCs_stress! :218-262
+      if (bcf >= 3) {   // sigma+ = sigma- (dg2D_CNS_modalESDG.jl:205-216)
+        sj[0] = 0.0; sj[1] = 0.0; sj[2] = 0.0;
+      } else if (bcf) {   // impose_BCs_stress! :218-262
         if (ph.BCTYPE == 1) {
           sj[0] = 0.0; sj[1] = 0.0;
           sj[2] = bcf == 2 ? -sn[2] + 1.0 * sn[0] : -sn[2];

@@ -75,7 +75,8 @@ class RhsEngine:
     """One esdg_ctx: operators + (local shard of the) mesh resident on one MI355X."""
 
     def __init__(self, rd, md, ops, formulation, lf_scale=None, inviscid_dissp=True, viscous_dissp=True, BCTYPE=1,
-                 Re=1000.0, mu=None, lam=None, Pr=.71, device=None, rank=0, nranks=1, rank_offsets=None, group=None):
+                 Re=1000.0, mu=None, lam=None, Pr=.71, device=None, rank=0, nranks=1, rank_offsets=None, group=None,
+                 inflow=None, inflow_nodes=None):
         L = _lib.lib()
         if not torch.cuda.is_available() or L.esdg_device_count() < 1:
             raise _lib.EsdgError("no MI355X/HIP device visible: the RHS engine has no CPU path")
@@ -88,7 +89,7 @@ class RhsEngine:
             ctx = self._create_hex(L, rd, md, ops, 0.0 if lf_scale is None else lf_scale, rank, nranks, rank_offsets)
         else:
             ctx = self._create_2d(L, rd, md, ops, formulation, lf_scale, inviscid_dissp, viscous_dissp, BCTYPE, Re, mu, lam, Pr,
-                                  rank, nranks, rank_offsets)
+                                  rank, nranks, rank_offsets, inflow, inflow_nodes)
         self.ctx = ctx
         self.L = L
         self.nphases = L.esdg_num_phases(ctx)
@@ -150,7 +151,7 @@ class RhsEngine:
         return ctx
 
     def _create_2d(self, L, rd, md, ops, formulation, lf_scale, inviscid_dissp, viscous_dissp, BCTYPE, Re, mu, lam, Pr,
-                   rank, nranks, rank_offsets):
+                   rank, nranks, rank_offsets, inflow=None, inflow_nodes=None):
         keep = self._keep
         modal = formulation != EULER_COLLOCATED
         Nq, Nfq = rd.wq.size, rd.wf.size
@@ -179,7 +180,26 @@ class RhsEngine:
         keep["mapP"] = np.asfortranarray(np.asarray(md.mapP, dtype=np.int64))
         m.mapP = keep["mapP"].ctypes.data_as(_lib.c_int64_p)
         mapB = np.asarray(getattr(md, "mapB", np.zeros(0)), dtype=np.int64)
-        if mapB.size:
+        if BCTYPE == 4:
+            # closures of the shock-tube driver (dg2D_CNS_modalESDG.jl:161-217): md.mapB = the x-side boundary nodes
+            # (they may carry periodic partners in mapP); Dirichlet inflow on `inflow_nodes` (default: the x-min side)
+            if inflow is None:
+                raise ValueError("BCTYPE 4 needs inflow=(rho, u, v, p)")
+            keep["mapB"] = np.ascontiguousarray(mapB)
+            loc = mapB - 1 - int(getattr(md, "elem_offset", 0)) * Nfq
+            inside = (loc >= 0) & (loc < md.K * Nfq)
+            if inflow_nodes is None:
+                xb = np.full(mapB.size, np.inf)
+                xb[inside] = md.xf.flatten(order="F")[loc[inside]]
+                kinds = np.abs(xb - md.VX.min()) < 1e-12
+            else:
+                kinds = np.isin(mapB, np.asarray(inflow_nodes, dtype=np.int64))
+            keep["bkind"] = np.ascontiguousarray(kinds.astype(np.uint8))
+            m.mapB = keep["mapB"].ctypes.data_as(_lib.c_int64_p)
+            m.NmapB = int(mapB.size)
+            m.bkind = keep["bkind"].ctypes.data_as(_lib.c_uint8_p)
+            mapB = np.zeros(0, dtype=np.int64)
+        elif mapB.size:
             # md.mapB survives the periodic patch of the drivers (mapP[mapB] = mapPB); only nodes that still map to
             # themselves are walls
             locB = mapB - 1 - int(getattr(md, "elem_offset", 0)) * Nfq
@@ -198,7 +218,7 @@ class RhsEngine:
             m.mapB = keep["mapB"].ctypes.data_as(_lib.c_int64_p)
             m.NmapB = int(mapB.size)
             m.bkind = keep["bkind"].ctypes.data_as(_lib.c_uint8_p)
-        else:
+        elif BCTYPE != 4:
             m.mapB, m.NmapB, m.bkind = None, 0, None
         m.elem_offset = int(getattr(md, "elem_offset", 0))
         m.Kglobal = int(getattr(md, "Kglobal", md.K))
@@ -214,6 +234,8 @@ class RhsEngine:
         mu = 1.0 / Re if mu is None else mu
         lam = -2.0 / 3.0 * mu if lam is None else lam
         p.Re, p.mu, p.lambda_, p.Pr = float(Re), float(mu), float(lam), float(Pr)
+        if inflow is not None:
+            p.inflow_rho, p.inflow_u, p.inflow_v, p.inflow_p = (float(x) for x in inflow)
 
         ctx = C.c_void_p()
         check(L.esdg_create(C.byref(o), C.byref(m), C.byref(p), C.byref(ctx)))

@@ -97,7 +97,9 @@ typedef struct {
                           * walls: mirror state for the inviscid flux, BCTYPE-dependent entropy-variable and
                           * stress traces, boundary penalty (init_BC_funs, cavity_optimized.jl:135-265, 827-837) */
   int64_t NmapB;
-  const uint8_t* bkind;  /* per mapB entry: 0 = wall, 1 = lid (init_BC_funs :139-148); NULL = all wall */
+  const uint8_t* bkind;  /* per mapB entry: 0 = wall, 1 = lid (init_BC_funs :139-148); NULL = all wall.
+                          * BCTYPE 4: 0 = copy ("rightwall"), 1 = Dirichlet inflow ("leftwall"); the listed nodes may
+                          * carry a periodic partner in mapP (the driver patches mapP first, modalESDG.jl:72-78) */
   /* element-index sharding.  Single process: elem_offset=0, Kglobal=K, nranks=1. */
   int64_t elem_offset;   /* global index (0-based) of the first local element */
   int64_t Kglobal;
@@ -110,8 +112,12 @@ typedef struct {
   double lf_scale;         /* .5 (euler_quad.jl:165) or .25 (cavity_optimized.jl:508); 0 disables LF */
   int32_t inviscid_dissp;  /* cavity_optimized.jl:29 */
   int32_t viscous_dissp;   /* cavity_optimized.jl:30 */
-  int32_t BCTYPE;          /* 1 adiabatic no-slip, 2 isothermal, 3 slip (cavity_optimized.jl:26) */
+  int32_t BCTYPE;          /* 1 adiabatic no-slip, 2 isothermal, 3 slip (cavity_optimized.jl:26);
+                            * 4 = inflow/outflow closures of the shock-tube driver (dg2D_CNS_modalESDG.jl:161-217):
+                            *     bkind 1 = Dirichlet state `inflow_*`, bkind 0 = copy of the interior trace, lam = 0 and
+                            *     sigma+ = sigma- on both; that driver has no penalty, so viscous_dissp must be 0 */
   double Re, mu, lambda, Pr; /* cavity_optimized.jl:33-36; lambda as passed to init_visc_fxn (:646) */
+  double inflow_rho, inflow_u, inflow_v, inflow_p; /* BCTYPE 4: (rhoL, uL, vL, pL), dg2D_CNS_modalESDG.jl:50-57 */
 } esdg_phys_t;
 
 /* Hexahedral path: operators of examples/dg3D_euler_hex.jl:34-98 (quadrature basis) and the 3D MeshData

@@ -36,7 +36,7 @@ class _CnsT(C.Structure):
                                       "rxJ", "sxJ", "ryJ", "syJ", "J", "wJq", "nxJ", "nyJ", "sJ")]
                 + [("mapP", _lp), ("Nb", C.c_int), ("mapB", _lp), ("bkind", _ip), ("BCTYPE", C.c_int),
                    ("Re", C.c_double), ("lambda_", C.c_double), ("mu", C.c_double), ("Pr", C.c_double),
-                   ("inviscid_dissp", C.c_int), ("viscous_dissp", C.c_int)])
+                   ("inviscid_dissp", C.c_int), ("viscous_dissp", C.c_int), ("inflow", C.c_double * 4)])
 
 
 class _HexT(C.Structure):
@@ -180,29 +180,76 @@ def build_euler_problem(N, Kx, Ky):
     return p
 
 
+def becker_constants():
+    """Constants of the Becker viscous shock tube, examples/CompressibleNS/dg2D_CNS_modalESDG.jl:31-61."""
+    g, M_0, mu = 1.4, 3.0, 0.01
+    v_inf, m_0, v_0 = 0.2, 1.0, 1.0
+    v_1 = (g - 1 + 2 / M_0 ** 2) / (g + 1)
+    v_01 = np.sqrt(v_0 * v_1)
+    uL, uR = v_0 + v_inf, v_1 + v_inf
+    rhoL, rhoR = m_0 / v_0, m_0 / v_1
+    eL = 1 / (2 * g) * ((g + 1) / (g - 1) * v_01 ** 2 - v_0 ** 2)
+    eR = 1 / (2 * g) * ((g + 1) / (g - 1) * v_01 ** 2 - v_1 ** 2)
+    return dict(mu=mu, lam=2 / 3 * mu, Pr=3 / 4, rhoL=rhoL, rhoR=rhoR, uL=uL, uR=uR, vL=0.0, vR=0.0,
+                pL=(g - 1) * rhoL * eL, pR=(g - 1) * rhoR * eR)
+
+
+def shocktube_state(x, y):
+    """Smooth surrogate of the Becker profile between the left and right states (tanh ramp around x = 0.25) with a
+    small y-periodic perturbation so that every term of the RHS is exercised."""
+    st = becker_constants()
+    s = .5 * (1 + np.tanh((x - .25) / .2))
+    wob = 1 + .02 * np.sin(2 * np.pi * y) * np.exp(-20 * (x - .3) ** 2)
+    rho = (st["rhoL"] + (st["rhoR"] - st["rhoL"]) * s) * wob
+    u = st["uL"] + (st["uR"] - st["uL"]) * s
+    v = .03 * np.cos(2 * np.pi * y) * np.exp(-20 * (x - .3) ** 2)
+    p = st["pL"] + (st["pR"] - st["pL"]) * s
+    return rho, u, v, p
+
+
 def build_cns_problem(N, Kx, Ky, bc="periodic", BCTYPE=1, Re=1000.0, Pr=.71):
     """Modal-ESDG CNS set-up of examples/CompressibleNS/dg2D_CNS_cavity_optimized.jl:21-90 fed
     with the reference *quad* element (SURVEY.md section 8 config mapping).
       bc="periodic": vortex box [0,15]x[-5,5], mapB emptied after the periodic patch;
-      bc="cavity"  : [-1,1]^2 lid-driven cavity walls with BCTYPE 1/2/3."""
+      bc="cavity"  : [-1,1]^2 lid-driven cavity walls with BCTYPE 1/2/3;
+      bc="shocktube": the set-up of examples/CompressibleNS/dg2D_CNS_modalESDG.jl:62-78 on quads: [-0.5,1]x[0,1],
+                     periodic patch on all sides, md.mapB kept (inflow at x=-0.5, copy at x=1), BCTYPE 4,
+                     mu=0.01, lambda=+2/3 mu, Pr=3/4, no penalty."""
     p = Problem()
     VX, VY, EToV = rs.uniform_quad_mesh(Kx, Ky)
     if bc == "periodic":
         VX = 15 * (1 + VX) / 2
         VY = 5 * VY
+    if bc == "shocktube":
+        VX = VX / 4 * 3 + 1 / 4                                    # dg2D_CNS_modalESDG.jl:63-65
+        VY = (VY + 1) / 2
     rd = rs.init_reference_quad(N)
     md = rs.init_mesh_2D(VX, VY, EToV, rd)
     if bc == "periodic":
         rs.make_periodic_2D(md, rd, VX, VY)
         md.mapB = np.zeros(0, dtype=np.int64)
+    if bc == "shocktube":
+        mapB = md.mapB.copy()
+        rs.make_periodic_2D(md, rd, VX, VY)                        # :72-78, md.mapB still lists all four sides
+        xb = rs.vec(md.xf)[mapB - 1]
+        keep = (np.abs(xb + .5) < 1e-12) | (np.abs(xb - 1.0) < 1e-12)   # leftwall / rightwall, :165-166
+        md.mapB = mapB[keep]
+        BCTYPE = 4
     ops = rs.cns_ops(rd)
     for n in ("rxJ", "sxJ", "ryJ", "syJ"):                       # :85-87
         setattr(md, n, np.asfortranarray(ops["Vh"] @ getattr(md, n)))
     p.mu = 1 / Re
     p.lam = -2 / 3 * p.mu                                          # :33-36
+    p.inflow = (0.0, 0.0, 0.0, 0.0)
+    if bc == "shocktube":
+        st = becker_constants()
+        p.mu, p.lam, Pr = st["mu"], st["lam"], st["Pr"]
+        p.inflow = (st["rhoL"], st["uL"], st["vL"], st["pL"])
     p.Re, p.Pr, p.BCTYPE, p.bc = Re, Pr, BCTYPE, bc
     if bc == "periodic":
         rho, u, v, pr = ph.vortex(md.x, md.y, 0)
+    elif bc == "shocktube":
+        rho, u, v, pr = shocktube_state(md.x, md.y)
     else:                                                          # smooth non-trivial cavity state
         x, y = md.x, md.y
         rho = 1.0 + .2 * np.exp(-10 * (x ** 2 + y ** 2))
@@ -294,6 +341,9 @@ class CnsOracle:
         yb = md.yf.flatten(order="F")[mapB - 1] if mapB.size else np.zeros(0)
         self.mapB = np.ascontiguousarray(mapB)
         self.bkind = np.ascontiguousarray((np.abs(yb - 1) < 1e-12).astype(np.int32))   # lid test, :139
+        if int(p.BCTYPE) == 4:                                                           # inflow = the x = xmin side
+            xb = md.xf.flatten(order="F")[mapB - 1]
+            self.bkind = np.ascontiguousarray((np.abs(xb - md.xf.min()) < 1e-12).astype(np.int32))
         t = _CnsT()
         t.K, t.Np, t.Nq, t.Nfq = md.K, self.Np, rd.Vq.shape[0], rd.Vf.shape[0]
         for k, v in self.keep.items():
@@ -305,6 +355,8 @@ class CnsOracle:
         t.BCTYPE = int(p.BCTYPE)
         t.Re, t.lambda_, t.mu, t.Pr = float(p.Re), float(p.lam), float(p.mu), float(p.Pr)
         t.inviscid_dissp, t.viscous_dissp = int(inviscid_dissp), int(viscous_dissp)
+        for i in range(4):
+            t.inflow[i] = float(getattr(p, "inflow", (0, 0, 0, 0))[i])
         self.t = t
 
     def rhs_inviscid(self, Q):

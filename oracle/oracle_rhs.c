@@ -283,6 +283,9 @@ typedef struct {
   /* physics */
   double Re, lambda, mu, Pr;
   int inviscid_dissp, viscous_dissp;
+  /* BCTYPE 4 = the boundary closures of the shock-tube driver (dg2D_CNS_modalESDG.jl:161-217): bkind 1 = Dirichlet
+   * inflow with the state (rho,u,v,p) below, bkind 0 = copy of the interior value; lam = lamP = 0 on both; no penalty */
+  double inflow[4];
 } oracle_cns_t;
 
 /* dg2D_CNS_cavity_optimized.jl:461-467: hard-coded gamma literals (quirk Q5) */
@@ -336,9 +339,22 @@ void oracle_cns_rhs_inviscid(const oracle_cns_t* c, const double* Q, double* rhs
       size_t op = (p / Nfq) * Nh + Nq + (p % Nfq);
       for (int f = 0; f < 4; ++f) QP[f * KNf + n] = Qh[f * KNh + op];
     }
+  unsigned char* nolf = (unsigned char*)calloc(KNf, 1); /* impose_BCs_lam! (modalESDG :180-185): lam = lamP = 0 */
   for (int b = 0; b < c->Nb; ++b) {
     size_t n = (size_t)(c->mapB[b] - 1);
     size_t om = (n / Nfq) * Nh + Nq + (n % Nfq);
+    if (c->BCTYPE == 4) { /* impose_BCs_inviscid!, dg2D_CNS_modalESDG.jl:168-178 */
+      nolf[n] = 1;
+      if (c->bkind[b]) {
+        QP[n] = c->inflow[0];
+        QP[KNf + n] = c->inflow[1];
+        QP[2 * KNf + n] = c->inflow[2];
+        QP[3 * KNf + n] = c->inflow[0] / (2 * c->inflow[3]);
+      } else {
+        for (int f = 0; f < 4; ++f) QP[f * KNf + n] = Qh[f * KNh + om];
+      }
+      continue;
+    }
     double nx = c->nxJ[n] / c->sJ[n], ny = c->nyJ[n] / c->sJ[n];
     double u1 = Qh[KNh + om], u2 = Qh[2 * KNh + om];
     double Un = u1 * nx + u2 * ny;
@@ -367,7 +383,7 @@ void oracle_cns_rhs_inviscid(const oracle_cns_t* c, const double* Q, double* rhs
       double lM[2] = {log(QMl[0]), log(QMl[3])}, lP[2] = {log(QPl[0]), log(QPl[3])};
       double Fx[4], Fy[4];
       oracle_euler_fluxes_2d(QPl, QMl, lP, lM, Fx, Fy); /* (QP,QM) order, quirk Q8 */
-      double LFc = .25 * fmax(lam[n], lam[p]) * c->sJ[n];
+      double LFc = nolf[n] ? 0.0 : .25 * fmax(lam[n], lam[p]) * c->sJ[n];
       for (int f = 0; f < 4; ++f) {
         double v = Fx[f] * c->nxJ[n] + Fy[f] * c->nyJ[n];
         if (c->inviscid_dissp) v -= LFc * (Uh[f * KNh + op] - Uh[f * KNh + om]);
@@ -401,7 +417,7 @@ void oracle_cns_rhs_inviscid(const oracle_cns_t* c, const double* Q, double* rhs
     matmul_elems(c->Ph, Np, Nh, QF + f * KNh, tmpN + f * KNp, K);
     for (size_t n = 0; n < KNp; ++n) rhs[f * KNp + n] = -(tmpN[f * KNp + n] + rhs[f * KNp + n]) / c->J[n];
   }
-  free(Qq); free(VU); free(Uh); free(Qh); free(QP); free(lam); free(flux); free(QF); free(tmpN);
+  free(Qq); free(VU); free(Uh); free(Qh); free(QP); free(lam); free(flux); free(QF); free(tmpN); free(nolf);
 }
 
 /* viscous_matrices!, :613-645 (let lambda = -lambda, quirk Q4); entries not listed stay 0 */
@@ -479,6 +495,15 @@ double oracle_cns_rhs_viscous(const oracle_cns_t* c, const double* Q, double* rh
       VUP[3 * KNf + n] = vf4;
       VUP[KNf + n] = vf2 - 2 * VUn * nx;
       VUP[2 * KNf + n] = vf3 - 2 * VUn * ny;
+    } else if (c->BCTYPE == 4) { /* dg2D_CNS_modalESDG.jl:187-203: VL = v_ufun(rhoL, rhoL*uL, rhoL*vL, EL) / VUf */
+      if (lid) {
+        double rho = c->inflow[0], u = c->inflow[1], v = c->inflow[2], p = c->inflow[3];
+        double U[4] = {rho, rho * u, rho * v, p / (GAMMA - 1) + .5 * rho * (u * u + v * v)}, VL[4];
+        oracle_v_ufun(U, VL);
+        for (int f = 0; f < 4; ++f) VUP[f * KNf + n] = VL[f];
+      } else {
+        for (int f = 0; f < 4; ++f) VUP[f * KNf + n] = VUf[f * KNf + n];
+      }
     }
   }
   /* dg_grad! :548-569 */
@@ -565,10 +590,12 @@ double oracle_cns_rhs_viscous(const oracle_cns_t* c, const double* Q, double* rh
       syP[2 * KNf + n] = -sy2 + 2 * n2 * sny;
       sxP[3 * KNf + n] = -sxf[3 * KNf + n];
       syP[3 * KNf + n] = -syf[3 * KNf + n];
+    } else if (c->BCTYPE == 4) { /* dg2D_CNS_modalESDG.jl:205-216: sigma+ = sigma- on both sides */
+      for (int f = 0; f < 4; ++f) { sxP[f * KNf + n] = sxf[f * KNf + n]; syP[f * KNf + n] = syf[f * KNf + n]; }
     }
   }
-  /* :817-840 penalty */
-  if (c->viscous_dissp) {
+  /* :817-840 penalty (the shock-tube driver has this block commented out, dg2D_CNS_modalESDG.jl:494-518) */
+  if (c->viscous_dissp && c->BCTYPE != 4) {
     for (size_t n = 0; n < KNf; ++n) {
       double tau = -1 / c->Re / VUf[3 * KNf + n];
       for (int f = 1; f < 4; ++f) pen[f * KNf + n] = tau * (VUP[f * KNf + n] - VUf[f * KNf + n]);
@@ -602,7 +629,7 @@ double oracle_cns_rhs_viscous(const oracle_cns_t* c, const double* Q, double* rh
         size_t n = (size_t)e * Np + i, g = (size_t)e * Nh + i;
         double vol = c->rxJ[g] * t1[n] + c->sxJ[g] * t2[n] + c->ryJ[g] * t3[n] + c->syJ[g] * t4[n];
         double r = (vol + tl[n]) / c->J[n];
-        if (c->viscous_dissp) r = r + penL[f * KNp + n];
+        if (c->viscous_dissp && c->BCTYPE != 4) r = r + penL[f * KNp + n];
         rhs[f * KNp + n] = r;
       }
   }

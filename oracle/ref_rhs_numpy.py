@@ -176,6 +176,46 @@ class BCFuns:
             self._set(syP[3], b, -g(syf[3], b))
 
 
+class InflowBCFuns:
+    """examples/CompressibleNS/dg2D_CNS_modalESDG.jl:161-217 (init_BC_funs of the shock-tube driver): Dirichlet inflow
+    state on the x-min side, copy of the interior trace on the x-max side, lam = lamP = 0 and sigma+ = sigma- on
+    both; the penalty block of that driver is commented out (:494-518).  md.mapB = the x-side boundary nodes."""
+    BCTYPE = 4
+
+    def __init__(self, md, inflow):
+        mapB = np.asarray(md.mapB, dtype=np.int64)
+        xb = gather(md.xf, mapB)
+        self.left = mapB[np.abs(xb - md.xf.min()) < 1e-12]
+        self.right = mapB[np.abs(xb - md.xf.max()) < 1e-12]
+        self.vwall = np.concatenate([self.left, self.right])
+        self.rhoL, self.uL, self.vL, self.pL = inflow
+
+    def inviscid(self, QP, Qf):                                   # :168-178
+        s = BCFuns._set
+        s(QP[0], self.left, self.rhoL)
+        s(QP[1], self.left, self.uL)
+        s(QP[2], self.left, self.vL)
+        s(QP[3], self.left, self.rhoL / (2 * self.pL))
+        for c in range(4):
+            s(QP[c], self.right, gather(Qf[c], self.right))
+
+    def lam(self, lamP, lam):                                     # :180-185
+        for a in (lam, lamP):
+            BCFuns._set(a, self.vwall, 0.0)
+
+    def entropyvars(self, VUP, VUf):                              # :187-203
+        EL = self.pL / (ph.GAMMA - 1) + .5 * self.rhoL * (self.uL ** 2 + self.vL ** 2)
+        VL = ph.v_ufun(np.float64(self.rhoL), np.float64(self.rhoL * self.uL), np.float64(self.rhoL * self.vL), np.float64(EL))
+        for c in range(4):
+            BCFuns._set(VUP[c], self.left, VL[c])
+            BCFuns._set(VUP[c], self.right, gather(VUf[c], self.right))
+
+    def stress(self, sxP, syP, sxf, syf, VUf):                    # :205-216
+        for c in range(4):
+            BCFuns._set(sxP[c], self.vwall, gather(sxf[c], self.vwall))
+            BCFuns._set(syP[c], self.vwall, gather(syf[c], self.vwall))
+
+
 def _v_hardcoded(Q):
     """dg2D_CNS_cavity_optimized.jl:461-467 (gamma literals 0.4 / 1.4 / 2.4, quirk Q5)."""
     n = Q[1] ** 2 + Q[2] ** 2
@@ -205,7 +245,11 @@ def rhs_inviscid(Q, md, ops, bc, inviscid_dissp=True, compute_rhstest=False):
     rhoM, rhouM, rhovM, EM = Uf
     rhoUM_n = (rhouM * md.nxJ + rhovM * md.nyJ) / md.sJ
     lam = np.abs(np.sqrt(np.abs(rhoUM_n / rhoM)) + np.sqrt(1.4 * 0.4 * (EM - .5 * rhoUM_n ** 2 / rhoM) / rhoM))
-    LFc = .25 * np.maximum(lam, gather(lam, mapP)) * md.sJ
+    lamP = np.array(gather(lam, mapP), order="F")
+    if hasattr(bc, "lam"):
+        lam = np.array(lam, order="F")
+        bc.lam(lamP, lam)                                  # impose_BCs_lam! of the shock-tube driver
+    LFc = .25 * np.maximum(lam, lamP) * md.sJ
     UP = [gather(x, mapP) for x in Uf]
     fx, fy = ph.euler_fluxes_UL_UR(QP, QM)                 # argument order (QP,QM), quirk Q8
     flux = []

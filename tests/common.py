@@ -146,3 +146,45 @@ def perturb_hex(Q, seed=20250117, amp=0.01):
     out[0] *= 1 + amp * (2 * rng.random(Q[0].shape) - 1)
     out[4] *= 1 + amp * (2 * rng.random(Q[0].shape) - 1)
     return out
+
+
+# ---- shock-tube closures (examples/CompressibleNS/dg2D_CNS_modalESDG.jl) on quads -----------------------------
+def becker_constants():
+    """dg2D_CNS_modalESDG.jl:31-61 (same numbers as oracle.becker_constants)."""
+    g, M_0, mu = 1.4, 3.0, 0.01
+    v_inf, m_0, v_0 = 0.2, 1.0, 1.0
+    v_1 = (g - 1 + 2 / M_0 ** 2) / (g + 1)
+    v_01 = np.sqrt(v_0 * v_1)
+    eL = 1 / (2 * g) * ((g + 1) / (g - 1) * v_01 ** 2 - v_0 ** 2)
+    eR = 1 / (2 * g) * ((g + 1) / (g - 1) * v_01 ** 2 - v_1 ** 2)
+    rhoL, rhoR = m_0 / v_0, m_0 / v_1
+    return dict(mu=mu, lam=2 / 3 * mu, Pr=3 / 4, rhoL=rhoL, rhoR=rhoR, uL=v_0 + v_inf, uR=v_1 + v_inf, vL=0.0,
+                pL=(g - 1) * rhoL * eL, pR=(g - 1) * rhoR * eR)
+
+
+def shocktube_state(x, y):
+    st = becker_constants()
+    s = .5 * (1 + np.tanh((x - .25) / .2))
+    wob = 1 + .02 * np.sin(2 * np.pi * y) * np.exp(-20 * (x - .3) ** 2)
+    rho = (st["rhoL"] + (st["rhoR"] - st["rhoL"]) * s) * wob
+    u = st["uL"] + (st["uR"] - st["uL"]) * s
+    v = .03 * np.cos(2 * np.pi * y) * np.exp(-20 * (x - .3) ** 2)
+    p = st["pL"] + (st["pR"] - st["pL"]) * s
+    return [np.asfortranarray(q) for q in ph.primitive_to_conservative(rho, u, v, p)]
+
+
+def product_shocktube_problem(N, Kx, Ky, elem_range=None):
+    """Mesh and maps of dg2D_CNS_modalESDG.jl:62-78 with the quad element: [-0.5,1]x[0,1], periodic patch on all four
+    sides, md.mapB = the nodes of the two x-sides (leftwall / rightwall of init_BC_funs :165-166)."""
+    VX, VY, EToV = sd.uniform_quad_mesh(Kx, Ky)
+    VX, VY = VX / 4 * 3 + 1 / 4, (VY + 1) / 2
+    rd = sd.init_reference_quad(N)
+    md = sd.init_mesh((VX, VY), EToV, rd, elem_range=elem_range)
+    mapB = md.mapB.copy()
+    sd.make_periodic(md, rd)
+    loc = mapB - 1 - md.elem_offset * md.mapP.shape[0]
+    xb = md.xf.flatten(order="F")[loc]
+    md.mapB = mapB[(np.abs(xb + .5) < 1e-12) | (np.abs(xb - 1.0) < 1e-12)]
+    ops = sd.cns_ops(rd)
+    sd.interp_geofacs_to_hybrid(md, ops["Vh"])
+    return rd, md, ops, shocktube_state(md.x, md.y)

@@ -141,3 +141,29 @@ def test_rhs_inviscid_viscous_split_and_rhsRK_diagnostics(eng_mod, oracle_lib, b
     # the reference-signature wrapper returns the same triple
     out, rt2, rtv2 = eng_mod.rhsRK(Q, rd, md, ops, BCTYPE=BCTYPE)
     assert rt2 == rt and rtv2 == rtv and rel_l2(out, ref) <= max(TOL, 4 * noise_floor(lambda q: co.rhsRK(q, False)[0], p.Q))
+
+
+def test_shocktube_inflow_outflow_closures_match_oracle(eng_mod, oracle_lib):
+    """BCTYPE 4: the boundary closures of examples/CompressibleNS/dg2D_CNS_modalESDG.jl:161-217 (Dirichlet inflow state,
+    copy on the outflow side, lam = lamP = 0, sigma+ = sigma-, no penalty), periodic in y, on quads."""
+    from common import becker_constants, product_shocktube_problem
+    from oracle import oracle as orc
+    N, Kx, Ky = 3, 8, 5
+    p = orc.build_cns_problem(N, Kx, Ky, bc="shocktube")
+    co = orc.CnsOracle(p, viscous_dissp=False)
+    rd, md, ops, Q = product_shocktube_problem(N, Kx, Ky)
+    assert np.array_equal(md.mapP, p.md.mapP) and np.array_equal(np.sort(md.mapB), np.sort(p.md.mapB))
+    st = becker_constants()
+    eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, BCTYPE=4, viscous_dissp=False, mu=st["mu"], lam=st["lam"], Pr=st["Pr"],
+                            inflow=(st["rhoL"], st["uL"], st["vL"], st["pL"]))
+    ref = co.rhsRK(p.Q, compute_diag=False)[0]
+    err = rel_l2(_gpu_rhs(eng, Q), ref)
+    floor = noise_floor(lambda q: co.rhsRK(q, compute_diag=False)[0], p.Q)
+    print(f"shock-tube closures N={N} {Kx}x{Ky}: err={err:.2e} oracle-noise-floor={floor:.2e}")
+    assert err <= max(TOL, 4 * floor), (err, floor)
+    # uniform inflow state is steady
+    c = [np.full_like(Q[0], v) for v in (st["rhoL"], st["rhoL"] * st["uL"], 0.0, st["pL"] / 0.4 + .5 * st["rhoL"] * st["uL"] ** 2)]
+    assert max(np.abs(x).max() for x in _gpu_rhs(eng, c)) < 1e-10
+    # the ABI refuses the penalty with these closures (the driver has that block commented out)
+    with pytest.raises(Exception):
+        eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, BCTYPE=4, viscous_dissp=True, inflow=(1.0, 1.2, 0.0, 0.08))

@@ -107,3 +107,28 @@ def test_omp_threads_do_not_change_results(oracle_lib):
     finally:
         orc.lib().oracle_set_threads(1)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_shocktube_closures_c_vs_numpy_and_consistency(oracle_lib):
+    """BCTYPE 4 = init_BC_funs of examples/CompressibleNS/dg2D_CNS_modalESDG.jl:161-217 (Dirichlet inflow, copy outflow,
+    lam = 0 and sigma+ = sigma- on both, no penalty) on the quad element: the two restatements agree, and a uniform
+    field equal to the inflow state is a steady state (the Dirichlet data is consistent with the interior)."""
+    p = orc.build_cns_problem(3, 6, 4, bc="shocktube")
+    assert p.BCTYPE == 4 and p.md.mapB.size == 2 * 4 * 4
+    co = orc.CnsOracle(p, viscous_dissp=False)
+    bc = rr.InflowBCFuns(p.md, p.inflow)
+    a, t1, t2 = rr.rhsRK(p.Q, p.rd, p.md, p.ops, bc, p.Re, p.lam, p.mu, p.Pr, True, False)
+    b, s1, s2 = co.rhsRK(p.Q)
+    floor = noise_floor(lambda q: co.rhsRK(q, False)[0], p.Q)
+    assert rel_l2(a, b) <= max(1e-12, 4 * floor), (rel_l2(a, b), floor)
+    assert abs(t1 - s1) <= 1e-9 * max(1.0, abs(s1)) and abs(t2 - s2) <= 1e-9 * max(1.0, abs(s2))
+    st = orc.becker_constants()
+    Qc = [np.full_like(p.Q[0], v) for v in ph.primitive_to_conservative(st["rhoL"], st["uL"], 0.0, st["pL"])]
+    assert max(np.abs(x).max() for x in co.rhsRK(Qc, False)[0]) < 1e-10
+    # the Dirichlet data acts on the first column of elements (and, through the BR1 gradient of its neighbour, on the
+    # second); nothing else moves
+    p2 = orc.build_cns_problem(3, 6, 4, bc="shocktube")
+    p2.inflow = (st["rhoL"] * 1.1, st["uL"], 0.0, st["pL"])
+    d = [x - y for x, y in zip(orc.CnsOracle(p2, viscous_dissp=False).rhsRK(p.Q, False)[0], b)]
+    cols = np.abs(np.stack(d)).max(axis=(0, 1)).reshape(4, 6)          # (Ky, Kx) element blocks
+    assert cols[:, 0].min() > 1e-6 and cols[:, 2:].max() == 0.0
