@@ -116,3 +116,16 @@ def test_lsrk45_hip_graph_replay_is_bitwise_equal_and_faster_on_cfg1():
     print(f"cfg1 LSRK45: {1e6 * (t1 - t0) / nsteps:.1f} us/step stage-by-stage, {1e6 * (t2 - t1b) / nsteps:.1f} us/step graph replay "
           f"(capture {1e3 * (t1b - t1):.1f} ms once)")
     assert torch.equal(Q1, Q2)
+
+
+def test_shocktube_driver_tracks_the_exact_viscous_shock():
+    """examples/dg2D_CNS_shocktube_quad.py (dg2D_CNS_modalESDG.jl on quads): the Becker travelling viscous shock is an
+    exact Navier-Stokes solution, so the error against it at the final time must be small and fall under refinement --
+    an end-to-end check of the CNS right-hand side, the BCTYPE 4 closures and the DOPRI45 loop that does not involve
+    the oracle."""
+    import dg2D_CNS_shocktube_quad as drv
+    e1, i1, _ = drv.run(N=2, K1D=32, T=0.05, Ky=2, verbose=False)
+    e2, i2, _ = drv.run(N=2, K1D=64, T=0.05, Ky=2, verbose=False)
+    rate = math.log2(e1 / e2)
+    print(f"Becker shock tube N=2, T=0.05: L2 error K1D=32 {e1:.3e}, K1D=64 {e2:.3e} (rate {rate:.2f}); Linf {i1:.2e} -> {i2:.2e}")
+    assert rate > 2.0 and e2 < 5e-3     # measured: 1.76e-2 -> 2.51e-3 (rate 2.8); N=3: 4.1e-3 -> 2.0e-4 (rate 4.4)
