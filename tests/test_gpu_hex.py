@@ -122,3 +122,26 @@ def test_hex_invariants_shards_and_fused_rk(eng_mod):
     eng.rhs_lsrk_fused(Q1, res1, a, b, dt)
     eng.lsrk_update(Q2, res2, eng.rhs(Q2), a, b, dt)
     assert torch.equal(Q1, Q2) and torch.equal(res1, res2)
+
+
+def test_hex_full_size_properties_128x128x16(eng_mod):
+    """One GPU's share of BASELINE config 5 (N=3, 128x128x16 of the 128^3 box = 262 144 hexahedra): the
+    size-independent properties that pin the scheme -- free stream, discrete conservation, entropy conservation with
+    the LF term at the script's factor 0 (`@show rhstest`), bitwise reproducibility."""
+    import torch
+    rd, md, ops, Q = product_hex_problem(3, 128, 128, 16, hybrid=False)
+    eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.EULER_HEX_COLLOCATED, lf_scale=0.0)
+    c = [np.full_like(Q[0], v) for v in (1.3, 0.4, -0.3, 0.2, 2.9)]
+    r = eng.rhs(eng.upload(c))
+    assert float(r.abs().max()) < 1e-11 / float(np.abs(md.J).min())       # round-off of O(1) fluxes times 1/|J|
+    Qp = perturb_hex(Q)
+    Qd = eng.upload(Qp)
+    rd_ = eng.rhs(Qd)
+    rh = eng.download(rd_)
+    for x in rh:
+        assert abs(float((md.wJq * x).sum())) <= 2e-9 * max(float(np.abs(md.wJq * x).sum()), 1.0)
+    rt = eng.rhstest(Qd, rd_)
+    scale = float(np.abs(md.wJq).sum()) * max(float(np.abs(x).max()) for x in rh)
+    print(f"hex 128x128x16: rhstest {rt:.3e} (scale {scale:.3e})")
+    assert abs(rt) < 1e-11 * scale
+    assert torch.equal(rd_, eng.rhs(Qd))
