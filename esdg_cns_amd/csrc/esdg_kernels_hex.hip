@@ -128,6 +128,12 @@ __device__ __forceinline__ double lf_lambda3(const double* q, double nx, double 
   return fabs(sqrt(fabs(rhoUn * ir)) + sqrt(1.4 * pn * ir));
 }
 
+// LDS slot of a volume node.  The face lanes of one face read/update the 16 nodes of a plane parallel to it; in the
+// natural order i0 + 4 i1 + 16 i2 the planes i0 = const and i1 = const fall on a quarter of the LDS banks (4-way
+// conflicts on every ds_read_b64 / ds_add_f64).  XOR-ing both 2-bit fields of the low nibble with i2 maps the 16 nodes
+// of all three plane families (and any 16 consecutive nodes) to 16 distinct double-width banks.
+__device__ __forceinline__ int slot_of(int node) { return node ^ ((node >> 4) * 5); }
+
 template <int N1>
 __device__ __forceinline__ void stage_tables(const HexTables& HT, double* sTab, int* sInt) {
   constexpr HexLayout L(N1);
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_project(HexTables HT, MeshDev M,
   v_of_prim3(q, V);
   if (vin) {
 #pragma unroll
-    for (int c = 0; c < HEX_NFLD; ++c) sV[wv][c * HW + lane] = V[c];
+    for (int c = 0; c < HEX_NFLD; ++c) sV[wv][c * HW + slot_of(lane)] = V[c];
   }
   __syncthreads();
 #pragma unroll
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_project(HexTables HT, MeshDev M,
       for (int i = 0; i < N1; ++i) {
         const double w = sTab[L.EE + (d * 2 + t) * N1 + i];
 #pragma unroll
-        for (int c = 0; c < HEX_NFLD; ++c) Vf[c] += w * sV[wv][c * HW + base + i * stride];
+        for (int c = 0; c < HEX_NFLD; ++c) Vf[c] += w * sV[wv][c * HW + slot_of(base + i * stride)];
       }
       double qf[HEX_NFLD];
       prim_of_v3(Vf, qf);
@@ -256,6 +262,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
   stage_tables<N1>(HT, sTab, sInt);
 #pragma unroll
   for (int c = 0; c < HEX_NFLD; ++c) sAcc[c * HW + lane] = 0.0;
+  const int myslot = slot_of(lane);
 
   // ---- pointwise: primitives + logs ------------------------------------------------------------------
   double acc[HEX_NFLD] = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
     double qv[7];
     prim_logs3(U, qv);
 #pragma unroll
-    for (int c = 0; c < 7; ++c) sP[c * HW + lane] = qv[c];
+    for (int c = 0; c < 7; ++c) sP[c * HW + myslot] = qv[c];
     __syncthreads();
 
     // ---- volume lanes: circulant line schedule, each unordered pair once -------------------------------
@@ -285,8 +292,9 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
         const bool act = vin && (!half || id < N1 / 2);
         const int node = act ? lane + (j - id) * stride : lane;
         double qn[7], F[HEX_NFLD];
+        const int ns = slot_of(node);
 #pragma unroll
-        for (int c = 0; c < 7; ++c) qn[c] = sP[c * HW + node];
+        for (int c = 0; c < 7; ++c) qn[c] = sP[c * HW + ns];
         const double W = sTab[L.S + (d * N1 + id) * N1 + j] * wt;
         ec_flux_dir(qv, qn, gx, gy, gz, F);
         if (act) {
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
           for (int c = 0; c < HEX_NFLD; ++c) {
             const double wf = W * F[c];
             acc[c] += wf;
-            lds_add(&sAcc[c * HW + node], -wf);
+            lds_add(&sAcc[c * HW + ns], -wf);
           }
         }
       }
@@ -357,15 +365,16 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
     for (int i = 0; i < N1; ++i) {
       const int node = base + ii * stride;
       double qn[7], F[HEX_NFLD];
+      const int ns = slot_of(node);
 #pragma unroll
-      for (int c = 0; c < 7; ++c) qn[c] = sP[c * HW + node];
+      for (int c = 0; c < 7; ++c) qn[c] = sP[c * HW + ns];
       const double W = sTab[L.SF + (d * 2 + t) * N1 + ii] * wtf;
       ec_flux_dir(qn, qm, gx, gy, gz, F);
 #pragma unroll
       for (int c = 0; c < HEX_NFLD; ++c) {
         const double wf = W * F[c];
         G[c] -= wf;
-        if (fin) lds_add(&sAcc[c * HW + node], wf);
+        if (fin) lds_add(&sAcc[c * HW + ns], wf);
       }
       ii = ii + 1 == N1 ? 0 : ii + 1;
     }
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
     double tot[HEX_NFLD];
     const double pd = sTab[L.PD + lq];
 #pragma unroll
-    for (int c = 0; c < HEX_NFLD; ++c) tot[c] = pd * (acc[c] + sAcc[c * HW + lane]);
+    for (int c = 0; c < HEX_NFLD; ++c) tot[c] = pd * (acc[c] + sAcc[c * HW + myslot]);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       const int id = d == 0 ? i0 : (d == 1 ? i1 : i2);
