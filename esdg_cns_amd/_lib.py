@@ -72,6 +72,10 @@ SYMBOLS = {
     "esdg_num_exchanges": (C.c_int, [_vp]),
     "esdg_exchange_info": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p]),
     "esdg_halo_segment": (C.c_int, [_vp, C.c_int, C.c_int, _i32p, _szp, _szp, _szp, _szp]),
+    "esdg_interior_range": (C.c_int, [_vp, c_int64_p, c_int64_p]),
+    "esdg_rhs_phase_range": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int64, _vp, _vp, _vp]),
+    "esdg_rhs_phase_range_lsrk": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int64, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp]),
+    "esdg_halo_pack": (C.c_int, [_vp, C.c_int, _vp]),
     "esdg_halo_plan_create": (C.c_int, [c_int64_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, c_int64_p, C.POINTER(_vp)]),
     "esdg_halo_plan_destroy": (C.c_int, [_vp]),
     "esdg_halo_plan_num_neighbors": (C.c_int, [_vp]),

@@ -468,8 +468,27 @@ struct esdg_ctx {
   size_t ws_bytes = 0;
   char* ws = nullptr;
   size_t off_AU = 0, off_Av = 0, off_B = 0, off_S = 0;
+  int64_t int_lo = 0, int_hi = 0;   // longest run of elements [int_lo, int_hi) that touch no ghost slot
   static constexpr int NPARTIAL = 1024;
 };
+
+// longest contiguous run of local elements none of whose face nodes maps to a ghost slot (halo overlap, see esdg_interior_range)
+static void set_interior(esdg_ctx* c, const std::vector<int32_t>& mapP, int64_t K, int Nfq) {
+  int64_t best_lo = 0, best_hi = 0, run_lo = 0;
+  const int32_t first_ghost = (int32_t)(K * Nfq);
+  for (int64_t e = 0; e <= K; ++e) {
+    bool touches = e == K;
+    if (!touches)
+      for (int i = 0; i < Nfq; ++i)
+        if (mapP[(size_t)e * Nfq + i] >= first_ghost) { touches = true; break; }
+    if (touches) {
+      if (e - run_lo > best_hi - best_lo) { best_lo = run_lo; best_hi = e; }
+      run_lo = e + 1;
+    }
+  }
+  c->int_lo = best_lo;
+  c->int_hi = best_hi;
+}
 
 extern "C" {
 
@@ -719,7 +738,9 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   T.Dr_idx = c->d_Dr_i.as<uint8_t>(); T.Dr_val = c->d_Dr_v.as<double>();
   T.Ds_idx = c->d_Ds_i.as<uint8_t>(); T.Ds_val = c->d_Ds_v.as<double>(); T.wD = visc ? eDr.w : 0;
   T.Vq = c->d_Vq.as<double>(); T.Pq = c->d_Pq.as<double>();
-  c->M.K = K; c->M.geo = c->d_geo.as<double>(); c->M.mapP = c->d_mapP.as<int32_t>(); c->M.bc = bcflag.empty() ? nullptr : c->d_bc.as<uint8_t>();
+  c->M.K = K; c->M.e_begin = 0; c->M.e_count = K;
+  c->M.geo = c->d_geo.as<double>(); c->M.mapP = c->d_mapP.as<int32_t>(); c->M.bc = bcflag.empty() ? nullptr : c->d_bc.as<uint8_t>();
+  set_interior(c, pl.mapP, K, Nfq);
   c->M.wJq = mesh->wJq ? c->d_wJq.as<double>() : nullptr;
   c->M.stamps = nullptr;
   if (c->ph.dbg & 8) {
@@ -862,7 +883,9 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
   c->HT.dbl = c->t_dbl.as<double>();
   c->HT.ints = c->t_int.as<int>();
   for (int d = 0; d < 3; ++d) c->HT.op[d] = hh.op[d];
-  c->M.K = K; c->M.geo = c->d_geo.as<double>(); c->M.mapP = c->d_mapP.as<int32_t>(); c->M.bc = nullptr;
+  c->M.K = K; c->M.e_begin = 0; c->M.e_count = K;
+  c->M.geo = c->d_geo.as<double>(); c->M.mapP = c->d_mapP.as<int32_t>(); c->M.bc = nullptr;
+  set_interior(c, pl.mapP, K, Nfq);
   c->M.wJq = mesh->wJq ? c->d_wJq.as<double>() : nullptr;
   c->M.stamps = nullptr;
 
@@ -899,8 +922,21 @@ int esdg_bind_workspace(esdg_ctx* ctx, void* dev_ptr, size_t bytes) {
 int esdg_num_phases(const esdg_ctx* ctx) { return ctx ? ctx->nphases : 0; }
 int esdg_uses_tensor_kernels(const esdg_ctx* ctx) { return ctx ? (int)ctx->use_fast : 0; }
 
-static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs, const LsrkFuse& lf, void* stream) {
+static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs, const LsrkFuse& lf, void* stream,
+                          int64_t e_begin = 0, int64_t e_count = -1) {
   if (!ctx || !Q) return fail(ESDG_ERR_ARG, "null argument");
+  const bool ranged = e_count >= 0;
+  if (ranged) {
+    if (!ctx->use_fast) return fail(ESDG_ERR_STATE, "element-range launches need the tensor / hex kernels");
+    if (e_begin < 0 || e_begin + e_count > ctx->K) return fail(ESDG_ERR_ARG, "element range [%lld, %lld) outside [0, %lld)", (long long)e_begin,
+                                                              (long long)(e_begin + e_count), (long long)ctx->K);
+    if (e_count == 0) return ESDG_OK;
+  }
+  struct RangeGuard {   // full-range launches leave the mesh record untouched
+    MeshDev& M; int64_t K;
+    ~RangeGuard() { M.e_begin = 0; M.e_count = K; }
+  } rg{ctx->M, ctx->K};
+  if (ranged) { ctx->M.e_begin = e_begin; ctx->M.e_count = e_count; }
   if (!ctx->ws) return fail(ESDG_ERR_STATE, "workspace not bound (esdg_bind_workspace)");
   if (phase < 0 || phase >= ctx->nphases) return fail(ESDG_ERR_ARG, "bad phase %d", phase);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -915,7 +951,7 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
   if (ctx->dim == 3) {
     if (phase == 0) {
       rc = launch_project_hex(ctx->T.N1, ctx->HT, ctx->M, ctx->ph, Q, A_U, s);
-      if (!rc && ctx->nsend)
+      if (!rc && ctx->nsend && !ranged)
         rc = launch_pack(A_U, ctx->au_nc, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[0].send_off), s);
     } else {
       if (!rhs && !lf.Qw) return fail(ESDG_ERR_ARG, "rhs output is null");
@@ -924,14 +960,14 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
   } else if (phase == 0) {
     rc = ctx->use_fast ? launch_project_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, A_v, s)
                        : launch_project(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, s);
-    if (!rc && ctx->nsend) {
+    if (!rc && ctx->nsend && !ranged) {
       rc = launch_pack(A_U, ctx->au_nc, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[0].send_off), s);
       if (!rc && need_Av) rc = launch_pack(A_v, AV_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[1].send_off), s);
     }
   } else if (visc && phase == 1) {
     rc = ctx->use_fast ? launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, SG, nullptr, s)
                        : launch_sigma(ctx->T, ctx->M, ctx->ph, Q, A_v, B, s);
-    if (!rc && ctx->nsend) rc = launch_pack(B, B_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch.back().send_off), s);
+    if (!rc && ctx->nsend && !ranged) rc = launch_pack(B, B_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch.back().send_off), s);
   } else {
     if (!rhs && !lf.Qw) return fail(ESDG_ERR_ARG, "rhs output is null");
     if (lf.Qw && !ctx->use_fast) return fail(ESDG_ERR_STATE, "the fused RK update needs the tensor kernels");
@@ -953,6 +989,40 @@ int esdg_rhs_phase_lsrk(esdg_ctx* ctx, int phase, double* Q, double* resQ, doubl
   const LsrkFuse none{nullptr, nullptr, 0.0, 0.0, 0.0};
   const bool last = ctx && phase == ctx->nphases - 1;
   return rhs_phase_impl(ctx, phase, Q, nullptr, last ? lf : none, stream);
+}
+
+int esdg_interior_range(const esdg_ctx* ctx, int64_t* e_begin, int64_t* e_end) {
+  if (!ctx || !e_begin || !e_end) return fail(ESDG_ERR_ARG, "null argument");
+  *e_begin = ctx->int_lo;
+  *e_end = ctx->int_hi;
+  return ESDG_OK;
+}
+
+int esdg_rhs_phase_range(esdg_ctx* ctx, int phase, int64_t e_begin, int64_t e_count, const double* Q, double* rhs, void* stream) {
+  const LsrkFuse none{nullptr, nullptr, 0.0, 0.0, 0.0};
+  if (e_count < 0) return fail(ESDG_ERR_ARG, "negative element count");
+  return rhs_phase_impl(ctx, phase, Q, rhs, none, stream, e_begin, e_count);
+}
+
+int esdg_rhs_phase_range_lsrk(esdg_ctx* ctx, int phase, int64_t e_begin, int64_t e_count, double* Q, double* resQ, double a,
+                              double b, double dt, void* stream) {
+  if (!resQ) return fail(ESDG_ERR_ARG, "null argument");
+  if (e_count < 0) return fail(ESDG_ERR_ARG, "negative element count");
+  const LsrkFuse lf{Q, resQ, a, b, dt};
+  const LsrkFuse none{nullptr, nullptr, 0.0, 0.0, 0.0};
+  const bool last = ctx && phase == ctx->nphases - 1;
+  return rhs_phase_impl(ctx, phase, Q, nullptr, last ? lf : none, stream, e_begin, e_count);
+}
+
+int esdg_halo_pack(esdg_ctx* ctx, int xch, void* stream) {
+  if (!ctx || xch < 0 || xch >= (int)ctx->xch.size()) return fail(ESDG_ERR_ARG, "bad exchange id");
+  if (!ctx->ws) return fail(ESDG_ERR_STATE, "workspace not bound (esdg_bind_workspace)");
+  if (!ctx->nsend) return ESDG_OK;
+  const Exchange& x = ctx->xch[xch];
+  int rc = launch_pack(reinterpret_cast<const double*>(ctx->ws + x.buf_off), x.ncomp, ctx->d_sendlist.as<int32_t>(), ctx->nsend,
+                       reinterpret_cast<double*>(ctx->ws + x.send_off), static_cast<hipStream_t>(stream));
+  if (rc) return fail(ESDG_ERR_NO_DEVICE, "pack launch: %s", hipGetErrorString((hipError_t)rc));
+  return ESDG_OK;
 }
 
 int esdg_rhs_lsrk(esdg_ctx* ctx, double* Q, double* resQ, double a, double b, double dt, void* stream) {

@@ -58,6 +58,7 @@ int launch_rhs_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Ph
 
 struct MeshDev {
   int64_t K;               // local elements
+  int64_t e_begin, e_count;  // element range a launch covers (tensor / hex kernels; the host sets 0, K for full launches)
   const double* geo;       // [K][GEO_STRIDE]
   const int32_t* mapP;     // [K][Nfq]  local face-node index, or ghost slot >= K*Nfq
   const uint8_t* bc;       // [K][Nfq]  0 interior/periodic, 1 wall, 2 lid, 3 Dirichlet inflow, 4 copy; may be null

@@ -166,13 +166,13 @@ __global__ __launch_bounds__(HW * HNWV) void kh_project(HexTables HT, MeshDev M,
   __shared__ double sTab[L.NDBL];
   __shared__ int sInt[L.NINT];
   __shared__ double sV[HNWV][HEX_NFLD * HW];
-  const int64_t nblk = (M.K + HNWV - 1) / HNWV;
+  const int64_t nblk = (M.e_count + HNWV - 1) / HNWV;
   const int64_t blk = block_of(nblk, remap != 0);
   if (blk < 0) return;
   const int lane = threadIdx.x & (HW - 1), wv = threadIdx.x / HW;
-  const int64_t e = blk * HNWV + wv;
-  const bool active = e < M.K;
-  const int64_t ec = active ? e : M.K - 1;
+  const int64_t e = M.e_begin + blk * HNWV + wv;
+  const bool active = e < M.e_begin + M.e_count;
+  const int64_t ec = active ? e : M.e_begin + M.e_count - 1;
   const bool vin = lane < Nq;
   double U[HEX_NFLD] = {1.0, 0.0, 0.0, 0.0, 1.0};
   if (vin) {
@@ -226,13 +226,13 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
   __shared__ double sPs[HNWV][7 * HW];
   __shared__ double sAccs[HNWV][HEX_NFLD * HW];
   __shared__ double sGs[HNWV][HEX_NFLD * Nfq];
-  const int64_t nblk = (M.K + HNWV - 1) / HNWV;
+  const int64_t nblk = (M.e_count + HNWV - 1) / HNWV;
   const int64_t blk = block_of(nblk, remap != 0);
   if (blk < 0) return;
   const int lane = threadIdx.x & (HW - 1), wv = threadIdx.x / HW;
-  const int64_t e = blk * HNWV + wv;
-  const bool active = e < M.K;
-  const int64_t ec = active ? e : M.K - 1;
+  const int64_t e = M.e_begin + blk * HNWV + wv;
+  const bool active = e < M.e_begin + M.e_count;
+  const int64_t ec = active ? e : M.e_begin + M.e_count - 1;
   const bool vin = lane < Nq;
   double* sP = sPs[wv];
   double* sAcc = sAccs[wv];
@@ -466,17 +466,17 @@ static inline unsigned hex_grid(int64_t K, bool remap) {
 
 int launch_project_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phys& ph, const double* Q, double* A_U,
                        hipStream_t s) {
-  if (M.K == 0) return 0;
+  if (M.e_count <= 0) return 0;
   const int remap = (ph.dbg & 16) ? 0 : 1;
-  ESDG_HEX_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_project<N1>), dim3(hex_grid(M.K, remap)), dim3(hdev::HW * hdev::HNWV), 0, s, HT, M, remap, Q, A_U));
+  ESDG_HEX_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_project<N1>), dim3(hex_grid(M.e_count, remap)), dim3(hdev::HW * hdev::HNWV), 0, s, HT, M, remap, Q, A_U));
   return (int)hipGetLastError();
 }
 
 int launch_rhs_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
                    double* rhs, const LsrkFuse& lf, hipStream_t s) {
-  if (M.K == 0) return 0;
+  if (M.e_count <= 0) return 0;
   const int remap = (ph.dbg & 16) ? 0 : 1;
-  ESDG_HEX_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_rhs<N1>), dim3(hex_grid(M.K, remap)), dim3(hdev::HW * hdev::HNWV), 0, s, HT, M, ph, remap, Q, A_U, rhs, lf));
+  ESDG_HEX_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_rhs<N1>), dim3(hex_grid(M.e_count, remap)), dim3(hdev::HW * hdev::HNWV), 0, s, HT, M, ph, remap, Q, A_U, rhs, lf));
   return (int)hipGetLastError();
 }
 

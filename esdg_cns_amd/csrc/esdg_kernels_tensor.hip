@@ -365,8 +365,8 @@ __global__ __launch_bounds__(TW * NWV) void kt_project(TensorTables TT, MeshDev 
   double* sB = sB_ + ln.wave * (E * 4 * Nq);
   stage_tables<N1>(TT, sTab, sInt);
   __syncthreads();
-  const int64_t e0 = ((int64_t)blockIdx.x * NWV + ln.wave) * E;
-  const int nE = (int)max((int64_t)0, min((int64_t)E, M.K - e0));
+  const int64_t e0 = M.e_begin + ((int64_t)blockIdx.x * NWV + ln.wave) * E;
+  const int nE = (int)max((int64_t)0, min((int64_t)E, M.e_begin + M.e_count - e0));
   const bool vactive = ln.tid < nE * Nq, factive = ln.tid < nE * Nfq;
 
   double x[4];
@@ -572,8 +572,8 @@ __global__ __launch_bounds__(TW * NWV) void kt_sigma(TensorTables TT, MeshDev M,
   double* sDv = sDv_ + ln.wave * (E * 3 * Nfq);
   stage_tables<N1>(TT, sTab, sInt);
   __syncthreads();
-  const int64_t e0 = ((int64_t)blockIdx.x * NWV + ln.wave) * E;
-  const int nE = (int)max((int64_t)0, min((int64_t)E, M.K - e0));
+  const int64_t e0 = M.e_begin + ((int64_t)blockIdx.x * NWV + ln.wave) * E;
+  const int nE = (int)max((int64_t)0, min((int64_t)E, M.e_begin + M.e_count - e0));
   const bool vactive = ln.tid < nE * Nq, factive = ln.tid < nE * Nfq;
 
   double x[4];
@@ -671,8 +671,8 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
   const Lane<N1> ln;
   stage_tables<N1>(TT, sTab, sInt);
   __syncthreads();
-  const int64_t e0 = ((int64_t)blockIdx.x * NWV + ln.wave) * E;
-  const int nE = (int)max((int64_t)0, min((int64_t)E, M.K - e0));
+  const int64_t e0 = M.e_begin + ((int64_t)blockIdx.x * NWV + ln.wave) * E;
+  const int nE = (int)max((int64_t)0, min((int64_t)E, M.e_begin + M.e_count - e0));
   const bool vactive = ln.tid < nE * Nq, factive = ln.tid < nE * Nfq;
   const double* g = M.geo + (e0 + (vactive ? ln.ev : 0)) * GEO_STRIDE;
 
@@ -960,11 +960,11 @@ int launch_log_test(const double* x, double* y, int64_t n, hipStream_t s) {
 
 int launch_project_tensor(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
                           double* A_U, double* A_v, hipStream_t s) {
-  if (M.K == 0) return 0;
+  if (M.e_count <= 0) return 0;
   const bool modal = ph.formulation != 0, visc = ph.formulation == 1;
   ESDG_DISPATCH_N1(N1v, {
     constexpr int E = TCfg<N1>::E;
-    const int nb = (int)((M.K + (int64_t)E * NWV - 1) / ((int64_t)E * NWV));
+    const int nb = (int)((M.e_count + (int64_t)E * NWV - 1) / ((int64_t)E * NWV));
     if (!modal)
       hipLaunchKernelGGL((kt_project<N1, false, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v);
     else if (visc)
@@ -985,10 +985,10 @@ int sigma_tensor_blocks(int N1v, int64_t K) {
 
 int launch_sigma_tensor(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
                         const double* A_U, double* B, double* SG, double* vt_partial, hipStream_t s) {
-  if (M.K == 0) return 0;
+  if (M.e_count <= 0) return 0;
   ESDG_DISPATCH_N1(N1v, {
     constexpr int E = TCfg<N1>::E;
-    const int nb = (int)((M.K + (int64_t)E * NWV - 1) / ((int64_t)E * NWV));
+    const int nb = (int)((M.e_count + (int64_t)E * NWV - 1) / ((int64_t)E * NWV));
     if (vt_partial)
       hipLaunchKernelGGL((kt_sigma<N1, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, B, SG, vt_partial);
     else
@@ -1000,11 +1000,11 @@ int launch_sigma_tensor(int N1v, const TensorTables& TT, const MeshDev& M, const
 int launch_rhs_tensor(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
                       const double* A_U, const double* SG, const double* B, double* rhs, const LsrkFuse& lf,
                       hipStream_t s) {
-  if (M.K == 0) return 0;
+  if (M.e_count <= 0) return 0;
   const bool modal = ph.formulation != 0, visc = ph.formulation == 1;
   ESDG_DISPATCH_N1(N1v, {
     constexpr int E = TCfg<N1>::E;
-    const int nb = (int)((M.K + (int64_t)E * NWV - 1) / ((int64_t)E * NWV));
+    const int nb = (int)((M.e_count + (int64_t)E * NWV - 1) / ((int64_t)E * NWV));
     const bool walls = M.bc != nullptr;
     if (!modal)
       hipLaunchKernelGGL((kt_rhs<N1, false, false, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);

@@ -116,6 +116,12 @@ class RhsEngine:
             segs.append(s)
         if nn:
             self.halo = HaloExchanger(segs, group)
+        lo, hi = C.c_int64(), C.c_int64()
+        check(L.esdg_interior_range(ctx, C.byref(lo), C.byref(hi)))
+        self.interior = (lo.value, hi.value)
+        # overlap exchanges with the interior elements (tensor / hex kernels); ESDG_NO_OVERLAP=1 restores phase-by-phase
+        import os
+        self.overlap = bool(L.esdg_uses_tensor_kernels(ctx)) and os.environ.get("ESDG_NO_OVERLAP", "0") != "1"
 
     def _create_hex(self, L, rd, md, ops, lf_scale, rank, nranks, rank_offsets):
         """esdg_create_hex from the arrays examples/dg3D_euler_hex.jl holds when it calls `rhs` (:167)."""
@@ -268,6 +274,36 @@ class RhsEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _phases(self, full, ranged):
+        """Drive the phases of one RHS evaluation with its halo exchanges.  `full(ph)` launches phase ph on all local
+        elements (and packs what it produces); `ranged(ph, e0, n)` launches it on elements [e0, e0+n) without packing.
+        With an interior range (esdg_interior_range) the exchanges overlap computation: phase 0 runs on the boundary
+        ranges first, later phases on the interior first (see include/esdg_hip.h)."""
+        L, ctx = self.L, self.ctx
+        pending = {}
+        lo, hi = self.interior
+        overlap = self.overlap and hi > lo and (hi - lo) < self.K
+        for ph in range(self.nphases):
+            incoming = [x for x, (a, b, _) in enumerate(self.xinfo) if b == ph and x in pending]
+            outgoing = [x for x, (a, b, _) in enumerate(self.xinfo) if a == ph]
+            if not overlap:
+                for x in incoming:
+                    HaloExchanger.wait(pending.pop(x))
+                full(ph)
+            else:
+                if ph > 0:
+                    ranged(ph, lo, hi - lo)                      # interior: needs no ghost data
+                for x in incoming:
+                    HaloExchanger.wait(pending.pop(x))
+                ranged(ph, 0, lo)                                # boundary ranges
+                ranged(ph, hi, self.K - hi)
+                for x in outgoing:
+                    check(L.esdg_halo_pack(ctx, x, self._stream()))
+            for x in outgoing:
+                pending[x] = self.halo.start(self.ws, x)
+            if overlap and ph == 0:
+                ranged(ph, lo, hi - lo)                          # interior of phase 0 overlaps the first exchange
+
     def rhs_into(self, Qd, out):
         """One RHS evaluation, state resident on device; asynchronous on torch's current stream."""
         assert Qd.is_contiguous() and out.is_contiguous() and Qd.dtype == torch.float64
@@ -275,15 +311,9 @@ class RhsEngine:
         if self.halo is None:
             check(L.esdg_rhs(ctx, C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr()), s))
             return out
-        pending = {}
-        for ph in range(self.nphases):
-            for x, (a, b, _) in enumerate(self.xinfo):
-                if b == ph and x in pending:
-                    HaloExchanger.wait(pending.pop(x))
-            check(L.esdg_rhs_phase(ctx, ph, C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr()), s))
-            for x, (a, b, _) in enumerate(self.xinfo):
-                if a == ph:
-                    pending[x] = self.halo.start(self.ws, x)
+        q, o = C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr())
+        self._phases(lambda ph: check(L.esdg_rhs_phase(ctx, ph, q, o, self._stream())),
+                     lambda ph, e0, n: check(L.esdg_rhs_phase_range(ctx, ph, e0, n, q, o, self._stream())))
         return out
 
     def rhs(self, Qd):
@@ -330,18 +360,13 @@ class RhsEngine:
     def rhs_lsrk_fused(self, Qd, resd, a, b, dt):
         """RHS + low-storage RK stage in one pass: resQ = a*resQ + dt*rhs(Q); Q += b*resQ (no rhs array)."""
         L, ctx, s = self.L, self.ctx, self._stream()
+        q, r = C.c_void_p(Qd.data_ptr()), C.c_void_p(resd.data_ptr())
+        a, b, dt = float(a), float(b), float(dt)
         if self.halo is None:
-            check(L.esdg_rhs_lsrk(ctx, C.c_void_p(Qd.data_ptr()), C.c_void_p(resd.data_ptr()), float(a), float(b), float(dt), s))
+            check(L.esdg_rhs_lsrk(ctx, q, r, a, b, dt, s))
             return
-        pending = {}
-        for ph in range(self.nphases):
-            for x, (aft, bef, _) in enumerate(self.xinfo):
-                if bef == ph and x in pending:
-                    HaloExchanger.wait(pending.pop(x))
-            check(L.esdg_rhs_phase_lsrk(ctx, ph, C.c_void_p(Qd.data_ptr()), C.c_void_p(resd.data_ptr()), float(a), float(b), float(dt), s))
-            for x, (aft, bef, _) in enumerate(self.xinfo):
-                if aft == ph:
-                    pending[x] = self.halo.start(self.ws, x)
+        self._phases(lambda ph: check(L.esdg_rhs_phase_lsrk(ctx, ph, q, r, a, b, dt, self._stream())),
+                     lambda ph, e0, n: check(L.esdg_rhs_phase_range_lsrk(ctx, ph, e0, n, q, r, a, b, dt, self._stream())))
 
     def lsrk45_step_fused(self, Qd, resd, dt, coeffs):
         rk4a, rk4b = coeffs[0], coeffs[1]

@@ -220,6 +220,19 @@ int esdg_exchange_info(const esdg_ctx* ctx, int xch, int32_t* after_phase, int32
 int esdg_halo_segment(const esdg_ctx* ctx, int xch, int nbr, int32_t* peer, size_t* send_off,
                       size_t* send_bytes, size_t* recv_off, size_t* recv_bytes);
 
+/* Overlap of the exchanges with computation.  [e_begin, e_end) is the longest run of local elements that touch no
+ * ghost slot ("interior"; the rest is "boundary").  esdg_rhs_phase_range runs one phase on an element range WITHOUT
+ * packing; esdg_halo_pack packs exchange `xch` once its producing phase has run on all boundary elements.  Schedule
+ * (RhsEngine.rhs_into): phase 0 on the boundary ranges, pack + start exchange, phase 0 on the interior; every later
+ * phase p: interior first (overlaps the incoming exchange), wait, boundary ranges, pack + start the exchange produced
+ * by p.  Tensor / hex kernels only. */
+int esdg_interior_range(const esdg_ctx* ctx, int64_t* e_begin, int64_t* e_end);
+int esdg_rhs_phase_range(esdg_ctx* ctx, int phase, int64_t e_begin, int64_t e_count, const double* Q_dev, double* rhs_dev,
+                         void* stream);
+int esdg_rhs_phase_range_lsrk(esdg_ctx* ctx, int phase, int64_t e_begin, int64_t e_count, double* Q_dev, double* resQ_dev,
+                              double a, double b, double dt, void* stream);
+int esdg_halo_pack(esdg_ctx* ctx, int xch, void* stream);
+
 /* Host-only construction of the same plan (no GPU needed; used by the gloo CPU tests and by
  * hosts that want to inspect the partition).  mapP: (Nfq x K) 1-based GLOBAL indices of the local
  * elements.  Offsets/counts are in face nodes; ghost slot g lives at local index K*Nfq + g. */
