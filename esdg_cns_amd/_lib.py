@@ -87,6 +87,14 @@ SYMBOLS = {
     "esdg_lsrk_update": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_int64, _vp]),
     "esdg_axpy_stages": (C.c_int, [_vp, _vp, C.POINTER(_vp), c_double_p, C.c_int, C.c_double, C.c_int64, _vp]),
     "esdg_dopri_error": (C.c_int, [_vp, C.POINTER(_vp), c_double_p, C.c_int, C.c_double, C.c_int64, c_double_p, _vp]),
+    "esdg_setup_uniform_quad_mesh": (C.c_int, [C.c_int, C.c_int, c_double_p, c_double_p, c_int64_p]),
+    "esdg_setup_quad": (C.c_int, [C.c_int, C.c_int, c_double_p, c_double_p, C.c_int64, c_int64_p, C.c_int64, C.c_int, C.c_int64,
+                                  C.c_int64, C.POINTER(_vp)]),
+    "esdg_setup_array": (c_double_p, [_vp, C.c_char_p, c_int64_p, c_int64_p]),
+    "esdg_setup_map": (c_int64_p, [_vp, C.c_char_p, c_int64_p]),
+    "esdg_setup_fill": (C.c_int, [_vp, C.POINTER(esdg_ops_t), C.POINTER(esdg_mesh_t)]),
+    "esdg_setup_destroy": (C.c_int, [_vp]),
+    "esdg_setup_last_error": (C.c_char_p, []),
     "esdg_dmalloc": (_vp, [C.c_size_t]),
     "esdg_dfree": (C.c_int, [_vp]),
     "esdg_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),

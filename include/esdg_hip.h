@@ -260,6 +260,29 @@ int esdg_axpy_stages(double* y_dev, const double* x0_dev, const double* const* k
 int esdg_dopri_error(const double* Q_dev, const double* const* k_dev, const double* coefE, int nstages,
                      double tol, int64_t n, double* result_host, void* stream);
 
+/* ---- set-up for hosts without a SetupDG of their own (host-only code, no GPU needed) ------------------------------
+ * esdg_setup_quad builds, for elements [e_begin, e_end) of a quad mesh (e_end <= 0: all), everything a reference
+ * driver holds when it enters its time loop: RefElemData of init_reference_quad(N) with the default Gauss rule
+ * (src/SetupDG.jl:205-268), MeshData of init_mesh (:271-318; connectivity is always global, mapP holds global 1-based
+ * indices), optionally the periodic patch of examples/dg2D_euler_quad.jl:38-44, the driver-level operators
+ * (formulation 0: dg2D_euler_quad.jl:47-91; 1/2: CompressibleNS/dg2D_CNS_cavity_optimized.jl:62-90) and the metrics
+ * interpolated to the hybrid nodes.  EToV is (K x 4) column-major, 1-based, vertex order of
+ * uniform_quad_mesh (src/UniformQuadMesh.jl:25-50), which esdg_setup_uniform_quad_mesh reproduces on [-1,1]^2
+ * (VX, VY: (Kx+1)(Ky+1) doubles, EToV: 4*Kx*Ky int64, caller-allocated).
+ * Arrays by name (column-major; rows/cols returned): r s V1 Dr Ds rf sf wf nrJ nsJ rq sq wq Vq M Pq Vf LIFT
+ *   Qrhskew Qshskew Ef Vh Ph Lf|VhP   x y xf yf xq yq rxJ sxJ ryJ syJ (Nh x K) J wJq nxJ nyJ sJ;
+ * maps by name (1-based): FToF mapM mapP mapB.  esdg_setup_fill points an esdg_ops_t / esdg_mesh_t pair into the
+ * set-up object (self-mapped boundary nodes become walls, bkind = 1 on the y = ymax side), ready for esdg_create. */
+typedef struct esdg_setup esdg_setup;
+int esdg_setup_uniform_quad_mesh(int Kx, int Ky, double* VX, double* VY, int64_t* EToV);
+int esdg_setup_quad(int N, int formulation, const double* VX, const double* VY, int64_t Nv, const int64_t* EToV, int64_t K,
+                    int periodic, int64_t e_begin, int64_t e_end, esdg_setup** out);
+const double* esdg_setup_array(const esdg_setup* s, const char* name, int64_t* rows, int64_t* cols);
+const int64_t* esdg_setup_map(const esdg_setup* s, const char* name, int64_t* n);
+int esdg_setup_fill(const esdg_setup* s, esdg_ops_t* ops, esdg_mesh_t* mesh);
+int esdg_setup_destroy(esdg_setup* s);
+const char* esdg_setup_last_error(void);
+
 /* ---- plain device-memory helpers for hosts without a GPU array package (Julia ccall) ---- */
 void* esdg_dmalloc(size_t bytes);
 int esdg_dfree(void* p);

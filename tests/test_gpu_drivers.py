@@ -129,3 +129,44 @@ def test_shocktube_driver_tracks_the_exact_viscous_shock():
     rate = math.log2(e1 / e2)
     print(f"Becker shock tube N=2, T=0.05: L2 error K1D=32 {e1:.3e}, K1D=64 {e2:.3e} (rate {rate:.2f}); Linf {i1:.2e} -> {i2:.2e}")
     assert rate > 2.0 and e2 < 5e-3     # measured: 1.76e-2 -> 2.51e-3 (rate 2.8); N=3: 4.1e-3 -> 2.0e-4 (rate 4.4)
+
+
+def test_pure_c_driver_on_the_c_abi_matches_python_path(tmp_path):
+    """examples/c/dg2D_euler_quad.c: set-up (esdg_setup_*), engine and LSRK45 loop through the C ABI only, built with
+    gcc against libesdg_hip.so and run as a child process; same numbers as the Python host path."""
+    import subprocess
+    import torch
+    from esdg_cns_amd import engine, physics as ph, setup_dg as sd, timestep
+    exe = str(tmp_path / "euler_quad_c")
+    lib = os.path.join(ROOT, "esdg_cns_amd")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c", "dg2D_euler_quad.c"),
+                           "-o", exe, "-L", lib, "-lesdg_hip", "-lm", "-Wl,-rpath," + lib])
+    N, K1D, T = 3, 9, 0.25
+    out = subprocess.check_output([exe, str(N), str(K1D), str(T)], text=True)
+    print(out.strip())
+    vals = dict(kv.split("=") for kv in out.split() if "=" in kv)
+    # the same run through the Python host mirror
+    Kx, Ky = 4 * K1D // 3, K1D
+    VX, VY, EToV = sd.uniform_quad_mesh(Kx, Ky)
+    VX, VY = 15 * (1 + VX) / 2, 5 * VY
+    rd = sd.init_reference_quad(N, sd.gauss_quad(0, 0, N))
+    md = sd.init_mesh((VX, VY), EToV, rd)
+    sd.make_periodic(md, rd)
+    ops = sd.euler_quad_ops(rd)
+    sd.interp_geofacs_to_hybrid(md, ops["Vh"])
+    Q = ph.primitive_to_conservative(*ph.vortex(md.xq, md.yq, 0))
+    CN = (N + 1) * (N + 2) / 2
+    dt = 2.0 * (2 / K1D) / CN
+    nsteps = int(np.ceil(T / dt))
+    dt = T / nsteps
+    eng = engine.RhsEngine(rd, md, ops, engine.EULER_COLLOCATED)
+    Qd = eng.upload(Q)
+    timestep.lsrk45_run(eng, Qd, dt, nsteps)
+    Qn = eng.download(Qd)
+    Qex = ph.primitive_to_conservative(*ph.vortex(md.xq, md.yq, T))
+    err = np.sqrt(sum(np.sum(md.wJq * (a - b) ** 2) for a, b in zip(Qn, Qex)))
+    integral = sum(np.sum(md.wJq * a) for a in Qn)
+    assert int(vals["steps"]) == nsteps
+    assert abs(float(vals["L2err_gauss"]) - err) <= 1e-9 * max(err, 1e-12) + 1e-13
+    assert abs(float(vals["integral"]) - integral) <= 1e-11 * abs(integral)
+    assert float(vals["rhstest"]) <= 1e-12
