@@ -15,7 +15,8 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from common import product_cns_problem, product_euler_problem, product_hex_problem  # noqa: E402
+from common import (becker_constants, product_cavity_problem, product_cns_problem, product_euler_problem,  # noqa: E402
+                    product_hex_problem, product_shocktube_problem)
 from esdg_cns_amd import engine  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -36,6 +37,17 @@ if args.formulation == "hex":
     offs = [layer * 4 * r for r in range(world + 1)]
     build = lambda er: product_hex_problem(N, *dims, elem_range=er)
     form, kw = engine.EULER_HEX_COLLOCATED, dict(lf_scale=0.25)
+elif args.formulation in ("cavity", "shocktube"):
+    N, Kx, Ky = 3, 8, 4 * world
+    offs = [Kx * 4 * r for r in range(world + 1)]
+    if args.formulation == "cavity":                      # walls + lid, BCTYPE 2, penalty on
+        build = lambda er: product_cavity_problem(N, Kx, Ky, elem_range=er)
+        form, kw = engine.CNS_MODAL, dict(BCTYPE=2)
+    else:                                                 # Dirichlet inflow / copy outflow, periodic in y (the sharded direction)
+        st = becker_constants()
+        build = lambda er: product_shocktube_problem(N, Kx, Ky, elem_range=er)
+        form, kw = engine.CNS_MODAL, dict(BCTYPE=4, viscous_dissp=False, mu=st["mu"], lam=st["lam"], Pr=st["Pr"],
+                                          inflow=(st["rhoL"], st["uL"], st["vL"], st["pL"]))
 else:
     N, Kx, Ky = 4, 12, 3 * world
     offs = [Kx * 3 * r for r in range(world + 1)]
