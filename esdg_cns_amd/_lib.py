@@ -93,6 +93,10 @@ SYMBOLS = {
     "esdg_setup_array": (c_double_p, [_vp, C.c_char_p, c_int64_p, c_int64_p]),
     "esdg_setup_map": (c_int64_p, [_vp, C.c_char_p, c_int64_p]),
     "esdg_setup_fill": (C.c_int, [_vp, C.POINTER(esdg_ops_t), C.POINTER(esdg_mesh_t)]),
+    "esdg_setup_uniform_hex_mesh": (C.c_int, [C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_int64_p]),
+    "esdg_setup_hex": (C.c_int, [C.c_int, c_double_p, c_double_p, c_double_p, C.c_int64, c_int64_p, C.c_int64, C.c_int, C.c_int64,
+                                 C.c_int64, C.POINTER(_vp)]),
+    "esdg_setup_fill_hex": (C.c_int, [_vp, C.POINTER(esdg_hex_ops_t), C.POINTER(esdg_hex_mesh_t)]),
     "esdg_setup_destroy": (C.c_int, [_vp]),
     "esdg_setup_last_error": (C.c_char_p, []),
     "esdg_dmalloc": (_vp, [C.c_size_t]),

@@ -537,3 +537,347 @@ int esdg_setup_destroy(esdg_setup* s) {
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// hexahedra: init_reference_hex (src/SetupDG.jl:323-387), init_mesh 3D (:389-434), uniform_hex_mesh
+// (src/UniformHexMesh.jl:25-80), 3D periodic patch (src/node_map_functions.jl:139-213) and the operator assembly of
+// examples/dg3D_euler_hex.jl:34-98 -- with the INTENDED face-vertex sets, mirroring
+// esdg_cns_amd/setup_dg.py:init_reference_hex / init_mesh_3d / hex_ops / hex_driver_geometry.
+// =====================================================================================================================
+namespace {
+
+void reference_hex(int N, std::map<std::string, Mat>& A) {
+  const int n1 = N + 1, nq1 = N + 1, Np = n1 * n1 * n1, Nq = nq1 * nq1 * nq1, nf = nq1 * nq1, Nfq = 6 * nf;
+  std::vector<double> x1 = gauss_lobatto(N), r1D, w1D;
+  gauss_legendre(nq1, r1D, w1D);
+  Mat D1 = lagrange_diff(x1), Iq = lagrange_interp(x1, r1D);
+  Mat r(Np, 1), s(Np, 1), t(Np, 1), Dr(Np, Np), Ds(Np, Np), Dt(Np, Np), V1(Np, 8);
+  for (int k = 0; k < n1; ++k)
+    for (int j = 0; j < n1; ++j)
+      for (int i = 0; i < n1; ++i) {
+        const int n = i + n1 * (j + n1 * k);
+        s(n, 0) = x1[i]; r(n, 0) = x1[j]; t(n, 0) = x1[k];
+        for (int m = 0; m < n1; ++m) {
+          Ds(n, m + n1 * (j + n1 * k)) = D1(i, m);
+          Dr(n, i + n1 * (m + n1 * k)) = D1(j, m);
+          Dt(n, i + n1 * (j + n1 * m)) = D1(k, m);
+        }
+        for (int v = 0; v < 8; ++v) {
+          const double sv = 2.0 * (v % 2) - 1, rv = 2.0 * ((v / 2) % 2) - 1, tv = 2.0 * (v / 4) - 1;
+          V1(n, v) = 0.125 * (1 + x1[j] * rv) * (1 + x1[i] * sv) * (1 + x1[k] * tv);
+        }
+      }
+  Mat rf(Nfq, 1), sf(Nfq, 1), tf(Nfq, 1), wf(Nfq, 1), nrJ(Nfq, 1), nsJ(Nfq, 1), ntJ(Nfq, 1);
+  for (int m = 0; m < nf; ++m) {
+    const double rq_ = r1D[m / nq1], sq_ = r1D[m % nq1], w = w1D[m / nq1] * w1D[m % nq1];
+    const double R[6] = {-1, 1, rq_, rq_, rq_, rq_}, S_[6] = {rq_, rq_, -1, 1, sq_, sq_}, T[6] = {sq_, sq_, sq_, sq_, -1, 1};
+    for (int f = 0; f < 6; ++f) {
+      rf(f * nf + m, 0) = R[f]; sf(f * nf + m, 0) = S_[f]; tf(f * nf + m, 0) = T[f]; wf(f * nf + m, 0) = w;
+    }
+    nrJ(m, 0) = -1; nrJ(nf + m, 0) = 1; nsJ(2 * nf + m, 0) = -1; nsJ(3 * nf + m, 0) = 1; ntJ(4 * nf + m, 0) = -1; ntJ(5 * nf + m, 0) = 1;
+  }
+  Mat rq(Nq, 1), sq(Nq, 1), tq(Nq, 1), wq(Nq, 1), Vq(Nq, Np);
+  for (int k = 0; k < nq1; ++k)
+    for (int j = 0; j < nq1; ++j)
+      for (int i = 0; i < nq1; ++i) {
+        const int q = i + nq1 * (j + nq1 * k);
+        sq(q, 0) = r1D[i]; rq(q, 0) = r1D[j]; tq(q, 0) = r1D[k]; wq(q, 0) = w1D[i] * w1D[j] * w1D[k];
+        for (int kk = 0; kk < n1; ++kk)
+          for (int jj = 0; jj < n1; ++jj)
+            for (int ii = 0; ii < n1; ++ii) Vq(q, ii + n1 * (jj + n1 * kk)) = Iq(k, kk) * Iq(j, jj) * Iq(i, ii);
+      }
+  Mat WVq(Nq, Np);
+  for (int q = 0; q < Nq; ++q)
+    for (int n = 0; n < Np; ++n) WVq(q, n) = wq(q, 0) * Vq(q, n);
+  Mat M = mul(tr(Vq), WVq);
+  Mat Pq = solve(M, tr(WVq));
+  Mat Ls = lagrange_interp(x1, sf.a), Lr = lagrange_interp(x1, rf.a), Lt = lagrange_interp(x1, tf.a), Vf(Nfq, Np);
+  for (int f = 0; f < Nfq; ++f)
+    for (int k = 0; k < n1; ++k)
+      for (int j = 0; j < n1; ++j)
+        for (int i = 0; i < n1; ++i) Vf(f, i + n1 * (j + n1 * k)) = Lt(f, k) * Lr(f, j) * Ls(f, i);
+  Mat VfW = tr(Vf);
+  for (int n = 0; n < Np; ++n)
+    for (int f = 0; f < Nfq; ++f) VfW(n, f) *= wf(f, 0);
+  Mat LIFT = solve(M, VfW);
+  droptol(Dr, 1e-12); droptol(Ds, 1e-12); droptol(Dt, 1e-12); droptol(Vf, 1e-12); droptol(LIFT, 1e-12);
+  A["r"] = r; A["s"] = s; A["t"] = t; A["V1"] = V1; A["Dr"] = Dr; A["Ds"] = Ds; A["Dt"] = Dt;
+  A["rf"] = rf; A["sf"] = sf; A["tf"] = tf; A["wf"] = wf; A["nrJ"] = nrJ; A["nsJ"] = nsJ; A["ntJ"] = ntJ;
+  A["rq"] = rq; A["sq"] = sq; A["tq"] = tq; A["wq"] = wq; A["Vq"] = Vq; A["M"] = M; A["Pq"] = Pq; A["Vf"] = Vf; A["LIFT"] = LIFT;
+}
+
+// dg3D_euler_hex.jl:34-56, 92-98
+void hex_driver_ops(std::map<std::string, Mat>& A) {
+  const Mat &M = A["M"], &Pq = A["Pq"], &Vf = A["Vf"], &wf = A["wf"], &wq = A["wq"];
+  const int64_t Nq = A["Vq"].r, Nfq = Vf.r, Nh = Nq + Nfq;
+  Mat Ef = mul(Vf, Pq), PtM = mul(tr(Pq), M);
+  const char* dn[3] = {"Dr", "Ds", "Dt"};
+  const char* nn[3] = {"nrJ", "nsJ", "ntJ"};
+  const char* on[3] = {"Qrhskew", "Qshskew", "Qthskew"};
+  for (int d = 0; d < 3; ++d) {
+    Mat Q = mul(mul(PtM, A[dn[d]]), Pq);
+    const Mat& nJ = A[nn[d]];
+    Mat Qh(Nh, Nh);
+    for (int64_t i = 0; i < Nq; ++i)
+      for (int64_t j = 0; j < Nq; ++j) Qh(i, j) = .5 * (Q(i, j) - Q(j, i));
+    for (int64_t i = 0; i < Nq; ++i)
+      for (int64_t f = 0; f < Nfq; ++f) {
+        const double b = wf(f, 0) * nJ(f, 0);
+        Qh(i, Nq + f) = .5 * Ef(f, i) * b;
+        Qh(Nq + f, i) = -.5 * b * Ef(f, i);
+      }
+    for (int64_t f = 0; f < Nfq; ++f) Qh(Nq + f, Nq + f) = .5 * wf(f, 0) * nJ(f, 0);
+    Mat S(Nh, Nh);
+    for (int64_t i = 0; i < Nh; ++i)
+      for (int64_t j = 0; j < Nh; ++j) S(i, j) = .5 * (Qh(i, j) - Qh(j, i));
+    A[on[d]] = S;
+  }
+  Mat Vh(Nh, Nq);
+  for (int64_t q = 0; q < Nq; ++q) Vh(q, q) = 1.0;
+  for (int64_t f = 0; f < Nfq; ++f)
+    for (int64_t q = 0; q < Nq; ++q) Vh(Nq + f, q) = Ef(f, q);
+  droptol(Vh, 1e-12);
+  Mat Ph(Nq, Nh), Lf(Nq, Nfq);
+  for (int64_t q = 0; q < Nq; ++q) {
+    for (int64_t j = 0; j < Nh; ++j) Ph(q, j) = 2 * Vh(j, q) / wq(q, 0);      // the factor 2 of :96
+    for (int64_t f = 0; f < Nfq; ++f) Lf(q, f) = Ef(f, q) * wf(f, 0) / wq(q, 0);
+  }
+  droptol(Ph, 1e-12); droptol(Lf, 1e-12);
+  A["Ef"] = Ef; A["Vh"] = Vh; A["Ph"] = Ph; A["Lf"] = Lf;
+}
+
+struct Face4 { int64_t v[4]; int64_t id; };
+
+}  // namespace
+
+extern "C" {
+
+int esdg_setup_uniform_hex_mesh(int Kx, int Ky, int Kz, double* VX, double* VY, double* VZ, int64_t* EToV) {
+  if (Kx < 1 || Ky < 1 || Kz < 1 || !VX || !VY || !VZ || !EToV) return sfail("bad uniform hex mesh arguments");
+  const int64_t Nxp = Kx + 1, Nyp = Ky + 1, Nzp = Kz + 1, K = (int64_t)Kx * Ky * Kz;
+  for (int64_t k = 0; k < Nzp; ++k)
+    for (int64_t j = 0; j < Nyp; ++j)
+      for (int64_t i = 0; i < Nxp; ++i) {
+        const int64_t v = i + Nxp * (j + Nyp * k);
+        VX[v] = i == Nxp - 1 ? 1.0 : -1.0 + i * (2.0 / Kx);
+        VY[v] = j == Nyp - 1 ? 1.0 : -1.0 + j * (2.0 / Ky);
+        VZ[v] = k == Nzp - 1 ? 1.0 : -1.0 + k * (2.0 / Kz);
+      }
+  for (int64_t e = 0; e < K; ++e) {
+    const int64_t k = e / ((int64_t)Kx * Ky), j = (e - k * Kx * Ky) / Kx, i = e % Kx;
+    const int64_t v0 = i + Nxp * j + Nxp * Nyp * k + 1;
+    const int64_t off[8] = {0, 1, Nxp, Nxp + 1, Nxp * Nyp, Nxp * Nyp + 1, Nxp * Nyp + Nxp, Nxp * Nyp + Nxp + 1};
+    for (int v = 0; v < 8; ++v) EToV[(size_t)v * K + e] = v0 + off[v];
+  }
+  return ESDG_OK;
+}
+
+int esdg_setup_hex(int N, const double* VX, const double* VY, const double* VZ, int64_t Nv, const int64_t* EToV, int64_t Kg,
+                   int periodic, int64_t e_begin, int64_t e_end, esdg_setup** out) {
+  if (!out) return sfail("null output");
+  *out = nullptr;
+  if (N < 1 || N > 3 || !VX || !VY || !VZ || !EToV || Kg < 1 || Nv < 8) return sfail("bad hex set-up arguments");
+  if (e_end <= 0) { e_begin = 0; e_end = Kg; }
+  if (e_begin < 0 || e_end > Kg || e_begin >= e_end) return sfail("bad element range");
+  esdg_setup* S = new esdg_setup();
+  S->N = N; S->formulation = ESDG_EULER_HEX_COLLOCATED; S->Kglobal = Kg; S->e0 = e_begin; S->K = e_end - e_begin;
+  auto& A = S->arr;
+  reference_hex(N, A);
+  hex_driver_ops(A);
+  const int64_t K = S->K, e0 = e_begin;
+  const Mat &V1 = A["V1"], &Vf = A["Vf"], &Vq = A["Vq"], &Dr = A["Dr"], &Ds = A["Ds"], &Dt = A["Dt"];
+  const int Np = (int)V1.r, Nfq = (int)Vf.r, Nfp = Nfq / 6, Nq = (int)Vq.r;
+  const double* VV[3] = {VX, VY, VZ};
+  auto ev = [&](int64_t e, int v) { return EToV[(size_t)v * Kg + e] - 1; };
+  for (int64_t e = 0; e < Kg; ++e)
+    for (int v = 0; v < 8; ++v)
+      if (ev(e, v) < 0 || ev(e, v) >= Nv) { delete S; return sfail("EToV entry out of range"); }
+
+  // connect_mesh with the intended hex_face_vertices (0-based here)
+  const int fv[6][4] = {{0, 1, 4, 5}, {2, 3, 6, 7}, {0, 2, 4, 6}, {1, 3, 5, 7}, {0, 1, 2, 3}, {4, 5, 6, 7}};
+  std::vector<Face4> faces((size_t)Kg * 6);
+  for (int64_t e = 0; e < Kg; ++e)
+    for (int f = 0; f < 6; ++f) {
+      Face4 F;
+      for (int m = 0; m < 4; ++m) F.v[m] = ev(e, fv[f][m]);
+      std::sort(F.v, F.v + 4);
+      F.id = e * 6 + f;
+      faces[(size_t)e * 6 + f] = F;
+    }
+  std::vector<Face4> sorted(faces);
+  std::stable_sort(sorted.begin(), sorted.end(), [](const Face4& x, const Face4& y) {
+    for (int m = 0; m < 4; ++m)
+      if (x.v[m] != y.v[m]) return x.v[m] < y.v[m];
+    return false;
+  });
+  std::vector<int64_t> FToF((size_t)Kg * 6);
+  for (size_t i = 0; i < FToF.size(); ++i) FToF[i] = (int64_t)i;
+  for (size_t i = 0; i + 1 < sorted.size(); ++i)
+    if (std::equal(sorted[i].v, sorted[i].v + 4, sorted[i + 1].v)) {
+      FToF[(size_t)sorted[i].id] = sorted[i + 1].id;
+      FToF[(size_t)sorted[i + 1].id] = sorted[i].id;
+    }
+
+  Mat X[3] = {Mat(Np, K), Mat(Np, K), Mat(Np, K)};
+  for (int64_t e = 0; e < K; ++e)
+    for (int n = 0; n < Np; ++n)
+      for (int c = 0; c < 3; ++c) {
+        double sum = 0;
+        for (int v = 0; v < 8; ++v) sum += V1(n, v) * VV[c][ev(e0 + e, v)];
+        X[c](n, e) = sum;
+      }
+  Mat VfV1 = mul(Vf, V1);
+  auto face_xyz = [&](int64_t gf, int i, double* p) {
+    const int64_t e = gf / 6; const int f = (int)(gf % 6);
+    for (int c = 0; c < 3; ++c) {
+      p[c] = 0;
+      for (int v = 0; v < 8; ++v) p[c] += VfV1(f * Nfp + i, v) * VV[c][ev(e, v)];
+    }
+  };
+  std::vector<int64_t> mapM((size_t)K * Nfq), mapP((size_t)K * Nfq);
+  std::vector<double> P1(3 * Nfp), P2(3 * Nfp);
+  for (int64_t lf = 0; lf < K * 6; ++lf) {
+    const int64_t f1 = e0 * 6 + lf, f2 = FToF[(size_t)f1];
+    for (int i = 0; i < Nfp; ++i) { face_xyz(f1, i, &P1[3 * i]); face_xyz(f2, i, &P2[3 * i]); }
+    auto dist = [&](int i, int j) { return std::fabs(P1[3 * i] - P2[3 * j]) + std::fabs(P1[3 * i + 1] - P2[3 * j + 1]) + std::fabs(P1[3 * i + 2] - P2[3 * j + 2]); };
+    double refd = 0;
+    for (int i = 0; i < Nfp; ++i)
+      for (int j = 0; j < Nfp; ++j) refd = std::max(refd, dist(i, j));
+    for (int i = 0; i < Nfp; ++i) {
+      const int64_t m = f1 * Nfp + i + 1;
+      mapM[(size_t)(lf * Nfp + i)] = m;
+      int64_t p = m;
+      if (f2 != f1)
+        for (int j = 0; j < Nfp; ++j)
+          if (dist(i, j) < 1e-10 * refd) { p = f2 * Nfp + j + 1; break; }
+      mapP[(size_t)(lf * Nfp + i)] = p;
+    }
+  }
+  std::vector<int64_t> mapB;
+  for (size_t n = 0; n < mapM.size(); ++n)
+    if (mapM[n] == mapP[n]) mapB.push_back(mapM[n]);
+
+  if (periodic) {   // dg3D_euler_hex.jl:59-65
+    double lo[3], hi[3];
+    for (int c = 0; c < 3; ++c) {
+      lo[c] = hi[c] = VV[c][0];
+      for (int64_t v = 0; v < Nv; ++v) { lo[c] = std::min(lo[c], VV[c][v]); hi[c] = std::max(hi[c], VV[c][v]); }
+    }
+    struct BF { int64_t gf; double c[3]; };
+    std::vector<BF> bf;
+    for (int64_t gf = 0; gf < Kg * 6; ++gf)
+      if (FToF[(size_t)gf] == gf) {
+        BF b{gf, {0, 0, 0}};
+        double p[3];
+        for (int i = 0; i < Nfp; ++i) { face_xyz(gf, i, p); for (int c = 0; c < 3; ++c) b.c[c] += p[c] / Nfp; }
+        bf.push_back(b);
+      }
+    std::map<int64_t, std::pair<int64_t, int>> partner;   // face -> (partner face, normal direction)
+    for (int d = 0; d < 3; ++d) {
+      const int a = d == 0 ? 1 : 0, b = d == 2 ? 1 : 2;
+      const double L = hi[d] - lo[d], La = hi[a] - lo[a], Lb = hi[b] - lo[b];
+      std::vector<BF> flo, fhi;
+      for (const BF& f : bf) {
+        if (std::fabs(f.c[d] - lo[d]) < 1e-12 * L) flo.push_back(f);
+        else if (std::fabs(f.c[d] - hi[d]) < 1e-12 * L) fhi.push_back(f);
+      }
+      auto key = [&](const BF& p, const BF& q) {
+        const double pa = std::round(p.c[a] / La * 1e9), qa = std::round(q.c[a] / La * 1e9);
+        if (pa != qa) return pa < qa;
+        return std::round(p.c[b] / Lb * 1e9) < std::round(q.c[b] / Lb * 1e9);
+      };
+      std::stable_sort(flo.begin(), flo.end(), key);
+      std::stable_sort(fhi.begin(), fhi.end(), key);
+      if (flo.size() != fhi.size()) { delete S; return sfail("periodic boundary faces do not pair up"); }
+      for (size_t i = 0; i < flo.size(); ++i) { partner[flo[i].gf] = {fhi[i].gf, d}; partner[fhi[i].gf] = {flo[i].gf, d}; }
+    }
+    for (size_t n = 0; n < mapM.size(); ++n) {
+      if (mapM[n] != mapP[n]) continue;
+      const int64_t gnode = mapM[n] - 1, gf = gnode / Nfp;
+      auto it = partner.find(gf);
+      if (it == partner.end()) { delete S; return sfail("boundary face off the box"); }
+      const int64_t pf = it->second.first;
+      const int d = it->second.second, a = d == 0 ? 1 : 0, b = d == 2 ? 1 : 2;
+      double p0[3], p1[3];
+      face_xyz(gf, (int)(gnode % Nfp), p0);
+      int64_t p = -1;
+      for (int j = 0; j < Nfp; ++j) {
+        face_xyz(pf, j, p1);
+        if (std::fabs(p0[a] - p1[a]) + std::fabs(p0[b] - p1[b]) < 1e-9 * std::max(hi[a] - lo[a], hi[b] - lo[b])) { p = pf * Nfp + j + 1; break; }
+      }
+      if (p < 0) { delete S; return sfail("periodic node matching failed"); }
+      mapP[n] = p;
+    }
+  }
+
+  // geometric factors (curl form, src/geometric_factors.jl:34-67), normals, then the driver's post-processing (:88-98)
+  const Mat &x = X[0], &y = X[1], &z = X[2];
+  auto had = [](const Mat& a_, const Mat& b_) { Mat c_(a_.r, a_.c); for (size_t i = 0; i < c_.a.size(); ++i) c_.a[i] = a_.a[i] * b_.a[i]; return c_; };
+  auto sub = [](const Mat& a_, const Mat& b_, double sgn) { Mat c_(a_.r, a_.c); for (size_t i = 0; i < c_.a.size(); ++i) c_.a[i] = sgn * (a_.a[i] - b_.a[i]); return c_; };
+  auto curl = [&](const Mat& u, const Mat& w, double sgn, Mat& gr, Mat& gs, Mat& gt) {
+    Mat Fr = had(mul(Dr, u), w), Fs = had(mul(Ds, u), w), Ft = had(mul(Dt, u), w);
+    gr = sub(mul(Dt, Fs), mul(Ds, Ft), sgn);
+    gs = sub(mul(Dr, Ft), mul(Dt, Fr), sgn);
+    gt = sub(mul(Ds, Fr), mul(Dr, Fs), sgn);
+  };
+  Mat g[9];   // rxJ sxJ txJ ryJ syJ tyJ rzJ szJ tzJ
+  curl(y, z, 1.0, g[0], g[1], g[2]);
+  curl(x, z, -1.0, g[3], g[4], g[5]);
+  curl(y, x, -1.0, g[6], g[7], g[8]);
+  Mat xr = mul(Dr, x), xs = mul(Ds, x), xt = mul(Dt, x), yr = mul(Dr, y), ys = mul(Ds, y), yt = mul(Dt, y),
+      zr = mul(Dr, z), zs = mul(Ds, z), zt = mul(Dt, z);
+  Mat J(Np, K);
+  for (size_t i = 0; i < J.a.size(); ++i)
+    J.a[i] = xr.a[i] * (ys.a[i] * zt.a[i] - zs.a[i] * yt.a[i]) - yr.a[i] * (xs.a[i] * zt.a[i] - zs.a[i] * xt.a[i]) +
+             zr.a[i] * (xs.a[i] * yt.a[i] - ys.a[i] * xt.a[i]);
+  Mat fg[9];
+  for (int m = 0; m < 9; ++m) fg[m] = mul(Vf, g[m]);
+  Mat nxJ(Nfq, K), nyJ(Nfq, K), nzJ(Nfq, K), sJ(Nfq, K);
+  for (int64_t e = 0; e < K; ++e)
+    for (int f = 0; f < Nfq; ++f) {
+      const double nr = A["nrJ"](f, 0), ns = A["nsJ"](f, 0), nt = A["ntJ"](f, 0);
+      nxJ(f, e) = nr * fg[0](f, e) + ns * fg[1](f, e) + nt * fg[2](f, e);
+      nyJ(f, e) = nr * fg[3](f, e) + ns * fg[4](f, e) + nt * fg[5](f, e);
+      nzJ(f, e) = nr * fg[6](f, e) + ns * fg[7](f, e) + nt * fg[8](f, e);
+      sJ(f, e) = std::sqrt(nxJ(f, e) * nxJ(f, e) + nyJ(f, e) * nyJ(f, e) + nzJ(f, e) * nzJ(f, e));
+    }
+  const int64_t Nh = Nq + Nfq;
+  Mat Vhg(Nh, Np);
+  for (int n = 0; n < Np; ++n) {
+    for (int q = 0; q < Nq; ++q) Vhg(q, n) = Vq(q, n);
+    for (int f = 0; f < Nfq; ++f) Vhg(Nq + f, n) = Vf(f, n);
+  }
+  const char* gn[9] = {"rxJ", "sxJ", "txJ", "ryJ", "syJ", "tyJ", "rzJ", "szJ", "tzJ"};
+  for (int m = 0; m < 9; ++m) A[gn[m]] = mul(Vhg, g[m]);
+  Mat Jq = mul(Vq, J), wJq(Nq, K);
+  for (int64_t e = 0; e < K; ++e)
+    for (int q = 0; q < Nq; ++q) wJq(q, e) = A["wq"](q, 0) * Jq(q, e);
+  A["x"] = x; A["y"] = y; A["z"] = z; A["xq"] = mul(Vq, x); A["yq"] = mul(Vq, y); A["zq"] = mul(Vq, z);
+  A["xf"] = mul(Vf, x); A["yf"] = mul(Vf, y); A["zf"] = mul(Vf, z);
+  A["J"] = Jq; A["wJq"] = wJq; A["nxJ"] = nxJ; A["nyJ"] = nyJ; A["nzJ"] = nzJ; A["sJ"] = sJ;
+  std::vector<int64_t> FToFl((size_t)K * 6);
+  for (int64_t lf = 0; lf < K * 6; ++lf) FToFl[(size_t)lf] = FToF[(size_t)(e0 * 6 + lf)] + 1;
+  S->maps["FToF"] = FToFl; S->maps["mapM"] = mapM; S->maps["mapP"] = mapP; S->maps["mapB"] = mapB;
+  *out = S;
+  return ESDG_OK;
+}
+
+int esdg_setup_fill_hex(const esdg_setup* s, esdg_hex_ops_t* ops, esdg_hex_mesh_t* mesh) {
+  if (!s || !ops || !mesh || s->formulation != ESDG_EULER_HEX_COLLOCATED) return sfail("not a hex set-up");
+  auto g = [&](const char* n) -> const double* { auto it = s->arr.find(n); return it == s->arr.end() ? nullptr : it->second.a.data(); };
+  std::memset(ops, 0, sizeof *ops);
+  std::memset(mesh, 0, sizeof *mesh);
+  const int N1 = s->N + 1;
+  ops->N = s->N; ops->Nq = N1 * N1 * N1; ops->Nfq = 6 * N1 * N1;
+  ops->Qrhskew = g("Qrhskew"); ops->Qshskew = g("Qshskew"); ops->Qthskew = g("Qthskew"); ops->Ph = g("Ph"); ops->Lf = g("Lf");
+  ops->Ef = g("Ef"); ops->wq = g("wq"); ops->wf = g("wf");
+  mesh->K = s->K; mesh->geo_ld = ops->Nq + ops->Nfq;
+  mesh->rxJ = g("rxJ"); mesh->sxJ = g("sxJ"); mesh->txJ = g("txJ"); mesh->ryJ = g("ryJ"); mesh->syJ = g("syJ"); mesh->tyJ = g("tyJ");
+  mesh->rzJ = g("rzJ"); mesh->szJ = g("szJ"); mesh->tzJ = g("tzJ"); mesh->J = g("J"); mesh->wJq = g("wJq");
+  mesh->nxJ = g("nxJ"); mesh->nyJ = g("nyJ"); mesh->nzJ = g("nzJ"); mesh->sJ = g("sJ");
+  mesh->mapP = s->maps.at("mapP").data();
+  mesh->elem_offset = s->e0; mesh->Kglobal = s->Kglobal; mesh->nranks = 1; mesh->rank = 0; mesh->rank_offsets = nullptr;
+  return ESDG_OK;
+}
+
+}  // extern "C"

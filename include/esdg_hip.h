@@ -280,6 +280,15 @@ int esdg_setup_quad(int N, int formulation, const double* VX, const double* VY, 
 const double* esdg_setup_array(const esdg_setup* s, const char* name, int64_t* rows, int64_t* cols);
 const int64_t* esdg_setup_map(const esdg_setup* s, const char* name, int64_t* n);
 int esdg_setup_fill(const esdg_setup* s, esdg_ops_t* ops, esdg_mesh_t* mesh);
+/* Hexahedra: init_reference_hex (src/SetupDG.jl:323-387), init_mesh 3D (:389-434) with the intended hex_face_vertices
+ * (DESIGN.md section 9), uniform_hex_mesh (src/UniformHexMesh.jl:25-80), the periodic patch and the operators /
+ * geometry post-processing of examples/dg3D_euler_hex.jl:34-98.  EToV is (K x 8) column-major, 1-based.  Arrays as for
+ * quads plus t tf tq Dt ntJ Qthskew z zf zq txJ tyJ rzJ szJ tzJ nzJ (metrics at the hybrid nodes, J at the quadrature
+ * nodes). */
+int esdg_setup_uniform_hex_mesh(int Kx, int Ky, int Kz, double* VX, double* VY, double* VZ, int64_t* EToV);
+int esdg_setup_hex(int N, const double* VX, const double* VY, const double* VZ, int64_t Nv, const int64_t* EToV, int64_t K,
+                   int periodic, int64_t e_begin, int64_t e_end, esdg_setup** out);
+int esdg_setup_fill_hex(const esdg_setup* s, esdg_hex_ops_t* ops, esdg_hex_mesh_t* mesh);
 int esdg_setup_destroy(esdg_setup* s);
 const char* esdg_setup_last_error(void);
 

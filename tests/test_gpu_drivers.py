@@ -170,3 +170,18 @@ def test_pure_c_driver_on_the_c_abi_matches_python_path(tmp_path):
     assert abs(float(vals["L2err_gauss"]) - err) <= 1e-9 * max(err, 1e-12) + 1e-13
     assert abs(float(vals["integral"]) - integral) <= 1e-11 * abs(integral)
     assert float(vals["rhstest"]) <= 1e-12
+
+
+def test_pure_c_hex_driver(tmp_path):
+    """examples/c/dg3D_euler_hex.c: the hex script on the C ABI alone (C set-up with the intended face-vertex sets,
+    esdg_create_hex, one rhs, `@show rhstest`): entropy conservative to round-off."""
+    import subprocess
+    exe = str(tmp_path / "euler_hex_c")
+    lib = os.path.join(ROOT, "esdg_cns_amd")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c", "dg3D_euler_hex.c"),
+                           "-o", exe, "-L", lib, "-lesdg_hip", "-lm", "-Wl,-rpath," + lib])
+    out = subprocess.check_output([exe, "3", "4"], text=True)
+    print(out.strip())
+    vals = dict(kv.split("=") for kv in out.split() if "=" in kv)
+    assert vals["fields"] == "5" and float(vals["max|rhs|"]) > 1e-3
+    assert abs(float(vals["rhstest"])) < 1e-11

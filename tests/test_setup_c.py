@@ -103,3 +103,72 @@ def test_setup_quad_element_range():
         assert np.abs(_arr(h, "J") - full.J[:, e0:e1]).max() < 1e-13
     finally:
         _lib.lib().esdg_setup_destroy(h)
+
+
+# ---- hexahedra ---------------------------------------------------------------------------------------------------
+def _setup_hex(N, VX, VY, VZ, EToV, periodic, er=None):
+    L = _lib.lib()
+    v = [np.ascontiguousarray(a, dtype=np.float64) for a in (VX, VY, VZ)]
+    et = np.asfortranarray(EToV.astype(np.int64))
+    h = C.c_void_p()
+    e0, e1 = er if er else (0, 0)
+    rc = L.esdg_setup_hex(N, *[a.ctypes.data_as(_lib.c_double_p) for a in v], v[0].size, et.ctypes.data_as(_lib.c_int64_p),
+                          EToV.shape[0], int(periodic), e0, e1, C.byref(h))
+    assert rc == 0, L.esdg_setup_last_error().decode()
+    return h
+
+
+def test_uniform_hex_mesh_matches():
+    L = _lib.lib()
+    for K3 in ((2, 2, 2), (3, 2, 4)):
+        VX, VY, VZ, E = sd.uniform_hex_mesh(*K3)
+        v = [np.zeros(VX.size) for _ in range(3)]
+        et = np.zeros((E.shape[0], 8), dtype=np.int64, order="F")
+        assert L.esdg_setup_uniform_hex_mesh(*K3, *[a.ctypes.data_as(_lib.c_double_p) for a in v], et.ctypes.data_as(_lib.c_int64_p)) == 0
+        assert np.array_equal(et, E) and all(np.allclose(a, b, atol=1e-15) for a, b in zip(v, (VX, VY, VZ)))
+
+
+@pytest.mark.parametrize("N,K3,periodic", [(1, (2, 2, 2), True), (2, (3, 2, 2), True), (3, (2, 3, 2), True), (2, (2, 2, 3), False)])
+def test_setup_hex_matches_python_mirror(N, K3, periodic):
+    VX, VY, VZ, EToV = sd.uniform_hex_mesh(*K3)
+    rd = sd.init_reference_hex(N)
+    md = sd.init_mesh_3d((VX, VY, VZ), EToV, rd)
+    if periodic:
+        sd.make_periodic_3d(md, rd)
+    ops = sd.hex_ops(rd)
+    sd.hex_driver_geometry(md, rd)
+    h = _setup_hex(N, VX, VY, VZ, EToV, periodic)
+    try:
+        sc = (N + 1) ** 3
+        for n in ("r", "s", "t", "V1", "Dr", "Ds", "Dt", "rf", "sf", "tf", "wf", "nrJ", "nsJ", "ntJ", "rq", "sq", "tq", "wq", "Vq", "M", "Pq", "Vf", "LIFT"):
+            ref = np.asarray(getattr(rd, n), dtype=float)
+            assert np.abs(_arr(h, n).reshape(ref.shape) - ref).max() < 2e-14 * max(1.0, np.abs(ref).max()) * sc, n
+        for n in ("Qrhskew", "Qshskew", "Qthskew", "Ef", "Vh", "Ph", "Lf"):
+            assert np.abs(_arr(h, n) - ops[n]).max() < 2e-14 * max(1.0, np.abs(ops[n]).max()) * sc, n
+        for n in ("x", "y", "z", "xf", "yf", "zf", "xq", "yq", "zq", "rxJ", "sxJ", "txJ", "ryJ", "syJ", "tyJ", "rzJ", "szJ", "tzJ", "J", "wJq",
+                  "nxJ", "nyJ", "nzJ", "sJ"):
+            assert np.abs(_arr(h, n) - getattr(md, n)).max() < 1e-12, n
+        Nfq, K = md.mapP.shape
+        assert np.array_equal(_map(h, "mapP").reshape((Nfq, K), order="F"), md.mapP)
+        assert np.array_equal(_map(h, "FToF").reshape((6, K), order="F"), md.FToF)
+        assert np.array_equal(_map(h, "mapB"), md.mapB)
+        o, m = _lib.esdg_hex_ops_t(), _lib.esdg_hex_mesh_t()
+        assert _lib.lib().esdg_setup_fill_hex(h, C.byref(o), C.byref(m)) == 0
+        assert (o.N, o.Nq, o.Nfq, m.K, m.geo_ld) == (N, (N + 1) ** 3, 6 * (N + 1) ** 2, K, (N + 1) ** 3 + 6 * (N + 1) ** 2)
+    finally:
+        _lib.lib().esdg_setup_destroy(h)
+
+
+def test_setup_hex_element_range():
+    N, K3 = 2, (2, 2, 4)
+    VX, VY, VZ, EToV = sd.uniform_hex_mesh(*K3)
+    rd = sd.init_reference_hex(N)
+    full = sd.init_mesh_3d((VX, VY, VZ), EToV, rd)
+    sd.make_periodic_3d(full, rd)
+    e0, e1 = 4, 12
+    h = _setup_hex(N, VX, VY, VZ, EToV, True, (e0, e1))
+    try:
+        Nfq = full.mapP.shape[0]
+        assert np.array_equal(_map(h, "mapP").reshape((Nfq, e1 - e0), order="F"), full.mapP[:, e0:e1])
+    finally:
+        _lib.lib().esdg_setup_destroy(h)
