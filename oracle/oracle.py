@@ -207,7 +207,7 @@ def shocktube_state(x, y):
     return rho, u, v, p
 
 
-def build_cns_problem(N, Kx, Ky, bc="periodic", BCTYPE=1, Re=1000.0, Pr=.71):
+def build_cns_problem(N, Kx, Ky, bc="periodic", BCTYPE=1, Re=1000.0, Pr=.71, shear=0.0):
     """Modal-ESDG CNS set-up of examples/CompressibleNS/dg2D_CNS_cavity_optimized.jl:21-90 fed
     with the reference *quad* element (SURVEY.md section 8 config mapping).
       bc="periodic": vortex box [0,15]x[-5,5], mapB emptied after the periodic patch;
@@ -223,6 +223,8 @@ def build_cns_problem(N, Kx, Ky, bc="periodic", BCTYPE=1, Re=1000.0, Pr=.71):
     if bc == "shocktube":
         VX = VX / 4 * 3 + 1 / 4                                    # dg2D_CNS_modalESDG.jl:63-65
         VY = (VY + 1) / 2
+    if shear:                                                      # parallelogram (still affine) elements: all four
+        VX = VX + shear * VY                                       # metric terms and both normal components non-zero
     rd = rs.init_reference_quad(N)
     md = rs.init_mesh_2D(VX, VY, EToV, rd)
     if bc == "periodic":
@@ -272,7 +274,7 @@ def hex_smooth_state(x, y, z):
     return rho, u, v, w, p
 
 
-def build_hex_problem(N, Kx, Ky=None, Kz=None):
+def build_hex_problem(N, Kx, Ky=None, Kz=None, A3=None):
     """examples/dg3D_euler_hex.jl:21-98: periodic box [-1,1]^3, Gauss collocation, a = 0 (affine)."""
     Ky = Kx if Ky is None else Ky
     Kz = Kx if Kz is None else Kz
@@ -281,7 +283,7 @@ def build_hex_problem(N, Kx, Ky=None, Kz=None):
     rd = rs.init_reference_hex(N, rs.gauss_quad(0, 0, N))
     md = rs.init_mesh_3D(VX, VY, VZ, EToV, rd)
     rs.make_periodic_3D(md, rd)
-    ops = rs.hex_driver_setup(md, rd, a=0.0)
+    ops = rs.hex_driver_setup(md, rd, a=0.0, A3=A3)
     p.Q = [np.asfortranarray(q) for q in ph.primitive_to_conservative_3D(*hex_smooth_state(md.xq, md.yq, md.zq))]
     p.rd, p.md, p.ops, p.VX, p.VY, p.VZ, p.EToV, p.N = rd, md, ops, VX, VY, VZ, EToV, N
     return p

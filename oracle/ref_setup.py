@@ -732,7 +732,7 @@ def make_periodic_3D(md, rd, LX=2.0, LY=2.0, LZ=2.0):
     return md
 
 
-def hex_driver_setup(md, rd, a=0.0):
+def hex_driver_setup(md, rd, a=0.0, A3=None):
     """examples/dg3D_euler_hex.jl:34-98: hybridized SBP operators in the quadrature basis, the (optionally curved)
     geometry re-computation, metrics interpolated to the hybrid nodes, J and wJq at the quadrature nodes.
     Mutates md like the script does and returns the `ops` dictionary."""
@@ -758,6 +758,9 @@ def hex_driver_setup(md, rd, a=0.0):
     x, y, z = md.x, md.y, md.z
     dx = (x - 1) * (x + 1) * (y - 1) * (y + 1) * (z - 1) * (z + 1)
     x, y, z = x + a * dx, y + a * dx, z + a * dx
+    if A3 is not None:       # affine map of the nodes (the script re-derives all geometry from x,y,z here, :75-90), for tests
+        x, y, z = (A3[i, 0] * x + A3[i, 1] * y + A3[i, 2] * z for i in range(3))
+        md.x, md.y, md.z = x, y, z
     md.xq, md.yq, md.zq = (np.asfortranarray(Vq @ c) for c in (x, y, z))
     vgeo = geometric_factors_3D(x, y, z, Dr, Ds, Dt)
     _hex_normals(md, rd, vgeo)

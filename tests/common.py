@@ -49,10 +49,11 @@ def cavity_state(x, y):
     return [np.asfortranarray(q) for q in ph.primitive_to_conservative(rho, u, v, p)]
 
 
-def product_cavity_problem(N, Kx, Ky, elem_range=None):
+def product_cavity_problem(N, Kx, Ky, elem_range=None, shear=0.0):
     """Lid-driven-cavity mesh of examples/CompressibleNS/dg2D_CNS_cavity_optimized.jl on quads: walls on all four
-    sides (md.mapB kept), lid = the y = +1 side."""
+    sides (md.mapB kept), lid = the y = +1 side.  shear != 0 turns the squares into parallelograms (affine)."""
     VX, VY, EToV = sd.uniform_quad_mesh(Kx, Ky)
+    VX = VX + shear * VY
     rd = sd.init_reference_quad(N)
     md = sd.init_mesh((VX, VY), EToV, rd, elem_range=elem_range)
     ops = sd.cns_ops(rd)
@@ -130,13 +131,13 @@ def hex_random_state(shape, seed=20250117, vel=(0.0, 1.0, 0.0)):
     return [np.asfortranarray(q) for q in ph.primitive_to_conservative_3d(rho, z + vel[0], z + vel[1], z + vel[2], p)]
 
 
-def product_hex_problem(N, Kx, Ky=None, Kz=None, elem_range=None, hybrid=True):
+def product_hex_problem(N, Kx, Ky=None, Kz=None, elem_range=None, hybrid=True, A3=None):
     VX, VY, VZ, EToV = sd.uniform_hex_mesh(Kx, Ky, Kz)
     rd = sd.init_reference_hex(N, sd.gauss_quad(0, 0, N))
     md = sd.init_mesh_3d((VX, VY, VZ), EToV, rd, elem_range=elem_range)
     sd.make_periodic_3d(md, rd)
     ops = sd.hex_ops(rd)
-    sd.hex_driver_geometry(md, rd, hybrid=hybrid)
+    sd.hex_driver_geometry(md, rd, hybrid=hybrid, A3=A3)
     return rd, md, ops, hex_smooth_state(md.xq, md.yq, md.zq)
 
 

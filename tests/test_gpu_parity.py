@@ -167,3 +167,23 @@ def test_shocktube_inflow_outflow_closures_match_oracle(eng_mod, oracle_lib):
     # the ABI refuses the penalty with these closures (the driver has that block commented out)
     with pytest.raises(Exception):
         eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, BCTYPE=4, viscous_dissp=True, inflow=(1.0, 1.2, 0.0, 0.08))
+
+
+@pytest.mark.parametrize("BCTYPE", [1, 3])
+def test_sheared_parallelogram_mesh_matches_oracle(eng_mod, oracle_lib, BCTYPE):
+    """Affine but not axis-aligned elements (x -> x + 0.35 y): all four metric terms rxJ, sxJ, ryJ, syJ and both
+    components of every face normal are non-zero, walls are oblique.  CNS with wall closures and modal Euler."""
+    from oracle import oracle as orc
+    N, Kx, Ky, sh = 3, 6, 5, 0.35
+    p = orc.build_cns_problem(N, Kx, Ky, bc="cavity", BCTYPE=BCTYPE, shear=sh)
+    assert np.abs(p.md.sxJ).min() > 1e-3 or np.abs(p.md.ryJ).min() > 1e-3      # the off-diagonal metrics are exercised
+    rd, md, ops, Q = product_cavity_problem(N, Kx, Ky, shear=sh)
+    assert np.array_equal(md.mapP, p.md.mapP) and np.abs(md.x - p.md.x).max() < 1e-14
+    for form, co, fn in ((eng_mod.CNS_MODAL, orc.CnsOracle(p), lambda c, q: c.rhsRK(q, compute_diag=False)[0]),
+                         (eng_mod.EULER_MODAL, orc.CnsOracle(p), lambda c, q: c.rhs_inviscid(q))):
+        eng = eng_mod.RhsEngine(rd, md, ops, form, BCTYPE=BCTYPE)
+        ref = fn(co, p.Q)
+        err = rel_l2(_gpu_rhs(eng, Q), ref)
+        floor = noise_floor(lambda q: fn(co, q), p.Q)
+        print(f"sheared cavity BCTYPE={BCTYPE} formulation={form}: err={err:.2e} oracle-noise-floor={floor:.2e}")
+        assert err <= max(TOL, 4 * floor), (err, floor)
