@@ -207,7 +207,13 @@ def shocktube_state(x, y):
     return rho, u, v, p
 
 
-def build_cns_problem(N, Kx, Ky, bc="periodic", BCTYPE=1, Re=1000.0, Pr=.71, shear=0.0):
+def grade_vertices(V, grade):
+    """Monotone map of [-1,1] onto itself: graded (non-uniform) rectangles, so that every element has its own J,
+    metrics and normals."""
+    return V + grade * np.sin(np.pi * V) / np.pi
+
+
+def build_cns_problem(N, Kx, Ky, bc="periodic", BCTYPE=1, Re=1000.0, Pr=.71, shear=0.0, grade=0.0):
     """Modal-ESDG CNS set-up of examples/CompressibleNS/dg2D_CNS_cavity_optimized.jl:21-90 fed
     with the reference *quad* element (SURVEY.md section 8 config mapping).
       bc="periodic": vortex box [0,15]x[-5,5], mapB emptied after the periodic patch;
@@ -217,6 +223,8 @@ def build_cns_problem(N, Kx, Ky, bc="periodic", BCTYPE=1, Re=1000.0, Pr=.71, she
                      mu=0.01, lambda=+2/3 mu, Pr=3/4, no penalty."""
     p = Problem()
     VX, VY, EToV = rs.uniform_quad_mesh(Kx, Ky)
+    if grade:
+        VX, VY = grade_vertices(VX, grade), grade_vertices(VY, -0.7 * grade)
     if bc == "periodic":
         VX = 15 * (1 + VX) / 2
         VY = 5 * VY
@@ -274,12 +282,14 @@ def hex_smooth_state(x, y, z):
     return rho, u, v, w, p
 
 
-def build_hex_problem(N, Kx, Ky=None, Kz=None, A3=None):
+def build_hex_problem(N, Kx, Ky=None, Kz=None, A3=None, grade=0.0):
     """examples/dg3D_euler_hex.jl:21-98: periodic box [-1,1]^3, Gauss collocation, a = 0 (affine)."""
     Ky = Kx if Ky is None else Ky
     Kz = Kx if Kz is None else Kz
     p = Problem()
     VX, VY, VZ, EToV = rs.uniform_hex_mesh(Kx, Ky, Kz)
+    if grade:
+        VX, VY, VZ = grade_vertices(VX, grade), grade_vertices(VY, -0.7 * grade), grade_vertices(VZ, 0.5 * grade)
     rd = rs.init_reference_hex(N, rs.gauss_quad(0, 0, N))
     md = rs.init_mesh_3D(VX, VY, VZ, EToV, rd)
     rs.make_periodic_3D(md, rd)

@@ -25,8 +25,14 @@ def product_euler_problem(N, Kx, Ky, elem_range=None):
     return rd, md, ops, Q
 
 
-def product_cns_problem(N, Kx, Ky, elem_range=None):
+def grade_vertices(V, grade):
+    return V + grade * np.sin(np.pi * V) / np.pi
+
+
+def product_cns_problem(N, Kx, Ky, elem_range=None, grade=0.0):
     VX, VY, EToV = sd.uniform_quad_mesh(Kx, Ky)
+    if grade:
+        VX, VY = grade_vertices(VX, grade), grade_vertices(VY, -0.7 * grade)
     VX = 15 * (1 + VX) / 2
     VY = 5 * VY
     rd = sd.init_reference_quad(N)
@@ -131,8 +137,10 @@ def hex_random_state(shape, seed=20250117, vel=(0.0, 1.0, 0.0)):
     return [np.asfortranarray(q) for q in ph.primitive_to_conservative_3d(rho, z + vel[0], z + vel[1], z + vel[2], p)]
 
 
-def product_hex_problem(N, Kx, Ky=None, Kz=None, elem_range=None, hybrid=True, A3=None):
+def product_hex_problem(N, Kx, Ky=None, Kz=None, elem_range=None, hybrid=True, A3=None, grade=0.0):
     VX, VY, VZ, EToV = sd.uniform_hex_mesh(Kx, Ky, Kz)
+    if grade:
+        VX, VY, VZ = grade_vertices(VX, grade), grade_vertices(VY, -0.7 * grade), grade_vertices(VZ, 0.5 * grade)
     rd = sd.init_reference_hex(N, sd.gauss_quad(0, 0, N))
     md = sd.init_mesh_3d((VX, VY, VZ), EToV, rd, elem_range=elem_range)
     sd.make_periodic_3d(md, rd)

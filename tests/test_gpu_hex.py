@@ -171,3 +171,20 @@ def test_hex_sheared_parallelepiped_mesh_matches_oracle(eng_mod, oracle_lib):
             assert err <= max(TOL, 4 * floor), (name, err, floor)
         c = [np.full_like(p.Q[0], v) for v in (1.3, 0.4, -0.3, 0.2, 2.9)]
         assert max(np.abs(x).max() for x in _gpu_rhs(eng, c)) < 1e-10
+
+
+def test_hex_graded_mesh_every_element_its_own_geometry(eng_mod, oracle_lib):
+    from oracle import oracle as orc
+    N, K3, g = 3, (5, 4, 3), 0.45
+    p = orc.build_hex_problem(N, *K3, grade=g)
+    assert np.abs(p.md.J).max() / np.abs(p.md.J).min() > 2
+    rd, md, ops, Q = product_hex_problem(N, *K3, grade=g)
+    assert np.array_equal(md.mapP, p.md.mapP)
+    for lf in (0.0, 0.25):
+        ho = orc.HexOracle(p, lf)
+        eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.EULER_HEX_COLLOCATED, lf_scale=lf)
+        ref = ho.rhs(p.Q)[0]
+        err = rel_l2(_gpu_rhs(eng, Q), ref)
+        floor = noise_floor(lambda q: ho.rhs(q)[0], p.Q)
+        print(f"graded hex mesh lf={lf}: err={err:.2e} oracle-noise-floor={floor:.2e}")
+        assert err <= max(TOL, 4 * floor), (err, floor)

@@ -187,3 +187,21 @@ def test_sheared_parallelogram_mesh_matches_oracle(eng_mod, oracle_lib, BCTYPE):
         floor = noise_floor(lambda q: fn(co, q), p.Q)
         print(f"sheared cavity BCTYPE={BCTYPE} formulation={form}: err={err:.2e} oracle-noise-floor={floor:.2e}")
         assert err <= max(TOL, 4 * floor), (err, floor)
+
+
+def test_graded_mesh_every_element_its_own_geometry(eng_mod, oracle_lib):
+    """Non-uniform rectangles (vertices graded by x + g sin(pi x)/pi): J, metrics and normals differ from element to
+    element, so any mix-up of per-element geometry records between the lanes/waves of a workgroup would show."""
+    from oracle import oracle as orc
+    N, Kx, Ky, g = 4, 9, 7, 0.45
+    p = orc.build_cns_problem(N, Kx, Ky, bc="periodic", grade=g)
+    assert p.md.J.max() / p.md.J.min() > 2
+    co = orc.CnsOracle(p)
+    rd, md, ops, Q = product_cns_problem(N, Kx, Ky, grade=g)
+    assert np.array_equal(md.mapP, p.md.mapP)
+    eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL)
+    ref = co.rhsRK(p.Q, compute_diag=False)[0]
+    err = rel_l2(_gpu_rhs(eng, Q), ref)
+    floor = noise_floor(lambda q: co.rhsRK(q, compute_diag=False)[0], p.Q)
+    print(f"graded CNS mesh: err={err:.2e} oracle-noise-floor={floor:.2e}, J ratio {p.md.J.max() / p.md.J.min():.1f}")
+    assert err <= max(TOL, 4 * floor), (err, floor)
