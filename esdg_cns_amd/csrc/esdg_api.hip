@@ -1226,6 +1226,57 @@ int esdg_dopri_error(const double* Q, const double* const* k, const double* coef
   return ESDG_OK;
 }
 
+// ---- whole-step entry points (unsharded meshes; sharded hosts drive the phases themselves) ------------------------
+int esdg_lsrk45_step(esdg_ctx* ctx, double* Q, double* resQ, double dt, void* stream) {
+  // rk45_coeffs, src/CommonUtils.jl:29-49; loop dg2D_euler_quad.jl:200-206
+  static const double rk4a[5] = {0.0, -567301805773.0 / 1357537059087.0, -2404267990393.0 / 2016746695238.0,
+                                 -3550918686646.0 / 2091501179385.0, -1275806237668.0 / 842570457699.0};
+  static const double rk4b[5] = {1432997174477.0 / 9575080441755.0, 5161836677717.0 / 13612068292357.0,
+                                 1720146321549.0 / 2090206949498.0, 3134564353537.0 / 4481467310338.0,
+                                 2277821191437.0 / 14882151754819.0};
+  if (!ctx || !Q || !resQ) return fail(ESDG_ERR_ARG, "null argument");
+  if (!ctx->use_fast) return fail(ESDG_ERR_STATE, "esdg_lsrk45_step needs the tensor / hex kernels (fused stage)");
+  for (int k = 0; k < 5; ++k) {
+    int rc = esdg_rhs_lsrk(ctx, Q, resQ, rk4a[k], rk4b[k], dt, stream);
+    if (rc) return rc;
+  }
+  return ESDG_OK;
+}
+
+int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* const* k, double dt, double err_tol,
+                         double* err_est, void* stream) {
+  // dopri45_coeffs and the stage loop of dg2D_CNS_cavity_optimized.jl:919-934, 1002-1021; k[0] must hold rhs(Q) (FSAL)
+  static const double A[7][6] = {{0, 0, 0, 0, 0, 0},
+                                 {0.2, 0, 0, 0, 0, 0},
+                                 {3.0 / 40.0, 9.0 / 40.0, 0, 0, 0, 0},
+                                 {44.0 / 45.0, -56.0 / 15.0, 32.0 / 9.0, 0, 0, 0},
+                                 {19372.0 / 6561.0, -25360.0 / 2187.0, 64448.0 / 6561.0, -212.0 / 729.0, 0, 0},
+                                 {9017.0 / 3168.0, -355.0 / 33.0, 46732.0 / 5247.0, 49.0 / 176.0, -5103.0 / 18656.0, 0},
+                                 {35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0}};
+  static const double E[7] = {71.0 / 57600.0, 0.0, -71.0 / 16695.0, 71.0 / 1920.0, -17253.0 / 339200.0, 22.0 / 525.0, -1.0 / 40.0};
+  if (!ctx || !Q || !Qtmp || !k || !err_est) return fail(ESDG_ERR_ARG, "null argument");
+  if (ctx->nghost) return fail(ESDG_ERR_STATE, "esdg_dopri45_attempt needs an unsharded mesh");
+  const int64_t n = (int64_t)ctx->nfld * ctx->K * ctx->Np;
+  for (int s = 1; s < 7; ++s) {
+    int rc = esdg_axpy_stages(Qtmp, Q, k, A[s], s, dt, n, stream);
+    if (!rc) rc = esdg_rhs(ctx, Qtmp, k[s], stream);
+    if (rc) return rc;
+  }
+  double acc = 0.0;
+  int rc = esdg_dopri_error(Q, k, E, 7, err_tol, n, &acc, stream);
+  if (rc) return rc;
+  *err_est = std::sqrt(acc / (double)n);    // sqrt(sum/(length(Q[1])*4)), :1021
+  return ESDG_OK;
+}
+
+double esdg_dopri45_next_dt(double dt, double dt0, double err_est, double prev_err_est, int64_t attempts) {
+  // P / PI controller of dg2D_CNS_cavity_optimized.jl:1027-1033
+  const int order = 5;
+  double dtnew = .8 * dt * std::pow(.9 / err_est, .4 / (order + 1));
+  if (attempts > 0) dtnew *= std::pow(prev_err_est / std::max(1e-14, err_est), .3 / (order + 1));
+  return std::max(std::min(10 * dt0, dtnew), 1e-9);
+}
+
 // ---- device-memory helpers ---------------------------------------------------------------------
 void* esdg_dmalloc(size_t bytes) {
   void* p = nullptr;

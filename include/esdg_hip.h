@@ -260,6 +260,16 @@ int esdg_axpy_stages(double* y_dev, const double* x0_dev, const double* const* k
 int esdg_dopri_error(const double* Q_dev, const double* const* k_dev, const double* coefE, int nstages,
                      double tol, int64_t n, double* result_host, void* stream);
 
+/* Whole steps (unsharded meshes).  esdg_lsrk45_step = the five stages of dg2D_euler_quad.jl:200-206 on the fused
+ * RHS+stage kernels.  esdg_dopri45_attempt = stages 2..7 and the Hairer error estimate of one DOPRI45 attempt
+ * (cavity_optimized.jl:1002-1021): k is an array of 7 device state buffers, k[0] = rhs(Q) on entry (FSAL); on return
+ * Qtmp is the candidate state, *err_est the estimate; the caller accepts (Q <- Qtmp, swap k[0], k[6]) if it is < 1 and
+ * takes the next step size from esdg_dopri45_next_dt (the P / PI controller of :1027-1033). */
+int esdg_lsrk45_step(esdg_ctx* ctx, double* Q_dev, double* resQ_dev, double dt, void* stream);
+int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q_dev, double* Qtmp_dev, double* const* k_dev, double dt, double err_tol,
+                         double* err_est, void* stream);
+double esdg_dopri45_next_dt(double dt, double dt0, double err_est, double prev_err_est, int64_t attempts);
+
 /* ---- set-up for hosts without a SetupDG of their own (host-only code, no GPU needed) ------------------------------
  * esdg_setup_quad builds, for elements [e_begin, e_end) of a quad mesh (e_end <= 0: all), everything a reference
  * driver holds when it enters its time loop: RefElemData of init_reference_quad(N) with the default Gauss rule

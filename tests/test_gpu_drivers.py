@@ -185,3 +185,49 @@ def test_pure_c_hex_driver(tmp_path):
     vals = dict(kv.split("=") for kv in out.split() if "=" in kv)
     assert vals["fields"] == "5" and float(vals["max|rhs|"]) > 1e-3
     assert abs(float(vals["rhstest"])) < 1e-11
+
+
+def test_whole_step_c_entry_points_match_the_python_loops():
+    """esdg_lsrk45_step / esdg_dopri45_attempt / esdg_dopri45_next_dt against timestep.lsrk45_run / timestep.Dopri45
+    (same kernels underneath): identical bits and identical step-size histories."""
+    import ctypes as C
+    import torch
+    from esdg_cns_amd import engine, timestep
+    from esdg_cns_amd._lib import check
+    rd, md, ops, Q = product_cns_problem(3, 6, 6)
+    eng = engine.RhsEngine(rd, md, ops, engine.CNS_MODAL)
+    L, ctx = eng.L, eng.ctx
+    # LSRK45
+    dt = 2e-3
+    Q1, Q2 = eng.upload(Q), eng.upload(Q)
+    timestep.lsrk45_run(eng, Q1, dt, 3)
+    res = torch.zeros_like(Q2)
+    for _ in range(3):
+        check(L.esdg_lsrk45_step(ctx, C.c_void_p(Q2.data_ptr()), C.c_void_p(res.data_ptr()), dt, eng._stream()))
+    assert torch.equal(Q1, Q2)
+    # DOPRI45
+    dt0 = 0.5 * (2 / 6) / 10
+    Qa = eng.upload(Q)
+    integ = timestep.Dopri45(eng, Qa, dt0)
+    hist = []
+    for _ in range(6):
+        ok, err = integ.step()
+        hist.append((ok, err, integ.dt))
+    Qb = eng.upload(Q)
+    k = [torch.zeros_like(Qb) for _ in range(7)]
+    Qtmp = torch.empty_like(Qb)
+    eng.rhs_into(Qb, k[0])
+    dtc, prev, t = dt0, 0.0, 0.0
+    for i in range(6):
+        ptrs = (C.c_void_p * 7)(*[x.data_ptr() for x in k])
+        e = C.c_double()
+        check(L.esdg_dopri45_attempt(ctx, C.c_void_p(Qb.data_ptr()), C.c_void_p(Qtmp.data_ptr()), ptrs, dtc, 1e-5, C.byref(e), eng._stream()))
+        ok = e.value < 1.0
+        if ok:
+            Qb.copy_(Qtmp)
+            t += dtc
+            k[0], k[6] = k[6], k[0]
+        dtc = L.esdg_dopri45_next_dt(dtc, dt0, e.value, prev, i)
+        prev = e.value
+        assert ok == hist[i][0] and abs(e.value - hist[i][1]) <= 1e-12 * max(1.0, hist[i][1]) and abs(dtc - hist[i][2]) <= 1e-15 * dt0 + 1e-12 * dtc
+    assert torch.equal(Qa, Qb) and abs(t - integ.t) < 1e-15
