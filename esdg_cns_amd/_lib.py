@@ -65,6 +65,7 @@ SYMBOLS = {
     "esdg_rhs_lsrk": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp]),
     "esdg_rhs_phase_lsrk": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp]),
     "esdg_rhstest": (C.c_int, [_vp, _vp, _vp, c_double_p, _vp]),
+    "esdg_check_state": (C.c_int, [_vp, _vp, c_double_p, _vp]),
     "esdg_set_parts": (C.c_int, [_vp, C.c_int]),
     "esdg_viscous_entropy_test": (C.c_int, [_vp, _vp, c_double_p, _vp]),
     "esdg_rhs_host": (C.c_int, [_vp, C.POINTER(c_double_p), C.POINTER(c_double_p)]),

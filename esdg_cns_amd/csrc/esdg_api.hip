@@ -1098,6 +1098,23 @@ int esdg_viscous_entropy_test(esdg_ctx* ctx, const double* Q, double* out, void*
   return ESDG_OK;
 }
 
+int esdg_check_state(esdg_ctx* ctx, const double* Q, double* min_rho_p, void* stream) {
+  if (!ctx || !Q || !min_rho_p) return fail(ESDG_ERR_ARG, "null argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nb = esdg_ctx::NPARTIAL / 2;
+  double* partial = static_cast<double*>(ctx->d_partial.p);
+  int rc = launch_min_rho_p(Q, ctx->nfld, ctx->K * ctx->Np, partial, nb, s);
+  if (rc) return fail(ESDG_ERR_NO_DEVICE, "state check launch: %s", hipGetErrorString((hipError_t)rc));
+  std::vector<double> h(2 * (size_t)nb);
+  HIP_TRY(hipMemcpyAsync(h.data(), partial, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  double mr = 1e300, mp = 1e300;
+  for (int b = 0; b < nb; ++b) { mr = std::min(mr, h[2 * b]); mp = std::min(mp, h[2 * b + 1]); }
+  min_rho_p[0] = mr;
+  min_rho_p[1] = mp;
+  return ESDG_OK;
+}
+
 int esdg_rhs_host(esdg_ctx* ctx, const double* const* Q, double* const* rhs) {
   if (!ctx || !Q || !rhs) return fail(ESDG_ERR_ARG, "null argument");
   if (ctx->nghost) return fail(ESDG_ERR_STATE, "esdg_rhs_host needs an unsharded mesh");

@@ -100,6 +100,7 @@ int launch_axpy_stages(double* y, const double* x0, const double* const* k, cons
                        int64_t n, hipStream_t s);
 int launch_dopri_err(const double* Q, const double* const* k, const double* coefE, int ns, double tol, int64_t n,
                      double* partial, int nblocks, hipStream_t s);
+int launch_min_rho_p(const double* Q, int nfld, int64_t n, double* partial, int nblocks, hipStream_t s);
 bool supported_degree(int N1);
 
 // hexahedral path (esdg_kernels_hex.hip)

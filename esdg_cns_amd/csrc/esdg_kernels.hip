@@ -812,6 +812,33 @@ int launch_axpy_stages(double* y, const double* x0, const double* const* k, cons
   return (int)hipGetLastError();
 }
 
+// admissibility of a state: per-block minima of rho and of p = (gamma-1)(E - |rhoU|^2/(2 rho)) over the n nodes of a
+// stacked state [nfld][n] (nfld = 4: 2D, 5: hex).  The reference throws a DomainError from log/sqrt instead.
+__global__ void k_min_rho_p(const double* __restrict__ Q, int nfld, int64_t n, double* __restrict__ partial) {
+  __shared__ double r0[256], r1[256];
+  double mr = 1e300, mp = 1e300;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double rho = Q[i];
+    double m2 = 0.0;
+    for (int c = 1; c < nfld - 1; ++c) m2 += Q[(int64_t)c * n + i] * Q[(int64_t)c * n + i];
+    const double p = 0.4 * (Q[(int64_t)(nfld - 1) * n + i] - .5 * m2 / rho);
+    mr = fmin(mr, rho == rho ? rho : -1e300);      // NaN counts as inadmissible
+    mp = fmin(mp, p == p ? p : -1e300);
+  }
+  r0[threadIdx.x] = mr; r1[threadIdx.x] = mp;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { r0[threadIdx.x] = fmin(r0[threadIdx.x], r0[threadIdx.x + w]); r1[threadIdx.x] = fmin(r1[threadIdx.x], r1[threadIdx.x + w]); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = r0[0]; partial[2 * blockIdx.x + 1] = r1[0]; }
+}
+
+int launch_min_rho_p(const double* Q, int nfld, int64_t n, double* partial, int nblocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_min_rho_p, dim3(nblocks), dim3(256), 0, s, Q, nfld, n, partial);
+  return (int)hipGetLastError();
+}
+
 int launch_dopri_err(const double* Q, const double* const* k, const double* coefE, int ns, double tol, int64_t n,
                      double* partial, int nblocks, hipStream_t s) {
   if (ns > 8) return (int)hipErrorInvalidValue;

@@ -325,6 +325,12 @@ class RhsEngine:
         check(self.L.esdg_rhstest(self.ctx, C.c_void_p(Qd.data_ptr()), C.c_void_p(rhsd.data_ptr()), diag, self._stream()))
         return diag[0]
 
+    def check_state(self, Qd):
+        """(min rho, min p) over the local nodal values; the reference raises DomainError where these are <= 0."""
+        out = (C.c_double * 2)()
+        check(self.L.esdg_check_state(self.ctx, C.c_void_p(Qd.data_ptr()), out, self._stream()))
+        return out[0], out[1]
+
     def set_parts(self, parts):
         """1 = rhs_inviscid! only, 2 = rhs_viscous! only, 3 = rhsRK! (default)."""
         check(self.L.esdg_set_parts(self.ctx, int(parts)))

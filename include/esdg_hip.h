@@ -192,6 +192,11 @@ int esdg_rhs_phase_lsrk(esdg_ctx* ctx, int phase, double* Q_dev, double* resQ_de
  * is the caller's job). */
 int esdg_rhstest(esdg_ctx* ctx, const double* Q_dev, const double* rhs_dev, double* diag, void* stream);
 
+/* Admissibility of a state (the reference throws Julia DomainErrors from log / sqrt / ^ on negative density or
+ * pressure; the kernels would silently produce NaNs): min_rho_p[0] = min rho, [1] = min p over the local nodal values
+ * of Q_dev (NaNs count as -1e300).  Device reduction, synchronises `stream`. */
+int esdg_check_state(esdg_ctx* ctx, const double* Q_dev, double* min_rho_p, void* stream);
+
 /* rhsRK! = rhs_inviscid! + rhs_viscous! (cavity_optimized.jl:955-957).  esdg_set_parts selects which of the two a
  * CNS context evaluates in the following esdg_rhs* calls: 1 = rhs_inviscid! (:447), 2 = rhs_viscous! (:749), 3 = both
  * (default).  esdg_viscous_entropy_test returns the second value of rhs_viscous!,

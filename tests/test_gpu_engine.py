@@ -170,3 +170,22 @@ def test_fused_lsrk_stage_is_bitwise_the_unfused_one(E):
         eng.lsrk45_step(Qa, ra, rhs, dt, rk)
         eng.lsrk45_step_fused(Qb, rb, dt, rk)
     assert torch.equal(Qa, Qb) and torch.equal(ra, rb)
+
+
+def test_check_state_reports_min_density_and_pressure(E):
+    from common import product_hex_problem
+    rd, md, ops, Q = product_cns_problem(3, 5, 4)
+    eng = E.RhsEngine(rd, md, ops, E.CNS_MODAL)
+    rho, p = Q[0], 0.4 * (Q[3] - .5 * (Q[1] ** 2 + Q[2] ** 2) / Q[0])
+    mr, mp = eng.check_state(eng.upload(Q))
+    assert abs(mr - rho.min()) < 1e-15 and abs(mp - p.min()) < 1e-14
+    Qb = [q.copy() for q in Q]
+    Qb[0][3, 2] = -0.5
+    Qb[3][1, 7] = np.nan
+    mr, mp = eng.check_state(eng.upload(Qb))
+    assert mr == -0.5 and mp == -1e300
+    rdh, mdh, opsh, Qh = product_hex_problem(2, 3, 2, 2)
+    engh = E.RhsEngine(rdh, mdh, opsh, E.EULER_HEX_COLLOCATED)
+    ph_ = 0.4 * (Qh[4] - .5 * (Qh[1] ** 2 + Qh[2] ** 2 + Qh[3] ** 2) / Qh[0])
+    mr, mp = engh.check_state(engh.upload(Qh))
+    assert abs(mr - Qh[0].min()) < 1e-15 and abs(mp - ph_.min()) < 1e-14
