@@ -276,26 +276,63 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
     __syncthreads();
 
     // ---- volume lanes: circulant line schedule, each unordered pair once -------------------------------
+    // full rounds: lane at position i of a line takes the pair (i, i+m mod N1), m = 1..(N1-1)/2
+    constexpr int MF = (N1 - 1) / 2;
+    if (MF > 0) {
 #pragma unroll 1
-    for (int d = 0; d < 3; ++d) {
-      const int opd = d == 0 ? HT.op[0] : (d == 1 ? HT.op[1] : HT.op[2]);
-      const double gx = geo[opd], gy = geo[3 + opd], gz = geo[6 + opd];
-      const int id = d == 0 ? i0 : (d == 1 ? i1 : i2);
-      const int o = d == 0 ? i1 + N1 * i2 : (d == 1 ? i0 + N1 * i2 : i0 + N1 * i1);
-      const int stride = d == 0 ? 1 : (d == 1 ? N1 : NN);
-      const double wt = sTab[L.WT + d * NN + o];
+      for (int d = 0; d < 3; ++d) {
+        const int opd = d == 0 ? HT.op[0] : (d == 1 ? HT.op[1] : HT.op[2]);
+        const double gx = geo[opd], gy = geo[3 + opd], gz = geo[6 + opd];
+        const int id = d == 0 ? i0 : (d == 1 ? i1 : i2);
+        const int o = d == 0 ? i1 + N1 * i2 : (d == 1 ? i0 + N1 * i2 : i0 + N1 * i1);
+        const int stride = d == 0 ? 1 : (d == 1 ? N1 : NN);
+        const double wt = sTab[L.WT + d * NN + o];
 #pragma unroll
-      for (int m = 1; m <= N1 / 2; ++m) {
-        int j = id + m;
+        for (int m = 1; m <= MF; ++m) {
+          int j = id + m;
+          j = j >= N1 ? j - N1 : j;
+          const int node = vin ? lane + (j - id) * stride : lane;
+          double qn[7], F[HEX_NFLD];
+          const int ns = slot_of(node);
+#pragma unroll
+          for (int c = 0; c < 7; ++c) qn[c] = sP[c * HW + ns];
+          const double W = sTab[L.S + (d * N1 + id) * N1 + j] * wt;
+          ec_flux_dir(qv, qn, gx, gy, gz, F);
+          if (vin) {
+#pragma unroll
+            for (int c = 0; c < HEX_NFLD; ++c) {
+              const double wf = W * F[c];
+              acc[c] += wf;
+              lds_add(&sAcc[c * HW + ns], -wf);
+            }
+          }
+        }
+      }
+    }
+    // even N1: the antipodal pairs (i, i+N1/2).  Only half of the lanes of a line own such a pair per direction, so the
+    // three directions are packed into two rounds instead of three: with b_d = (i_d >= N1/2) and S = {b0^b1^b2 = 1},
+    // every antipodal pair has exactly one endpoint in S; round A: S-lanes take their d=0 pair, the others their d=1
+    // pair; round B: S-lanes take their d=2 pair.
+    if (N1 % 2 == 0) {
+      constexpr int H = N1 / 2;
+      const bool inS = (((i0 >= H) ? 1 : 0) ^ ((i1 >= H) ? 1 : 0) ^ ((i2 >= H) ? 1 : 0)) != 0;
+#pragma unroll 1
+      for (int rnd = 0; rnd < 2; ++rnd) {
+        const int d = rnd == 0 ? (inS ? 0 : 1) : 2;
+        const bool act = vin && (rnd == 0 || inS);
+        const int opd = d == 0 ? HT.op[0] : (d == 1 ? HT.op[1] : HT.op[2]);
+        const double gx = geo[opd], gy = geo[3 + opd], gz = geo[6 + opd];
+        const int id = d == 0 ? i0 : (d == 1 ? i1 : i2);
+        const int o = d == 0 ? i1 + N1 * i2 : (d == 1 ? i0 + N1 * i2 : i0 + N1 * i1);
+        const int stride = d == 0 ? 1 : (d == 1 ? N1 : NN);
+        int j = id + H;
         j = j >= N1 ? j - N1 : j;
-        const bool half = (N1 % 2 == 0) && (m == N1 / 2);
-        const bool act = vin && (!half || id < N1 / 2);
         const int node = act ? lane + (j - id) * stride : lane;
         double qn[7], F[HEX_NFLD];
         const int ns = slot_of(node);
 #pragma unroll
         for (int c = 0; c < 7; ++c) qn[c] = sP[c * HW + ns];
-        const double W = sTab[L.S + (d * N1 + id) * N1 + j] * wt;
+        const double W = sTab[L.S + (d * N1 + id) * N1 + j] * sTab[L.WT + d * NN + o];
         ec_flux_dir(qv, qn, gx, gy, gz, F);
         if (act) {
 #pragma unroll
