@@ -52,7 +52,7 @@ def build_problem(N, Kx, Ky_total, e0, e1, formulation):
     return rd, md, ops, Q
 
 
-def build_hex_problem(N, Kx, Ky, Kz_total, e0, e1):
+def build_hex_problem(N, Kx, Ky, Kz_total, e0, e1, curve=0.0):
     from esdg_cns_amd import physics as ph
     from esdg_cns_amd import setup_dg as sd
     VX, VY, VZ, EToV = sd.uniform_hex_mesh(Kx, Ky, Kz_total)
@@ -60,7 +60,8 @@ def build_hex_problem(N, Kx, Ky, Kz_total, e0, e1):
     md = sd.init_mesh_3d((VX, VY, VZ), EToV, rd, elem_range=(e0, e1))
     sd.make_periodic_3d(md, rd)
     ops = sd.hex_ops(rd)
-    sd.hex_driver_geometry(md, rd, hybrid=False)      # affine: one metric row per element (geo_ld = 1)
+    # affine: one metric row per element (geo_ld = 1); curved (--hex-curve a, the script's mapping :67-73): all Nh rows
+    sd.hex_driver_geometry(md, rd, hybrid=bool(curve), a=curve)
     x, y, z = md.xq, md.yq, md.zq
     rho = 2 + .5 * np.sin(np.pi * x) * np.cos(np.pi * y)
     u, v, w = .3 * np.sin(np.pi * z + .2), 1 + .1 * np.cos(np.pi * x), .1 * np.sin(np.pi * (x + y) + .3)
@@ -150,6 +151,7 @@ def main():
     ap.add_argument("--ky-per-gpu", type=int, default=512, help="element rows per GPU (weak scaling, 2D)")
     ap.add_argument("--kz-per-gpu", type=int, default=16, help="element layers per GPU (weak scaling, hex)")
     ap.add_argument("--lf", type=float, default=0.0, help="hex: LF factor (the reference has 0*.25)")
+    ap.add_argument("--hex-curve", type=float, default=0.0, help="hex: amplitude a of the script's curved mapping (0 = affine)")
     ap.add_argument("--formulation", choices=["cns", "euler", "hex"], default="cns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
@@ -183,7 +185,7 @@ def main():
         Kz_total = args.kz_per_gpu * world
         rank_offsets = np.array([Kx * Kx * args.kz_per_gpu * r for r in range(world + 1)], dtype=np.int64)   # z-slabs
         e0, e1 = int(rank_offsets[rank]), int(rank_offsets[rank + 1])
-        rd, md, ops, Q = build_hex_problem(N, Kx, Kx, Kz_total, e0, e1)
+        rd, md, ops, Q = build_hex_problem(N, Kx, Kx, Kz_total, e0, e1, args.hex_curve)
         eng = engine.RhsEngine(rd, md, ops, engine.EULER_HEX_COLLOCATED, lf_scale=args.lf, rank=rank, nranks=world,
                                rank_offsets=rank_offsets)
         K_total = Kx * Kx * Kz_total
@@ -255,7 +257,7 @@ def main():
                 "whole_rhs_frac": (alg_bytes * evals_per_s / 1e9) / HBM_PEAK_GBS}
 
     if hexw:
-        workload = f"euler3d_hex_N{N}_{Kx}x{Kx}x{Kz_total}_periodic_box_lf{args.lf:g}"
+        workload = f"euler3d_hex_N{N}_{Kx}x{Kx}x{Kz_total}_periodic_box_lf{args.lf:g}" + (f"_curved{args.hex_curve:g}" if args.hex_curve else "")
     else:
         workload = (f"{args.formulation}2d_N{N}_{Kx}x{Ky_total}_quads_periodic_vortex"
                     + ("_Re1000_inviscid+viscous_dissipation" if args.formulation == "cns" else ""))

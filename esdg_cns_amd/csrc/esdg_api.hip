@@ -459,7 +459,7 @@ struct esdg_ctx {
   // device storage
   DevBuf d_pair_ij, d_pair_c, d_inc_ptr, d_inc, d_Ef_i, d_Ef_v, d_Ph_i, d_Ph_v, d_Lf_i, d_Lf_v, d_Dr_i, d_Dr_v, d_Ds_i,
       d_Ds_v, d_Vq, d_Pq, d_geo, d_mapP, d_bc, d_wJq, d_sendlist, d_partial;
-  DevBuf t_dbl, t_int, d_stamps;
+  DevBuf t_dbl, t_int, d_stamps, d_G9, d_Jq, d_nrm;
   // halo plan
   std::vector<int32_t> nbr_rank;
   std::vector<int64_t> nbr_send_off, nbr_send_cnt, nbr_recv_off, nbr_recv_cnt;  // in face nodes
@@ -829,32 +829,45 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
   if (!build_hex_host(N1, Q3, from_colmajor(ops->Ph, Nq, Nh), from_colmajor(ops->Lf, Nq, Nfq), from_colmajor(ops->Ef, Nfq, Nq), hh, why))
     return fail(ESDG_ERR_STRUCTURE, "operators are not those of a tensor-product Gauss hexahedron: %s", why.c_str());
 
-  // ---- geometry: affine check + per-element records ---------------------------------------------
+  // ---- geometry: per-element records if every element is affine, per-node arrays otherwise ------------
   const int64_t K = mesh->K;
   const int ld = mesh->geo_ld > 0 ? mesh->geo_ld : Nh;
   std::vector<double> geo((size_t)K * HEX_GEO_STRIDE);
+  bool curved = false;
   for (int64_t e = 0; e < K; ++e) {
     double* g = &geo[(size_t)e * HEX_GEO_STRIDE];
     double scale = 0;
     for (int m = 0; m < 9; ++m) scale = std::max(scale, std::fabs(gsrc[m][(size_t)e * ld]));
     for (int m = 0; m < 9; ++m) {
       const double* src = gsrc[m] + (size_t)e * ld;
-      for (int i = 1; i < ld; ++i)
-        if (std::fabs(src[i] - src[0]) > 1e-10 * scale) return fail(ESDG_ERR_STRUCTURE, "element %lld is not affine (metric term %d varies)", (long long)e, m);
+      for (int i = 1; i < ld; ++i) curved = curved || std::fabs(src[i] - src[0]) > 1e-10 * scale;
       g[m] = src[0];
     }
     const double* J = mesh->J + (size_t)e * Nq;
-    for (int i = 1; i < Nq; ++i)
-      if (std::fabs(J[i] - J[0]) > 1e-10 * std::fabs(J[0])) return fail(ESDG_ERR_STRUCTURE, "element %lld is not affine (J varies)", (long long)e);
-    if (J[0] == 0.0) return fail(ESDG_ERR_ARG, "element %lld has J = 0", (long long)e);
+    for (int i = 1; i < Nq; ++i) curved = curved || std::fabs(J[i] - J[0]) > 1e-10 * std::fabs(J[0]);
+    for (int i = 0; i < Nq; ++i)
+      if (J[i] == 0.0) return fail(ESDG_ERR_ARG, "element %lld has J = 0", (long long)e);
     g[9] = J[0];
     for (int f = 0; f < 6; ++f) {
       const size_t o = (size_t)e * Nfq + (size_t)f * NN;
       for (int i = 1; i < NN; ++i)
-        if (std::fabs(mesh->nxJ[o + i] - mesh->nxJ[o]) > 1e-10 * mesh->sJ[o] || std::fabs(mesh->nyJ[o + i] - mesh->nyJ[o]) > 1e-10 * mesh->sJ[o] ||
-            std::fabs(mesh->nzJ[o + i] - mesh->nzJ[o]) > 1e-10 * mesh->sJ[o])
-          return fail(ESDG_ERR_STRUCTURE, "element %lld face %d is curved", (long long)e, f);
+        curved = curved || std::fabs(mesh->nxJ[o + i] - mesh->nxJ[o]) > 1e-10 * mesh->sJ[o] || std::fabs(mesh->nyJ[o + i] - mesh->nyJ[o]) > 1e-10 * mesh->sJ[o] ||
+                 std::fabs(mesh->nzJ[o + i] - mesh->nzJ[o]) > 1e-10 * mesh->sJ[o];
       g[10 + 4 * f] = mesh->nxJ[o]; g[11 + 4 * f] = mesh->nyJ[o]; g[12 + 4 * f] = mesh->nzJ[o]; g[13 + 4 * f] = mesh->sJ[o];
+    }
+  }
+  // curved elements (the `a != 0` mapping of dg3D_euler_hex.jl:67-73): per-node metric terms at the hybrid nodes, J at
+  // the quadrature nodes and per-node normals, as the script's sparse_hadamard_sum / rhs use them (:145-151, :193-198)
+  std::vector<double> G9, Jq, nrm;
+  if (curved) {
+    if (ld != Nh) return fail(ESDG_ERR_STRUCTURE, "curved hexahedra need the metric arrays at all Nh = %d hybrid nodes (geo_ld = %d)", Nh, ld);
+    G9.resize((size_t)K * 9 * Nh);
+    Jq.assign(mesh->J, mesh->J + (size_t)K * Nq);
+    nrm.resize((size_t)K * 4 * Nfq);
+    const double* nsrc[4] = {mesh->nxJ, mesh->nyJ, mesh->nzJ, mesh->sJ};
+    for (int64_t e = 0; e < K; ++e) {
+      for (int m = 0; m < 9; ++m) std::copy(gsrc[m] + (size_t)e * Nh, gsrc[m] + (size_t)(e + 1) * Nh, &G9[((size_t)e * 9 + m) * Nh]);
+      for (int c = 0; c < 4; ++c) std::copy(nsrc[c] + (size_t)e * Nfq, nsrc[c] + (size_t)(e + 1) * Nfq, &nrm[((size_t)e * 4 + c) * Nfq]);
     }
   }
 
@@ -874,6 +887,7 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
 #define UP(buf, vec) if ((rc = c->buf.upload(vec)) != 0) return rc
   UP(d_geo, geo); UP(d_mapP, pl.mapP); UP(d_sendlist, pl.sendlist);
   UP(t_dbl, hh.dbl); UP(t_int, hh.ints);
+  if (curved) { UP(d_G9, G9); UP(d_Jq, Jq); UP(d_nrm, nrm); }
   if (mesh->wJq) {
     std::vector<double> w(mesh->wJq, mesh->wJq + (size_t)K * Nq);
     UP(d_wJq, w);
@@ -885,6 +899,9 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
   for (int d = 0; d < 3; ++d) c->HT.op[d] = hh.op[d];
   c->M.K = K; c->M.e_begin = 0; c->M.e_count = K;
   c->M.geo = c->d_geo.as<double>(); c->M.mapP = c->d_mapP.as<int32_t>(); c->M.bc = nullptr;
+  c->M.G9 = curved ? c->d_G9.as<double>() : nullptr;
+  c->M.Jq = curved ? c->d_Jq.as<double>() : nullptr;
+  c->M.nrm = curved ? c->d_nrm.as<double>() : nullptr;
   set_interior(c, pl.mapP, K, Nfq);
   c->M.wJq = mesh->wJq ? c->d_wJq.as<double>() : nullptr;
   c->M.stamps = nullptr;

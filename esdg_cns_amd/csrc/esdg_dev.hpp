@@ -63,6 +63,11 @@ struct MeshDev {
   const int32_t* mapP;     // [K][Nfq]  local face-node index, or ghost slot >= K*Nfq
   const uint8_t* bc;       // [K][Nfq]  0 interior/periodic, 1 wall, 2 lid, 3 Dirichlet inflow, 4 copy; may be null
   const double* wJq;       // [K][Nq] (diagnostics) may be null
+  // curved (non-affine) hexahedra only, null otherwise: per-node metric terms [K][9][Nh] (row m9 = comp*3 + operator:
+  // rxJ sxJ txJ ryJ syJ tyJ rzJ szJ tzJ), J at the quadrature nodes [K][Nq], normals [K][4][Nfq] = nxJ nyJ nzJ sJ
+  const double* G9;
+  const double* Jq;
+  const double* nrm;
   unsigned long long* stamps;  // diagnostic builds only (ESDG_DBG & 8): [4096][16] s_memtime deltas
 };
 

@@ -214,7 +214,9 @@ __global__ __launch_bounds__(HW * HNWV) void kh_project(HexTables HT, MeshDev M,
 }
 
 // ---- phase 1 -----------------------------------------------------------------------------------------------
-template <int N1>
+// CURVED: per-node metric terms / normals / J (M.G9, M.nrm, M.Jq) and the reference's per-pair metric average
+// .5 (G_i + G_j) (dg3D_euler_hex.jl:145-151) instead of one affine record per element
+template <int N1, bool CURVED>
 __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phys ph, int remap,
                                                      const double* __restrict__ Q, const double* __restrict__ A_U,
                                                      double* __restrict__ rhs, LsrkFuse lf) {
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
   __shared__ double sPs[HNWV][7 * HW];
   __shared__ double sAccs[HNWV][HEX_NFLD * HW];
   __shared__ double sGs[HNWV][HEX_NFLD * Nfq];
+  __shared__ double sMs[CURVED ? HNWV : 1][CURVED ? 9 * HW : 1];   // metric terms of the volume nodes, [c*3 + op][slot]
   const int64_t nblk = (M.e_count + HNWV - 1) / HNWV;
   const int64_t blk = block_of(nblk, remap != 0);
   if (blk < 0) return;
@@ -238,6 +241,8 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
   double* sAcc = sAccs[wv];
   double* sG = sGs[wv];
   const double* geo = sGeo[wv];
+  double* sM = sMs[CURVED ? wv : 0];
+  constexpr int Nh = Nq + Nfq;
 
   // ---- issue the global loads ---------------------------------------------------------------------
   double U[HEX_NFLD] = {1.0, 0.0, 0.0, 0.0, 1.0};
@@ -263,6 +268,10 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
 #pragma unroll
   for (int c = 0; c < HEX_NFLD; ++c) sAcc[c * HW + lane] = 0.0;
   const int myslot = slot_of(lane);
+  if (CURVED && vin) {
+#pragma unroll
+    for (int m9 = 0; m9 < 9; ++m9) sM[m9 * HW + myslot] = M.G9[(ec * 9 + m9) * Nh + lane];
+  }
 
   // ---- pointwise: primitives + logs ------------------------------------------------------------------
   double acc[HEX_NFLD] = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -296,8 +305,14 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
           const int ns = slot_of(node);
 #pragma unroll
           for (int c = 0; c < 7; ++c) qn[c] = sP[c * HW + ns];
-          const double W = sTab[L.S + (d * N1 + id) * N1 + j] * wt;
-          ec_flux_dir(qv, qn, gx, gy, gz, F);
+          double W = sTab[L.S + (d * N1 + id) * N1 + j] * wt;
+          if (CURVED) {   // metric of the pair = average of the two nodes (the .5 goes into the weight)
+            W *= .5;
+            ec_flux_dir(qv, qn, sM[opd * HW + myslot] + sM[opd * HW + ns], sM[(3 + opd) * HW + myslot] + sM[(3 + opd) * HW + ns],
+                        sM[(6 + opd) * HW + myslot] + sM[(6 + opd) * HW + ns], F);
+          } else {
+            ec_flux_dir(qv, qn, gx, gy, gz, F);
+          }
           if (vin) {
 #pragma unroll
             for (int c = 0; c < HEX_NFLD; ++c) {
@@ -332,8 +347,14 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
         const int ns = slot_of(node);
 #pragma unroll
         for (int c = 0; c < 7; ++c) qn[c] = sP[c * HW + ns];
-        const double W = sTab[L.S + (d * N1 + id) * N1 + j] * sTab[L.WT + d * NN + o];
-        ec_flux_dir(qv, qn, gx, gy, gz, F);
+        double W = sTab[L.S + (d * N1 + id) * N1 + j] * sTab[L.WT + d * NN + o];
+        if (CURVED) {
+          W *= .5;
+          ec_flux_dir(qv, qn, sM[opd * HW + myslot] + sM[opd * HW + ns], sM[(3 + opd) * HW + myslot] + sM[(3 + opd) * HW + ns],
+                      sM[(6 + opd) * HW + myslot] + sM[(6 + opd) * HW + ns], F);
+        } else {
+          ec_flux_dir(qv, qn, gx, gy, gz, F);
+        }
         if (act) {
 #pragma unroll
           for (int c = 0; c < HEX_NFLD; ++c) {
@@ -374,7 +395,11 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
     qp[5] = log_pos(qp[0]);
     qp[6] = log_pos(qp[4]);
     const int face = fc / NN;
-    const double nx = geo[10 + 4 * face], ny = geo[11 + 4 * face], nz = geo[12 + 4 * face], sJ = geo[13 + 4 * face];
+    double nx = geo[10 + 4 * face], ny = geo[11 + 4 * face], nz = geo[12 + 4 * face], sJ = geo[13 + 4 * face];
+    if (CURVED) {
+      const double* nr = M.nrm + ec * 4 * Nfq + fc;
+      nx = nr[0]; ny = nr[Nfq]; nz = nr[2 * Nfq]; sJ = nr[3 * Nfq];
+    }
     double G[HEX_NFLD];
     ec_flux_dir(qm, qp, nx, ny, nz, G);
     if (ph.lf_scale != 0.0) {
@@ -395,7 +420,11 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
     int base, stride;
     line_of<N1>(d, o, base, stride);
     const int opd = d == 0 ? HT.op[0] : (d == 1 ? HT.op[1] : HT.op[2]);
-    const double gx = geo[opd], gy = geo[3 + opd], gz = geo[6 + opd];
+    double gx = geo[opd], gy = geo[3 + opd], gz = geo[6 + opd];
+    if (CURVED) {   // this face node's own metric row of direction d (hybrid node Nq + f)
+      const double* gm = M.G9 + (ec * 9 + opd) * Nh + Nq + fc;
+      gx = gm[0]; gy = gm[3 * Nh]; gz = gm[6 * Nh];
+    }
     const double wtf = sTab[L.WTF + (d * 2 + t) * NN + o];
     int ii = t ? (N1 + 1) / 2 : 0;
 #pragma unroll 1
@@ -405,8 +434,13 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
       const int ns = slot_of(node);
 #pragma unroll
       for (int c = 0; c < 7; ++c) qn[c] = sP[c * HW + ns];
-      const double W = sTab[L.SF + (d * 2 + t) * N1 + ii] * wtf;
-      ec_flux_dir(qn, qm, gx, gy, gz, F);
+      double W = sTab[L.SF + (d * 2 + t) * N1 + ii] * wtf;
+      if (CURVED) {
+        W *= .5;
+        ec_flux_dir(qn, qm, gx + sM[opd * HW + ns], gy + sM[(3 + opd) * HW + ns], gz + sM[(6 + opd) * HW + ns], F);
+      } else {
+        ec_flux_dir(qn, qm, gx, gy, gz, F);
+      }
 #pragma unroll
       for (int c = 0; c < HEX_NFLD; ++c) {
         const double wf = W * F[c];
@@ -440,7 +474,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
         for (int c = 0; c < HEX_NFLD; ++c) tot[c] += w * sG[c * Nfq + fi];
       }
     }
-    const double miJ = -rcp_refined(geo[9]);
+    const double miJ = -rcp_refined(CURVED ? M.Jq[ec * Nq + lq] : geo[9]);
     if (active) {
 #pragma unroll
       for (int c = 0; c < HEX_NFLD; ++c) {
@@ -513,7 +547,11 @@ int launch_rhs_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phys& p
                    double* rhs, const LsrkFuse& lf, hipStream_t s) {
   if (M.e_count <= 0) return 0;
   const int remap = (ph.dbg & 16) ? 0 : 1;
-  ESDG_HEX_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_rhs<N1>), dim3(hex_grid(M.e_count, remap)), dim3(hdev::HW * hdev::HNWV), 0, s, HT, M, ph, remap, Q, A_U, rhs, lf));
+  if (M.G9) {
+    ESDG_HEX_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_rhs<N1, true>), dim3(hex_grid(M.e_count, remap)), dim3(hdev::HW * hdev::HNWV), 0, s, HT, M, ph, remap, Q, A_U, rhs, lf));
+  } else {
+    ESDG_HEX_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_rhs<N1, false>), dim3(hex_grid(M.e_count, remap)), dim3(hdev::HW * hdev::HNWV), 0, s, HT, M, ph, remap, Q, A_U, rhs, lf));
+  }
   return (int)hipGetLastError();
 }
 

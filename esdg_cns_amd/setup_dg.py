@@ -688,14 +688,17 @@ def hex_ops(rd):
     return out
 
 
-def hex_driver_geometry(md, rd, hybrid=True, A3=None):
+def hex_driver_geometry(md, rd, hybrid=True, A3=None, a=0.0):
     """dg3D_euler_hex.jl:88-98: metrics interpolated to the hybrid nodes ([Vq;Vf]*), J and wJq at the quadrature
     nodes.  hybrid=False keeps one row per element instead of Nh (affine meshes; saves 9*Nh*K doubles of host memory
     at scale -- esdg_hex_mesh_t.geo_ld says which)."""
-    if A3 is not None:
-        # the script re-derives all geometry from the (possibly mapped) nodes x,y,z at this point (:67-90); A3 is an
-        # affine map of them (parallelepiped elements: all nine metric terms non-zero)
-        x, y, z = (A3[i, 0] * md.x + A3[i, 1] * md.y + A3[i, 2] * md.z for i in range(3))
+    if A3 is not None or a:
+        # the script re-derives all geometry from the (possibly mapped) nodes x,y,z at this point (:67-90): `a` is its
+        # curved mapping x,y,z += a (x^2-1)(y^2-1)(z^2-1) (:67-73), A3 an affine map (parallelepiped elements)
+        dx = (md.x - 1) * (md.x + 1) * (md.y - 1) * (md.y + 1) * (md.z - 1) * (md.z + 1)
+        x, y, z = md.x + a * dx, md.y + a * dx, md.z + a * dx
+        if A3 is not None:
+            x, y, z = (A3[i, 0] * x + A3[i, 1] * y + A3[i, 2] * z for i in range(3))
         md.x, md.y, md.z = (np.asfortranarray(a) for a in (x, y, z))
         md.xq, md.yq, md.zq = (np.asfortranarray(rd.Vq @ a) for a in (x, y, z))
         geo = geometric_factors_3d(x, y, z, rd.Dr, rd.Ds, rd.Dt)

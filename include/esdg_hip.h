@@ -135,7 +135,9 @@ typedef struct {
 
 typedef struct {
   int64_t K;
-  int32_t geo_ld;  /* rows of the metric arrays: Nh as stored by the driver (:88-90), or any >= 1 (affine: row 1 is used) */
+  int32_t geo_ld;  /* rows of the metric arrays: Nh as stored by the driver (:88-90); affine meshes may pass any >= 1
+                    * (row 1 is used).  Curved elements (the `a != 0` mapping, :67-73) are detected at create and need
+                    * all Nh rows: per-node metrics, per-pair averages (:145-151), per-node normals and J are then used */
   const double *rxJ, *sxJ, *txJ, *ryJ, *syJ, *tyJ, *rzJ, *szJ, *tzJ; /* (geo_ld x K) */
   const double* J;    /* (Nq x K) = Vq*J, :94 */
   const double* wJq;  /* (Nq x K), diagnostics only, may be NULL */

@@ -282,7 +282,7 @@ def hex_smooth_state(x, y, z):
     return rho, u, v, w, p
 
 
-def build_hex_problem(N, Kx, Ky=None, Kz=None, A3=None, grade=0.0):
+def build_hex_problem(N, Kx, Ky=None, Kz=None, A3=None, grade=0.0, a=0.0):
     """examples/dg3D_euler_hex.jl:21-98: periodic box [-1,1]^3, Gauss collocation, a = 0 (affine)."""
     Ky = Kx if Ky is None else Ky
     Kz = Kx if Kz is None else Kz
@@ -293,7 +293,7 @@ def build_hex_problem(N, Kx, Ky=None, Kz=None, A3=None, grade=0.0):
     rd = rs.init_reference_hex(N, rs.gauss_quad(0, 0, N))
     md = rs.init_mesh_3D(VX, VY, VZ, EToV, rd)
     rs.make_periodic_3D(md, rd)
-    ops = rs.hex_driver_setup(md, rd, a=0.0, A3=A3)
+    ops = rs.hex_driver_setup(md, rd, a=a, A3=A3)    # a != 0: the script's curved mapping (:67-73)
     p.Q = [np.asfortranarray(q) for q in ph.primitive_to_conservative_3D(*hex_smooth_state(md.xq, md.yq, md.zq))]
     p.rd, p.md, p.ops, p.VX, p.VY, p.VZ, p.EToV, p.N = rd, md, ops, VX, VY, VZ, EToV, N
     return p

@@ -137,7 +137,7 @@ def hex_random_state(shape, seed=20250117, vel=(0.0, 1.0, 0.0)):
     return [np.asfortranarray(q) for q in ph.primitive_to_conservative_3d(rho, z + vel[0], z + vel[1], z + vel[2], p)]
 
 
-def product_hex_problem(N, Kx, Ky=None, Kz=None, elem_range=None, hybrid=True, A3=None, grade=0.0):
+def product_hex_problem(N, Kx, Ky=None, Kz=None, elem_range=None, hybrid=True, A3=None, grade=0.0, a=0.0):
     VX, VY, VZ, EToV = sd.uniform_hex_mesh(Kx, Ky, Kz)
     if grade:
         VX, VY, VZ = grade_vertices(VX, grade), grade_vertices(VY, -0.7 * grade), grade_vertices(VZ, 0.5 * grade)
@@ -145,7 +145,7 @@ def product_hex_problem(N, Kx, Ky=None, Kz=None, elem_range=None, hybrid=True, A
     md = sd.init_mesh_3d((VX, VY, VZ), EToV, rd, elem_range=elem_range)
     sd.make_periodic_3d(md, rd)
     ops = sd.hex_ops(rd)
-    sd.hex_driver_geometry(md, rd, hybrid=hybrid, A3=A3)
+    sd.hex_driver_geometry(md, rd, hybrid=hybrid, A3=A3, a=a)
     return rd, md, ops, hex_smooth_state(md.xq, md.yq, md.zq)
 
 

@@ -188,3 +188,35 @@ def test_hex_graded_mesh_every_element_its_own_geometry(eng_mod, oracle_lib):
         floor = noise_floor(lambda q: ho.rhs(q)[0], p.Q)
         print(f"graded hex mesh lf={lf}: err={err:.2e} oracle-noise-floor={floor:.2e}")
         assert err <= max(TOL, 4 * floor), (err, floor)
+
+
+@pytest.mark.parametrize("N,K3", [(3, (4, 4, 4)), (2, (3, 3, 4))])
+def test_hex_curved_mesh_matches_oracle(eng_mod, oracle_lib, N, K3):
+    """The script's curved mapping x,y,z += a (x^2-1)(y^2-1)(z^2-1) (dg3D_euler_hex.jl:67-73; a = 0 in the script
+    itself): per-node metric terms at the hybrid nodes, per-pair metric averages (:145-151), per-node normals and J.
+    Entropy conservation (`@show rhstest`) and the free stream hold on the curved mesh too (curl-form metrics)."""
+    from oracle import oracle as orc
+    a = 0.12
+    p = orc.build_hex_problem(N, *K3, a=a)
+    assert np.abs(p.md.rxJ - p.md.rxJ[0]).max() > 1e-3                      # really non-affine
+    rd, md, ops, Q = product_hex_problem(N, *K3, a=a)
+    for n in ("rxJ", "tyJ", "szJ", "J", "nxJ", "nzJ", "sJ"):
+        assert np.abs(getattr(md, n) - getattr(p.md, n)).max() < 1e-12, n
+    for lf in (0.0, 0.25):
+        ho = orc.HexOracle(p, lf)
+        eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.EULER_HEX_COLLOCATED, lf_scale=lf)
+        for name, state in (("smooth", p.Q), ("random", hex_random_state(p.Q[0].shape, vel=(.13, 1, -.07)))):
+            ref = ho.rhs(state)[0]
+            err = rel_l2(_gpu_rhs(eng, state), ref)
+            floor = noise_floor(lambda q: ho.rhs(q)[0], state)
+            print(f"curved hex N={N} lf={lf} {name}: err={err:.2e} oracle-noise-floor={floor:.2e}")
+            assert err <= max(TOL, 4 * floor), (name, err, floor)
+        c = [np.full_like(p.Q[0], v) for v in (1.3, 0.4, -0.3, 0.2, 2.9)]
+        assert max(np.abs(x).max() for x in _gpu_rhs(eng, c)) < 1e-10          # free stream on the curved mesh
+        if lf == 0.0:
+            Qd = eng.upload(hex_random_state(p.Q[0].shape, vel=(.13, 1, -.07)))
+            r = eng.rhs(Qd)
+            rt = eng.rhstest(Qd, r)
+            scale = float(np.sum(np.abs(md.wJq)) * float(r.abs().max()))
+            print(f"curved hex rhstest (LF off) {rt:.3e} scale {scale:.3e}")
+            assert abs(rt) < 1e-12 * scale
