@@ -659,7 +659,8 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
                                              const double* __restrict__ B, double* rhs, LsrkFuse lf) {
   using LD = RhsLds<N1, VISC>;
   constexpr int Nq = LD::Nq, Nfq = LD::Nfq, Nh = LD::Nh, E = LD::E, NF = N1 / 2;
-  constexpr int UNR_K = VISC ? (NF > 0 ? NF : 1) : 1, UNR_T = VISC ? 2 : 1;
+  constexpr int NFULL = (N1 - 1) / 2;   // full circulant rounds per direction (the antipodal round of even N1 is separate)
+  constexpr int UNR_K = VISC ? (NFULL > 0 ? NFULL : 1) : 1, UNR_T = VISC ? 2 : 1;
   constexpr TensorLayout L(N1);
   __shared__ double sTab[L.NDBL];
   __shared__ int sInt[L.NINT];
@@ -763,27 +764,21 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
       const int pos = ln.pos(d), oth = ln.oth(d), stride = d == 0 ? 1 : N1;
       const double wt = sTab[L.WT + d * N1 + oth];
 #pragma unroll UNR_K   // unrolled only where it does not cost an occupancy step (A/B: CNS -0.7 %, Euler +3 %)
-      for (int k = 0; k < NF; ++k) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int o = k + 1;
-        const bool half = (N1 % 2 == 0) && (o == N1 / 2);
-        int pp = pos + o;
+      for (int k = 0; k < NFULL; ++k) {   // full circulant rounds: pair (pos, pos+k+1 mod N1), every lane busy
+        int pp = pos + k + 1;
         if (pp >= N1) pp -= N1;
-        if (!(half && pos >= N1 / 2)) {
-          const int pid = ln.q + (pp - pos) * stride;
-          const double cw = sTab[L.S + (d * N1 + pos) * N1 + pp] * wt;
-          const double2* pr = reinterpret_cast<const double2*>(sQh + (ln.ev * Nh + pid) * 6);
-          const double2 p0 = pr[0], p1 = pr[1], p2 = pr[2];
-          const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
-          double Fd[4];
-          ec_flux_dir<MODAL>(qh, qj, cw * gx, cw * gy, Fd);
-          double* tgt = sAcc + ln.ev * 4 * Nq + pid;
+        const int pid = ln.q + (pp - pos) * stride;
+        const double cw = sTab[L.S + (d * N1 + pos) * N1 + pp] * wt;
+        const double2* pr = reinterpret_cast<const double2*>(sQh + (ln.ev * Nh + pid) * 6);
+        const double2 p0 = pr[0], p1 = pr[1], p2 = pr[2];
+        const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
+        double Fd[4];
+        ec_flux_dir<MODAL>(qh, qj, cw * gx, cw * gy, Fd);
+        double* tgt = sAcc + ln.ev * 4 * Nq + pid;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            acc[c] += Fd[c];
-            lds_add(tgt + c * Nq, -Fd[c]);
-          }
+        for (int c = 0; c < 4; ++c) {
+          acc[c] += Fd[c];
+          lds_add(tgt + c * Nq, -Fd[c]);
         }
       }
 #pragma unroll UNR_T
@@ -806,6 +801,32 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
           const double w = rot == 0 ? vv[i] : (rot == 1 ? vv[(i + 1) & 3] : (rot == 2 ? vv[(i + 2) & 3] : vv[(i + 3) & 3]));
           lds_add(tgt + ((i + rot) & 3) * Nfq, -w);
         }
+      }
+    }
+    // even N1: the antipodal pairs (pos, pos + N1/2) exist once per two lanes of a line.  With b_d = (pos_d >= N1/2)
+    // and S = {b_0 != b_1} every such pair has exactly one endpoint in S, so ONE round serves both directions:
+    // S-lanes take their d = 0 pair, the other lanes their d = 1 pair.
+    if (N1 % 2 == 0) {
+      constexpr int H = N1 / 2;
+      const bool inS = (ln.a >= H) != (ln.b >= H);
+      const int d = inS ? 0 : 1;
+      const int op = d == 0 ? TT.op0 : TT.op1;
+      const double gx = 2 * g[op], gy = 2 * g[2 + op];
+      const int pos = ln.pos(d), oth = ln.oth(d), stride = d == 0 ? 1 : N1;
+      int pp = pos + H;
+      if (pp >= N1) pp -= N1;
+      const int pid = ln.q + (pp - pos) * stride;
+      const double cw = sTab[L.S + (d * N1 + pos) * N1 + pp] * sTab[L.WT + d * N1 + oth];
+      const double2* pr = reinterpret_cast<const double2*>(sQh + (ln.ev * Nh + pid) * 6);
+      const double2 p0 = pr[0], p1 = pr[1], p2 = pr[2];
+      const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
+      double Fd[4];
+      ec_flux_dir<MODAL>(qh, qj, cw * gx, cw * gy, Fd);
+      double* tgt = sAcc + ln.ev * 4 * Nq + pid;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc[c] += Fd[c];
+        lds_add(tgt + c * Nq, -Fd[c]);
       }
     }
   }
