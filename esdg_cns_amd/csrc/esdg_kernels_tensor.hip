@@ -681,7 +681,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
   // ---- every global load of this workgroup is issued before any arithmetic -------------------
   double x[4];
   issue_state_loads<N1>(Q, M.K, e0, vactive, x);
-  double qM[8], qP[8], vPn[3] = {0, 0, 0}, bPn[3] = {0, 0, 0};
+  double qM[8], qP[8], vPn[3] = {0, 0, 0}, bPn[3] = {0, 0, 0}, bOwn[3] = {0, 0, 0};
   int64_t mpk = 0;
   int bcf = 0;
 #pragma unroll
@@ -860,6 +860,11 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
       const double* bp = B + mpk * B_NC;
 #pragma unroll
       for (int c = 0; c < 3; ++c) bPn[c] = bp[c];
+      if (!WALLS) {   // own normal stress: phase 1 already computed it (no walls: the x/y split is not needed)
+        const double* bo = B + ((e0 + ln.ef) * Nfq + ln.fn) * B_NC;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bOwn[c] = bo[c];
+      }
     }
     // sigma = K(v) grad v at the Gauss nodes was computed (and its face traces exchanged) by phase 1: reload it
     // instead of recomputing gradient and stress (HBM has headroom here, the LDS does not)
@@ -893,8 +898,13 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     // its own outward normal = minus ours (dg_div! :606)
     if (ln.fin) {
       const double* gn = M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
-      double sn[3], fx[3], fy[3], sj[3];
-      face_normal_stress<N1>(ln, sTab, sInt, sS, gn[0], gn[1], sn, fx, fy);
+      double sn[3], fx[3] = {0, 0, 0}, fy[3] = {0, 0, 0}, sj[3];
+      if (WALLS) {
+        face_normal_stress<N1>(ln, sTab, sInt, sS, gn[0], gn[1], sn, fx, fy);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sn[c] = bOwn[c];
+      }
 #pragma unroll
       for (int c = 0; c < 3; ++c) sj[c] = .5 * (-bPn[c] - sn[c]);
       if (bcf >= 3) {   // sigma+ = sigma- (dg2D_CNS_modalESDG.jl:205-216)
