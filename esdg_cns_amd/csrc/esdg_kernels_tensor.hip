@@ -414,23 +414,11 @@ __global__ __launch_bounds__(TW * NWV) void kt_project(TensorTables TT, MeshDev 
 // face lanes: projected entropy variables at the face node, exterior state (neighbour, or the wall
 // boundary condition of impose_BCs_entropyvars!, cavity :178-216), half jump, penalty tau*[[v]] (:817-837)
 //   bc: 0 interior/periodic, 1 wall, 2 lid;  gn = (nxJ, nyJ, sJ) of the face;  pn_out (registers) may be null (phase 1)
-template <int N1>
-__device__ __forceinline__ void visc_face_jumps(const Lane<N1>& ln, const double* sTab, const int* sInt,
-                                                const double* sVn, const double* vPin, int bc, const double* gn,
-                                                const Phys& ph, double* sDv, double* pn_out) {
-  constexpr int Nq = N1 * N1, Nfq = 4 * N1;
-  constexpr TensorLayout L(N1);
-  int d, t, o;
-  face_dto(sInt, L.FINV, ln.fn, d, t, o);
-  double vf[3] = {0, 0, 0};
-#pragma unroll
-  for (int j = 0; j < N1; ++j) {
-    const double w = sTab[L.EE + (d * 2 + t) * N1 + j];
-    const double* r = sVn + ln.ef * 3 * Nq + node_of<N1>(d, j, o);
-    vf[0] += w * r[0];
-    vf[1] += w * r[Nq];
-    vf[2] += w * r[2 * Nq];
-  }
+// exterior entropy variables and penalty at one face node, given its own projected values vf = (v2,v3,v4):
+// vP = neighbour's values, or the closure of impose_BCs_entropyvars! (cavity :178-216 / modalESDG :187-203);
+// dV = vP - vf; pn_out (may be null) = tau*[[v]] with the boundary overrides of :817-837
+__device__ __forceinline__ void face_jump_and_penalty(const double* vf, const double* vPin, int bc, const double* gn,
+                                                      const Phys& ph, double* dV, double* pn_out) {
   double vP[3] = {vPin[0], vPin[1], vPin[2]};
   if (bc >= 3) {                                          // shock-tube closures, dg2D_CNS_modalESDG.jl:187-203
 #pragma unroll
@@ -455,24 +443,45 @@ __device__ __forceinline__ void visc_face_jumps(const Lane<N1>& ln, const double
       vP[2] = vf[2];
     }
   }
-  double dV[3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    dV[c] = vP[c] - vf[c];
-    if (sDv) sDv[(ln.ef * 3 + c) * Nfq + ln.fn] = .5 * dV[c];
-  }
+  for (int c = 0; c < 3; ++c) dV[c] = vP[c] - vf[c];
   if (pn_out) {
     const double iv4 = rcp_refined(vf[2]);
     const double tau = -iv4 / ph.Re;
-    double pn[3] = {tau * dV[0], tau * dV[1], tau * dV[2]};
+    pn_out[0] = tau * dV[0]; pn_out[1] = tau * dV[1]; pn_out[2] = tau * dV[2];
     if (bc) {   // :827-837
       const double a2 = .5 * (vP[0] + vf[0]), a3 = .5 * (vP[1] + vf[1]);
       double s = a2 * dV[0] + a3 * dV[1];
       if (ph.BCTYPE != 1) s += dV[2] * dV[2] * .5;
-      pn[2] = -tau * s * iv4;
+      pn_out[2] = -tau * s * iv4;
     }
+  }
+}
+
+// face lanes: projected entropy variables at the face node by interpolation of the nodal ones (Vf*VU), half jump to
+// sDv (may be null), penalty (may be null).  bc: 0 interior/periodic, 1 wall, 2 lid, 3 inflow, 4 copy
+template <int N1>
+__device__ __forceinline__ void visc_face_jumps(const Lane<N1>& ln, const double* sTab, const int* sInt,
+                                                const double* sVn, const double* vPin, int bc, const double* gn,
+                                                const Phys& ph, double* sDv, double* pn_out) {
+  constexpr int Nq = N1 * N1, Nfq = 4 * N1;
+  constexpr TensorLayout L(N1);
+  int d, t, o;
+  face_dto(sInt, L.FINV, ln.fn, d, t, o);
+  double vf[3] = {0, 0, 0};
 #pragma unroll
-    for (int c = 0; c < 3; ++c) pn_out[c] = pn[c];
+  for (int j = 0; j < N1; ++j) {
+    const double w = sTab[L.EE + (d * 2 + t) * N1 + j];
+    const double* r = sVn + ln.ef * 3 * Nq + node_of<N1>(d, j, o);
+    vf[0] += w * r[0];
+    vf[1] += w * r[Nq];
+    vf[2] += w * r[2 * Nq];
+  }
+  double dV[3];
+  face_jump_and_penalty(vf, vPin, bc, gn, ph, dV, pn_out);
+  if (sDv) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sDv[(ln.ef * 3 + c) * Nfq + ln.fn] = .5 * dV[c];
   }
 }
 
@@ -648,7 +657,7 @@ struct RhsLds {
   static constexpr int nQh = E * Nh * 6;                 // prims+logs of all hybrid nodes; also interp scratch
   static constexpr int nFlux = E * (4 * Nq + 4 * Nfq);   // sAcc + sG
   static constexpr int nVisc = VISC ? E * 3 * Nfq : 0;   // sSj(3) per face node (sVn and sS live in the sQh region)
-  static_assert(!VISC || 9 * Nq <= 6 * Nh, "sVn + sS must fit in the sQh region");
+  static_assert(!VISC || 6 * Nq <= 6 * Nh, "sS must fit in the sQh region");
   static constexpr int nR2 = nFlux > nVisc ? nFlux : nVisc;
   static_assert(8 * Nq <= 6 * Nh, "interp scratch must fit in the sQh region");
 };
@@ -681,7 +690,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
   // ---- every global load of this workgroup is issued before any arithmetic -------------------
   double x[4];
   issue_state_loads<N1>(Q, M.K, e0, vactive, x);
-  double qM[8], qP[8], vPn[3] = {0, 0, 0}, bPn[3] = {0, 0, 0}, bOwn[3] = {0, 0, 0};
+  double qM[8], qP[8], pnr[3] = {0, 0, 0}, bPn[3] = {0, 0, 0}, bOwn[3] = {0, 0, 0};   // pnr: penalty tau*[[v]] of the face node
   int64_t mpk = 0;
   int bcf = 0;
 #pragma unroll
@@ -723,6 +732,14 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     dq[1] = make_double2(qM[2], qM[3]);
     dq[2] = make_double2(qM[4], qM[5]);
     const double* gn = M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
+    if (VISC && ph.viscous_dissp) {
+      // penalty tau*[[v]] (:817-837): own and neighbour projected entropy variables are the entropy variables of the
+      // two trace states (see kt_project), so no interpolation of nodal values is needed here
+      const double bM = 2 * Gas<MODAL>::GM1 * qM[3], bP = 2 * Gas<MODAL>::GM1 * qP[3];
+      const double vf[3] = {bM * qM[1], bM * qM[2], -bM}, vPn[3] = {bP * qP[1], bP * qP[2], -bP};
+      double dV[3];
+      face_jump_and_penalty(vf, vPn, bcf, gn, ph, dV, pnr);
+    }
     if (bcf >= 3) {   // shock-tube closures (dg2D_CNS_modalESDG.jl:168-185): Dirichlet state / copy, lam = lamP = 0
 #pragma unroll
       for (int c = 0; c < 6; ++c) qP[c] = bcf == 3 ? ph.inflow_q[c] : qM[c];
@@ -736,10 +753,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
       qP[1] = qM[1] - 2 * un * nx;
       qP[2] = qM[2] - 2 * un * ny;
     }
-    if (VISC) {   // neighbour's projected entropy variables (v2,v3,v4), rebuilt from its trace record (see kt_project)
-      const double b2 = 2 * Gas<MODAL>::GM1 * qP[3];
-      vPn[0] = b2 * qP[1]; vPn[1] = b2 * qP[2]; vPn[2] = -b2;
-    }
+
     double Fn[4];
     ec_flux_dir<MODAL>(qM, qP, gn[0], gn[1], Fn);
     const double LFc = ph.inviscid_dissp ? ph.lf_scale * fmax(qM[6], qP[6]) * gn[2] : 0.0;
@@ -868,9 +882,8 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     }
     // sigma = K(v) grad v at the Gauss nodes was computed (and its face traces exchanged) by phase 1: reload it
     // instead of recomputing gradient and stress (HBM has headroom here, the LDS does not)
-    double* sVn = sQh;                       // [E][3][Nq]  (v2,v3,v4): primitives no longer needed
     double* sSj = sR2;                       // [E][3][Nfq]  stress jump (+ J * penalty, see below)
-    double* sS = sQh + E * 3 * Nq;           // [E][Nq][6]   behind sVn in the dead primitive region
+    double* sS = sQh;                        // [E][Nq][6]   in the dead primitive region
     double2 sg0 = make_double2(0, 0), sg1 = sg0, sg2 = sg0;
     if (vactive) {
       const int64_t n = e0 * Nq + ln.tid, KN = M.K * Nq;
@@ -878,22 +891,11 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
       sg1 = make_double2(SG[2 * KN + n], SG[3 * KN + n]);
       sg2 = make_double2(SG[4 * KN + n], SG[5 * KN + n]);
     }
-    const bool pen = ph.viscous_dissp != 0;
-    if (ln.vin && pen) {
-      double V[4];
-      v_of_prim<MODAL>(qh, V);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) sVn[(ln.ev * 3 + c) * Nq + ln.q] = V[c + 1];
-    }
     if (ln.vin) {
       double2* r = reinterpret_cast<double2*>(sS + (ln.ev * Nq + ln.q) * 6);
       r[0] = sg0; r[1] = sg1; r[2] = sg2;
     }
     __syncthreads();
-    double pnr[3] = {0, 0, 0};               // penalty tau*[[v]] of this face node (:817-837)
-    if (ln.fin && pen)
-      visc_face_jumps<N1>(ln, sTab, sInt, sVn, vPn, bcf, M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1),
-                          ph, nullptr, pnr);
     // stress jumps .5*((sxP-sxf)*nxJ + (syP-syf)*nyJ): the neighbour's normal stress from B carries
     // its own outward normal = minus ours (dg_div! :606)
     if (ln.fin) {
