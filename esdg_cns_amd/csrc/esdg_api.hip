@@ -753,7 +753,9 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t nodes = (size_t)(K * Nfq + c->nghost);
   size_t off = 0;
-  c->off_AU = off; off = align(off + nodes * c->au_nc * sizeof(double));
+  // A_U: generic kernels one array of 5-double records; tensor kernels two arrays of 4-double records back to back
+  c->off_AU = off; off = align(off + nodes * (use_fast ? 2 * FAU_NC : AU_NC) * sizeof(double));
+  c->M.trace_nodes = (int64_t)nodes;
   const bool need_Av = visc && !use_fast;   // the tensor kernels rebuild the neighbour's (v2,v3,v4) from its A_U record
   if (visc) {
     if (need_Av) { c->off_Av = off; off = align(off + nodes * AV_NC * sizeof(double)); }
@@ -764,6 +766,11 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   Exchange x0{0, (visc && use_fast) ? 1 : c->nphases - 1, c->au_nc, c->off_AU, off};
   off = align(off + (size_t)c->nsend * c->au_nc * sizeof(double));
   c->xch.push_back(x0);
+  if (use_fast) {   // second half of the trace (log rho, log beta, lam, E): only the last phase reads it
+    Exchange x0b{0, c->nphases - 1, FAU_NC, c->off_AU + nodes * FAU_NC * sizeof(double), off};
+    off = align(off + (size_t)c->nsend * FAU_NC * sizeof(double));
+    c->xch.push_back(x0b);
+  }
   if (need_Av) {
     Exchange x1{0, 1, AV_NC, c->off_Av, off};
     off = align(off + (size_t)c->nsend * AV_NC * sizeof(double));
@@ -968,8 +975,6 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
   if (ctx->dim == 3) {
     if (phase == 0) {
       rc = launch_project_hex(ctx->T.N1, ctx->HT, ctx->M, ctx->ph, Q, A_U, s);
-      if (!rc && ctx->nsend && !ranged)
-        rc = launch_pack(A_U, ctx->au_nc, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[0].send_off), s);
     } else {
       if (!rhs && !lf.Qw) return fail(ESDG_ERR_ARG, "rhs output is null");
       rc = launch_rhs_hex(ctx->T.N1, ctx->HT, ctx->M, ctx->ph, Q, A_U, rhs, lf, s);
@@ -977,20 +982,21 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
   } else if (phase == 0) {
     rc = ctx->use_fast ? launch_project_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, A_v, s)
                        : launch_project(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, s);
-    if (!rc && ctx->nsend && !ranged) {
-      rc = launch_pack(A_U, ctx->au_nc, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[0].send_off), s);
-      if (!rc && need_Av) rc = launch_pack(A_v, AV_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch[1].send_off), s);
-    }
   } else if (visc && phase == 1) {
     rc = ctx->use_fast ? launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, SG, nullptr, s)
                        : launch_sigma(ctx->T, ctx->M, ctx->ph, Q, A_v, B, s);
-    if (!rc && ctx->nsend && !ranged) rc = launch_pack(B, B_NC, sl, ctx->nsend, reinterpret_cast<double*>(ctx->ws + ctx->xch.back().send_off), s);
   } else {
     if (!rhs && !lf.Qw) return fail(ESDG_ERR_ARG, "rhs output is null");
     if (lf.Qw && !ctx->use_fast) return fail(ESDG_ERR_STATE, "the fused RK update needs the tensor kernels");
     rc = ctx->use_fast ? launch_rhs_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s)
                        : launch_rhs(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, B, rhs, s);
   }
+  // pack what this phase produced for the off-rank neighbours (ranged launches leave that to esdg_halo_pack)
+  if (!rc && ctx->nsend && !ranged)
+    for (const Exchange& x : ctx->xch)
+      if (!rc && x.after_phase == phase)
+        rc = launch_pack(reinterpret_cast<const double*>(ctx->ws + x.buf_off), x.ncomp, sl, ctx->nsend,
+                         reinterpret_cast<double*>(ctx->ws + x.send_off), s);
   if (rc) return fail(ESDG_ERR_NO_DEVICE, "kernel launch failed in phase %d: %s", phase, hipGetErrorString((hipError_t)rc));
   return ESDG_OK;
 }

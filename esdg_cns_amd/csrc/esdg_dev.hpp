@@ -40,8 +40,9 @@ struct Tables {
   const double* Pq;        // [Np][Nq] row-major (modal)
 };
 
-// Trace record of the tensor kernels (esdg_kernels_tensor.hip): (rho, u, v, beta, log rho, log beta, lam, E)
-constexpr int FAU_NC = 8;
+// Trace of the tensor kernels (esdg_kernels_tensor.hip): (rho, u, v, beta | log rho, log beta, lam, E), stored as two
+// arrays of FAU_NC-double records so that phase 1 (which needs u, v, beta only) fetches half the bytes
+constexpr int FAU_NC = 4;
 
 struct TensorTables;
 struct MeshDev;
@@ -58,6 +59,8 @@ int launch_rhs_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Ph
 
 struct MeshDev {
   int64_t K;               // local elements
+  int64_t trace_nodes;       // K*Nfq + ghost slots: the tensor kernels keep the A_U trace as two arrays of 4-double
+                             // records, (rho,u,v,beta) at A_U and (log rho,log beta,lam,E) at A_U + 4*trace_nodes
   int64_t e_begin, e_count;  // element range a launch covers (tensor / hex kernels; the host sets 0, K for full launches)
   const double* geo;       // [K][GEO_STRIDE]
   const int32_t* mapP;     // [K][Nfq]  local face-node index, or ghost slot >= K*Nfq

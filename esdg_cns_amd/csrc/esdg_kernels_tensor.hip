@@ -400,10 +400,11 @@ __global__ __launch_bounds__(TW * NWV) void kt_project(TensorTables TT, MeshDev 
     const double lam = lf_lambda<MODAL>(Uf, g[0], g[1], g[2]);
     const int64_t n = (e0 + ln.ef) * Nfq + ln.fn;
     double2* a = reinterpret_cast<double2*>(A_U + n * FAU_NC);
+    double2* a2 = reinterpret_cast<double2*>(A_U + (M.trace_nodes + n) * FAU_NC);
     a[0] = make_double2(qf[0], qf[1]);
     a[1] = make_double2(qf[2], qf[3]);
-    a[2] = make_double2(qf[4], qf[5]);
-    a[3] = make_double2(lam, Uf[3]);
+    a2[0] = make_double2(qf[4], qf[5]);
+    a2[1] = make_double2(lam, Uf[3]);
   }
   (void)A_v;
 }
@@ -701,11 +702,15 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     if (WALLS) bcf = M.bc[n];   // WALLS <=> M.bc != null (periodic meshes compile the wall branches away)
     const double2* aM = reinterpret_cast<const double2*>(A_U + n * FAU_NC);
     const double2* aP = reinterpret_cast<const double2*>(A_U + mp * FAU_NC);
+    const double2* aM2 = reinterpret_cast<const double2*>(A_U + (M.trace_nodes + n) * FAU_NC);
+    const double2* aP2 = reinterpret_cast<const double2*>(A_U + (M.trace_nodes + mp) * FAU_NC);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const double2 m = aM[c], p = aP[c];
+    for (int c = 0; c < 2; ++c) {
+      const double2 m = aM[c], p = aP[c], m2 = aM2[c], p2 = aP2[c];
       qM[2 * c] = m.x; qM[2 * c + 1] = m.y;
       qP[2 * c] = p.x; qP[2 * c + 1] = p.y;
+      qM[4 + 2 * c] = m2.x; qM[5 + 2 * c] = m2.y;
+      qP[4 + 2 * c] = p2.x; qP[5 + 2 * c] = p2.y;
     }
     mpk = mp;
   }
