@@ -22,7 +22,11 @@ class esdg_mesh_t(C.Structure):
                 ("J", c_double_p), ("wJq", c_double_p), ("nxJ", c_double_p), ("nyJ", c_double_p), ("sJ", c_double_p),
                 ("mapP", c_int64_p), ("mapB", c_int64_p), ("NmapB", C.c_int64), ("bkind", c_uint8_p),
                 ("elem_offset", C.c_int64), ("Kglobal", C.c_int64), ("nranks", C.c_int32), ("rank", C.c_int32),
-                ("rank_offsets", c_int64_p)]
+                ("rank_offsets", c_int64_p), ("vlid", c_double_p)]
+
+
+class esdg_err_ops_t(C.Structure):
+    _fields_ = [("Nq2", C.c_int32)] + [(n, c_double_p) for n in ("Vq2", "wq2", "x", "y", "J", "Vf", "wf")]
 
 
 class esdg_hex_ops_t(C.Structure):
@@ -66,6 +70,10 @@ SYMBOLS = {
     "esdg_rhs_phase_lsrk": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp]),
     "esdg_rhstest": (C.c_int, [_vp, _vp, _vp, c_double_p, _vp]),
     "esdg_check_state": (C.c_int, [_vp, _vp, c_double_p, _vp]),
+    "esdg_error_setup": (C.c_int, [_vp, C.POINTER(esdg_err_ops_t)]),
+    "esdg_error_l2": (C.c_int, [_vp, _vp, C.c_int32, c_double_p, C.c_double, c_double_p, _vp]),
+    "esdg_error_nodal": (C.c_int, [_vp, _vp, C.c_int32, c_double_p, C.c_double, c_double_p, _vp]),
+    "esdg_error_boundary_velocity": (C.c_int, [_vp, _vp, C.c_double, c_double_p, _vp]),
     "esdg_set_parts": (C.c_int, [_vp, C.c_int]),
     "esdg_viscous_entropy_test": (C.c_int, [_vp, _vp, c_double_p, _vp]),
     "esdg_rhs_host": (C.c_int, [_vp, C.POINTER(c_double_p), C.POINTER(c_double_p)]),

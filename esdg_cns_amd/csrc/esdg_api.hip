@@ -458,8 +458,11 @@ struct esdg_ctx {
   int Np = 0, Nq = 0, Nfq = 0;
   // device storage
   DevBuf d_pair_ij, d_pair_c, d_inc_ptr, d_inc, d_Ef_i, d_Ef_v, d_Ph_i, d_Ph_v, d_Lf_i, d_Lf_v, d_Dr_i, d_Dr_v, d_Ds_i,
-      d_Ds_v, d_Vq, d_Pq, d_geo, d_mapP, d_bc, d_wJq, d_sendlist, d_partial;
+      d_Ds_v, d_Vq, d_Pq, d_geo, d_mapP, d_bc, d_vlid, d_wJq, d_sendlist, d_partial;
   DevBuf t_dbl, t_int, d_stamps, d_G9, d_Jq, d_nrm;
+  DevBuf e_Vq2, e_wq2, e_x, e_y, e_J, e_Vf, e_wf;   // error functionals (esdg_error_setup)
+  ErrDev E{};
+  bool have_err = false;
   // halo plan
   std::vector<int32_t> nbr_rank;
   std::vector<int64_t> nbr_send_off, nbr_send_cnt, nbr_recv_off, nbr_recv_cnt;  // in face nodes
@@ -699,6 +702,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   UP(d_geo, geo); UP(d_mapP, mapP); UP(d_sendlist, sendlist);
   // wall-boundary flags per local face node: 1 wall, 2 lid (init_BC_funs, cavity :135-155)
   std::vector<uint8_t> bcflag;
+  std::vector<double> vlid;
   if (mesh->NmapB > 0) {
     if (!use_fast) return fail(ESDG_ERR_STRUCTURE, "wall boundary conditions need tensor-structured operators (generic kernels are periodic-only)");
     bcflag.assign((size_t)K * Nfq, 0);
@@ -711,8 +715,13 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
       }
       if (mapP[l] != l) return fail(ESDG_ERR_ARG, "mapB[%lld] is not a boundary node (mapP != mapM)", (long long)i);
       bcflag[l] = (uint8_t)(1 + (mesh->bkind ? (mesh->bkind[i] != 0) : 0));
+      if (mesh->vlid && bcflag[l] == 2) {
+        if (vlid.empty()) vlid.assign((size_t)K * Nfq, 1.0);
+        vlid[l] = mesh->vlid[i];
+      }
     }
     UP(d_bc, bcflag);
+    if (!vlid.empty()) UP(d_vlid, vlid);
   }
   if (use_fast) {
     UP(t_dbl, th.dbl); UP(t_int, th.ints);
@@ -740,6 +749,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   T.Vq = c->d_Vq.as<double>(); T.Pq = c->d_Pq.as<double>();
   c->M.K = K; c->M.e_begin = 0; c->M.e_count = K;
   c->M.geo = c->d_geo.as<double>(); c->M.mapP = c->d_mapP.as<int32_t>(); c->M.bc = bcflag.empty() ? nullptr : c->d_bc.as<uint8_t>();
+  c->M.vlid = vlid.empty() ? nullptr : c->d_vlid.as<double>();
   set_interior(c, pl.mapP, K, Nfq);
   c->M.wJq = mesh->wJq ? c->d_wJq.as<double>() : nullptr;
   c->M.stamps = nullptr;
@@ -905,7 +915,7 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
   c->HT.ints = c->t_int.as<int>();
   for (int d = 0; d < 3; ++d) c->HT.op[d] = hh.op[d];
   c->M.K = K; c->M.e_begin = 0; c->M.e_count = K;
-  c->M.geo = c->d_geo.as<double>(); c->M.mapP = c->d_mapP.as<int32_t>(); c->M.bc = nullptr;
+  c->M.geo = c->d_geo.as<double>(); c->M.mapP = c->d_mapP.as<int32_t>(); c->M.bc = nullptr; c->M.vlid = nullptr;
   c->M.G9 = curved ? c->d_G9.as<double>() : nullptr;
   c->M.Jq = curved ? c->d_Jq.as<double>() : nullptr;
   c->M.nrm = curved ? c->d_nrm.as<double>() : nullptr;
@@ -1118,6 +1128,128 @@ int esdg_viscous_entropy_test(esdg_ctx* ctx, const double* Q, double* out, void*
   double t = 0.0;
   for (double v : h) t += v;
   *out = t;
+  return ESDG_OK;
+}
+
+// ---- error functionals ----------------------------------------------------------
+static std::vector<double> to_row_major(const double* A, int rows, int cols) {   // column-major (rows x cols) -> [rows][cols]
+  std::vector<double> r((size_t)rows * cols);
+  for (int i = 0; i < rows; ++i)
+    for (int j = 0; j < cols; ++j) r[(size_t)i * cols + j] = A[(size_t)j * rows + i];
+  return r;
+}
+
+int esdg_error_setup(esdg_ctx* ctx, const esdg_err_ops_t* e) {
+  if (!ctx || !e) return fail(ESDG_ERR_ARG, "null argument");
+  if (ctx->dim != 2) return fail(ESDG_ERR_ARG, "the error functionals are those of the 2D drivers");
+  if (!e->x || !e->y || !e->J) return fail(ESDG_ERR_ARG, "x, y, J are required");
+  if (e->Nq2 < 0 || (e->Nq2 > 0 && (!e->Vq2 || !e->wq2))) return fail(ESDG_ERR_ARG, "Nq2 > 0 needs Vq2 and wq2");
+  if ((e->Vf != nullptr) != (e->wf != nullptr)) return fail(ESDG_ERR_ARG, "Vf and wf go together");
+  esdg_ctx* c = ctx;
+  c->have_err = false;
+  for (DevBuf* b : {&c->e_Vq2, &c->e_wq2, &c->e_x, &c->e_y, &c->e_J, &c->e_Vf, &c->e_wf})
+    if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
+  const size_t n = (size_t)c->K * c->Np;
+  int rc;
+#define UP(buf, vec) if ((rc = c->buf.upload(vec)) != 0) return rc
+  UP(e_x, std::vector<double>(e->x, e->x + n));
+  UP(e_y, std::vector<double>(e->y, e->y + n));
+  UP(e_J, std::vector<double>(e->J, e->J + n));
+  if (e->Nq2 > 0) {
+    UP(e_Vq2, to_row_major(e->Vq2, e->Nq2, c->Np));
+    UP(e_wq2, std::vector<double>(e->wq2, e->wq2 + e->Nq2));
+  }
+  if (e->Vf) {
+    UP(e_Vf, to_row_major(e->Vf, c->Nfq, c->Np));
+    UP(e_wf, std::vector<double>(e->wf, e->wf + c->Nfq));
+  }
+#undef UP
+  c->E = ErrDev{c->K, c->Np, e->Nq2, c->Nfq, c->e_Vq2.as<double>(), c->e_wq2.as<double>(), c->e_x.as<double>(),
+                c->e_y.as<double>(), c->e_J.as<double>(), c->e_Vf.as<double>(), c->e_wf.as<double>()};
+  c->have_err = true;
+  return ESDG_OK;
+}
+
+static int err_check(esdg_ctx* ctx, const double* Q, const double* out, int32_t exact, const double* par) {
+  if (!ctx || !Q || !out) return fail(ESDG_ERR_ARG, "null argument");
+  if (!ctx->have_err) return fail(ESDG_ERR_STATE, "esdg_error_setup has not been called");
+  if (exact != ESDG_EXACT_VORTEX && exact != ESDG_EXACT_BECKER) return fail(ESDG_ERR_ARG, "unknown exact solution %d", exact);
+  if (exact == ESDG_EXACT_BECKER) {
+    if (!par) return fail(ESDG_ERR_ARG, "ESDG_EXACT_BECKER needs par = (v_0, v_1, v_01, m_0, L_k, v_inf)");
+    if (!(par[1] < par[2] && par[2] < par[0])) return fail(ESDG_ERR_ARG, "Becker profile needs v_1 < v_01 < v_0");
+  }
+  return ESDG_OK;
+}
+
+static int fetch_partials(esdg_ctx* ctx, std::vector<double>& h, hipStream_t s) {
+  HIP_TRY(hipMemcpyAsync(h.data(), ctx->d_partial.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return ESDG_OK;
+}
+
+int esdg_error_l2(esdg_ctx* ctx, const double* Q, int32_t exact, const double* par, double t, double* out, void* stream) {
+  int rc = err_check(ctx, Q, out, exact, par);
+  if (rc) return rc;
+  if (ctx->E.Nq2 <= 0) return fail(ESDG_ERR_STATE, "esdg_error_setup was given no error quadrature");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nb = esdg_ctx::NPARTIAL / 4;
+  rc = launch_err_l2(ctx->E, Q, exact, par, t, static_cast<double*>(ctx->d_partial.p), nb, s);
+  if (rc) return fail(ESDG_ERR_NO_DEVICE, "error functional launch: %s", hipGetErrorString((hipError_t)rc));
+  std::vector<double> h(4 * (size_t)nb);
+  if ((rc = fetch_partials(ctx, h, s))) return rc;
+  double tot = 0.0;
+  for (int f = 0; f < 4; ++f) {
+    double a = 0.0;
+    for (int b = 0; b < nb; ++b) a += h[4 * (size_t)b + f];
+    out[1 + f] = a;
+    tot += a;
+  }
+  out[0] = std::sqrt(tot);
+  return ESDG_OK;
+}
+
+int esdg_error_nodal(esdg_ctx* ctx, const double* Q, int32_t exact, const double* par, double t, double* out, void* stream) {
+  int rc = err_check(ctx, Q, out, exact, par);
+  if (rc) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nb = esdg_ctx::NPARTIAL / 12;
+  rc = launch_err_nodal(ctx->E, Q, exact, par, t, static_cast<double*>(ctx->d_partial.p), nb, s);
+  if (rc) return fail(ESDG_ERR_NO_DEVICE, "error functional launch: %s", hipGetErrorString((hipError_t)rc));
+  std::vector<double> h(12 * (size_t)nb);
+  if ((rc = fetch_partials(ctx, h, s))) return rc;
+  out[0] = out[1] = 0.0;
+  for (int c = 0; c < 3; ++c) {
+    double sd = 0, sq = 0, md = 0, mq = 0;
+    for (int b = 0; b < nb; ++b) {
+      const double* r = &h[12 * (size_t)b];
+      sd += r[2 * c]; sq += r[2 * c + 1];
+      md = std::max(md, r[6 + 2 * c]); mq = std::max(mq, r[7 + 2 * c]);
+    }
+    out[2 + 4 * c] = sd; out[3 + 4 * c] = sq; out[4 + 4 * c] = md; out[5 + 4 * c] = mq;
+    out[0] += sd / sq;
+    out[1] += md / mq;
+  }
+  return ESDG_OK;
+}
+
+int esdg_error_boundary_velocity(esdg_ctx* ctx, const double* Q, double Jf, double* out, void* stream) {
+  if (!ctx || !Q || !out) return fail(ESDG_ERR_ARG, "null argument");
+  if (!ctx->have_err || !ctx->E.Vf) return fail(ESDG_ERR_STATE, "esdg_error_setup has not been given Vf and wf");
+  if (!ctx->M.bc) return fail(ESDG_ERR_STATE, "the mesh has no wall boundary (mapB)");
+  if (ctx->ph.BCTYPE == 4) return fail(ESDG_ERR_STATE, "the boundary-velocity error is defined for the wall closures (BCTYPE 1-3)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nb = 256;
+  int rc = launch_err_boundary(ctx->E, ctx->M.bc, ctx->M.vlid, Q, Jf, static_cast<double*>(ctx->d_partial.p), nb, s);
+  if (rc) return fail(ESDG_ERR_NO_DEVICE, "error functional launch: %s", hipGetErrorString((hipError_t)rc));
+  std::vector<double> h(3 * (size_t)nb);
+  if ((rc = fetch_partials(ctx, h, s))) return rc;
+  for (int c = 0; c < 3; ++c) {
+    double a = 0.0;
+    for (int b = 0; b < nb; ++b) a += h[3 * (size_t)b + c];
+    out[2 + c] = a;
+  }
+  out[0] = std::sqrt(out[2]);                      // as the script executes (see the header)
+  out[1] = std::sqrt(out[2] + out[3] + out[4]);    // as it reads
   return ESDG_OK;
 }
 

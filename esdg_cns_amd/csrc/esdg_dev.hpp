@@ -65,6 +65,7 @@ struct MeshDev {
   const double* geo;       // [K][GEO_STRIDE]
   const int32_t* mapP;     // [K][Nfq]  local face-node index, or ghost slot >= K*Nfq
   const uint8_t* bc;       // [K][Nfq]  0 interior/periodic, 1 wall, 2 lid, 3 Dirichlet inflow, 4 copy; may be null
+  const double* vlid;      // [K][Nfq]  lid velocity where bc == 2; null = 1 everywhere
   const double* wJq;       // [K][Nq] (diagnostics) may be null
   // curved (non-affine) hexahedra only, null otherwise: per-node metric terms [K][9][Nh] (row m9 = comp*3 + operator:
   // rxJ sxJ txJ ryJ syJ tyJ rzJ szJ tzJ), J at the quadrature nodes [K][Nq], normals [K][4][Nfq] = nxJ nyJ nzJ sJ
@@ -108,6 +109,22 @@ int launch_axpy_stages(double* y, const double* x0, const double* const* k, cons
                        int64_t n, hipStream_t s);
 int launch_dopri_err(const double* Q, const double* const* k, const double* coefE, int ns, double tol, int64_t n,
                      double* partial, int nblocks, hipStream_t s);
+// error functionals (esdg_kernels_err.hip); all arrays on the device
+struct ErrDev {
+  int64_t K;
+  int Np, Nq2, Nfq;
+  const double* Vq2;          // [Nq2][Np] row-major: state nodes -> error quadrature
+  const double* wq2;          // [Nq2]
+  const double *x, *y, *J;    // [K][Np] at the state's nodes
+  const double* Vf;           // [Nfq][Np] row-major (boundary-velocity functional), may be null
+  const double* wf;           // [Nfq]
+};
+int launch_err_l2(const ErrDev& E, const double* Q, int kind, const double* par, double t, double* partial, int nblocks,
+                  hipStream_t s);
+int launch_err_nodal(const ErrDev& E, const double* Q, int kind, const double* par, double t, double* partial, int nblocks,
+                     hipStream_t s);
+int launch_err_boundary(const ErrDev& E, const uint8_t* bc, const double* vlid, const double* Q, double Jf, double* partial,
+                        int nblocks, hipStream_t s);
 int launch_min_rho_p(const double* Q, int nfld, int64_t n, double* partial, int nblocks, hipStream_t s);
 bool supported_degree(int N1);
 

@@ -418,14 +418,14 @@ __global__ __launch_bounds__(TW * NWV) void kt_project(TensorTables TT, MeshDev 
 // exterior entropy variables and penalty at one face node, given its own projected values vf = (v2,v3,v4):
 // vP = neighbour's values, or the closure of impose_BCs_entropyvars! (cavity :178-216 / modalESDG :187-203);
 // dV = vP - vf; pn_out (may be null) = tau*[[v]] with the boundary overrides of :817-837
-__device__ __forceinline__ void face_jump_and_penalty(const double* vf, const double* vPin, int bc, const double* gn,
-                                                      const Phys& ph, double* dV, double* pn_out) {
+__device__ __forceinline__ void face_jump_and_penalty(const double* vf, const double* vPin, int bc, double vlid,
+                                                      const double* gn, const Phys& ph, double* dV, double* pn_out) {
   double vP[3] = {vPin[0], vPin[1], vPin[2]};
   if (bc >= 3) {                                          // shock-tube closures, dg2D_CNS_modalESDG.jl:187-203
 #pragma unroll
     for (int c = 0; c < 3; ++c) vP[c] = bc == 3 ? ph.inflow_vv[c] : vf[c];
   } else if (bc) {
-    const double vlid = 1.0;                              // cavity :148
+    // vlid: lid velocity at this node (ones in cavity :147, (1+cos(pi x))/2 in dg2D_CNS_convergence_test.jl:76)
     if (ph.BCTYPE == 1) {                                 // adiabatic no-slip
       vP[0] = bc == 2 ? -vf[0] - 2 * vlid * vf[2] : -vf[0];
       vP[1] = -vf[1];
@@ -463,8 +463,8 @@ __device__ __forceinline__ void face_jump_and_penalty(const double* vf, const do
 // sDv (may be null), penalty (may be null).  bc: 0 interior/periodic, 1 wall, 2 lid, 3 inflow, 4 copy
 template <int N1>
 __device__ __forceinline__ void visc_face_jumps(const Lane<N1>& ln, const double* sTab, const int* sInt,
-                                                const double* sVn, const double* vPin, int bc, const double* gn,
-                                                const Phys& ph, double* sDv, double* pn_out) {
+                                                const double* sVn, const double* vPin, int bc, double vlid,
+                                                const double* gn, const Phys& ph, double* sDv, double* pn_out) {
   constexpr int Nq = N1 * N1, Nfq = 4 * N1;
   constexpr TensorLayout L(N1);
   int d, t, o;
@@ -479,7 +479,7 @@ __device__ __forceinline__ void visc_face_jumps(const Lane<N1>& ln, const double
     vf[2] += w * r[2 * Nq];
   }
   double dV[3];
-  face_jump_and_penalty(vf, vPin, bc, gn, ph, dV, pn_out);
+  face_jump_and_penalty(vf, vPin, bc, vlid, gn, ph, dV, pn_out);
   if (sDv) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) sDv[(ln.ef * 3 + c) * Nfq + ln.fn] = .5 * dV[c];
@@ -608,7 +608,8 @@ __global__ __launch_bounds__(TW * NWV) void kt_sigma(TensorTables TT, MeshDev M,
   if (ln.fin) {
     const int64_t nn = (e0 + (factive ? ln.ef : 0)) * Nfq + ln.fn;
     const int bc = (M.bc && factive) ? M.bc[nn] : 0;
-    visc_face_jumps<N1>(ln, sTab, sInt, sA, vP, bc, M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1), ph, sDv, nullptr);
+    const double vlid = (bc == 2 && M.vlid) ? M.vlid[nn] : 1.0;
+    visc_face_jumps<N1>(ln, sTab, sInt, sA, vP, bc, vlid, M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1), ph, sDv, nullptr);
   }
   __syncthreads();
   double vt = 0.0;
@@ -694,12 +695,14 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
   double qM[8], qP[8], pnr[3] = {0, 0, 0}, bPn[3] = {0, 0, 0}, bOwn[3] = {0, 0, 0};   // pnr: penalty tau*[[v]] of the face node
   int64_t mpk = 0;
   int bcf = 0;
+  double vlid = 1.0;
 #pragma unroll
   for (int c = 0; c < 8; ++c) { qM[c] = 1.0; qP[c] = 1.0; }
   if (factive) {
     const int64_t n = (e0 + ln.ef) * Nfq + ln.fn;
     const int64_t mp = M.mapP[n];
     if (WALLS) bcf = M.bc[n];   // WALLS <=> M.bc != null (periodic meshes compile the wall branches away)
+    if (WALLS && bcf == 2 && M.vlid) vlid = M.vlid[n];
     const double2* aM = reinterpret_cast<const double2*>(A_U + n * FAU_NC);
     const double2* aP = reinterpret_cast<const double2*>(A_U + mp * FAU_NC);
     const double2* aM2 = reinterpret_cast<const double2*>(A_U + (M.trace_nodes + n) * FAU_NC);
@@ -743,7 +746,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
       const double bM = 2 * Gas<MODAL>::GM1 * qM[3], bP = 2 * Gas<MODAL>::GM1 * qP[3];
       const double vf[3] = {bM * qM[1], bM * qM[2], -bM}, vPn[3] = {bP * qP[1], bP * qP[2], -bP};
       double dV[3];
-      face_jump_and_penalty(vf, vPn, bcf, gn, ph, dV, pnr);
+      face_jump_and_penalty(vf, vPn, bcf, vlid, gn, ph, dV, pnr);
     }
     if (bcf >= 3) {   // shock-tube closures (dg2D_CNS_modalESDG.jl:168-185): Dirichlet state / copy, lam = lamP = 0
 #pragma unroll
@@ -919,7 +922,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
       } else if (bcf) {   // impose_BCs_stress! :218-262
         if (ph.BCTYPE == 1) {
           sj[0] = 0.0; sj[1] = 0.0;
-          sj[2] = bcf == 2 ? -sn[2] + 1.0 * sn[0] : -sn[2];
+          sj[2] = bcf == 2 ? -sn[2] + vlid * sn[0] : -sn[2];
         } else if (ph.BCTYPE == 2) {
           sj[0] = 0.0; sj[1] = 0.0; sj[2] = 0.0;
         } else {

@@ -76,7 +76,7 @@ class RhsEngine:
 
     def __init__(self, rd, md, ops, formulation, lf_scale=None, inviscid_dissp=True, viscous_dissp=True, BCTYPE=1,
                  Re=1000.0, mu=None, lam=None, Pr=.71, device=None, rank=0, nranks=1, rank_offsets=None, group=None,
-                 inflow=None, inflow_nodes=None):
+                 inflow=None, inflow_nodes=None, vlid=None):
         L = _lib.lib()
         if not torch.cuda.is_available() or L.esdg_device_count() < 1:
             raise _lib.EsdgError("no MI355X/HIP device visible: the RHS engine has no CPU path")
@@ -89,7 +89,7 @@ class RhsEngine:
             ctx = self._create_hex(L, rd, md, ops, 0.0 if lf_scale is None else lf_scale, rank, nranks, rank_offsets)
         else:
             ctx = self._create_2d(L, rd, md, ops, formulation, lf_scale, inviscid_dissp, viscous_dissp, BCTYPE, Re, mu, lam, Pr,
-                                  rank, nranks, rank_offsets, inflow, inflow_nodes)
+                                  rank, nranks, rank_offsets, inflow, inflow_nodes, vlid)
         self.ctx = ctx
         self.L = L
         self.nphases = L.esdg_num_phases(ctx)
@@ -157,7 +157,7 @@ class RhsEngine:
         return ctx
 
     def _create_2d(self, L, rd, md, ops, formulation, lf_scale, inviscid_dissp, viscous_dissp, BCTYPE, Re, mu, lam, Pr,
-                   rank, nranks, rank_offsets, inflow=None, inflow_nodes=None):
+                   rank, nranks, rank_offsets, inflow=None, inflow_nodes=None, vlid=None):
         keep = self._keep
         modal = formulation != EULER_COLLOCATED
         Nq, Nfq = rd.wq.size, rd.wf.size
@@ -224,6 +224,13 @@ class RhsEngine:
             m.mapB = keep["mapB"].ctypes.data_as(_lib.c_int64_p)
             m.NmapB = int(mapB.size)
             m.bkind = keep["bkind"].ctypes.data_as(_lib.c_uint8_p)
+            if vlid is not None:
+                # lid velocity: a callable of the lid nodes' x (dg2D_CNS_convergence_test.jl:72-76) or one value per mapB entry
+                xb = np.zeros(mapB.size)
+                xb[inside] = md.xf.flatten(order="F")[loc[inside]]
+                vl = vlid(xb) if callable(vlid) else np.broadcast_to(np.asarray(vlid, dtype=np.float64), mapB.shape)
+                keep["vlid"] = np.ascontiguousarray(vl, dtype=np.float64)
+                m.vlid = _dp(keep["vlid"])
         elif BCTYPE != 4:
             m.mapB, m.NmapB, m.bkind = None, 0, None
         m.elem_offset = int(getattr(md, "elem_offset", 0))
@@ -324,6 +331,51 @@ class RhsEngine:
         diag = (C.c_double * 2)()
         check(self.L.esdg_rhstest(self.ctx, C.c_void_p(Qd.data_ptr()), C.c_void_p(rhsd.data_ptr()), diag, self._stream()))
         return diag[0]
+
+    # ---- error functionals of the drivers, evaluated on the device ----
+    def setup_errors(self, rd, md, Vq2=None, wq2=None, boundary=False):
+        """Upload what the error functionals need: the error quadrature (Vq2, wq2; setup_dg.error_quadrature), the
+        coordinates and J at the state's nodes, and rd.Vf/rd.wf for the boundary-velocity error."""
+        from ._lib import esdg_err_ops_t
+        keep = self._keep
+        colloc = self.formulation == EULER_COLLOCATED
+        e = esdg_err_ops_t()
+        xs, ys, Js = (md.xq, md.yq, rd.Vq @ md.J) if colloc else (md.x, md.y, md.J)
+        for n, a in (("x", xs), ("y", ys), ("J", Js)):
+            keep["e_" + n] = _f(a)
+            setattr(e, n, _dp(keep["e_" + n]))
+        if Vq2 is not None:
+            V = Vq2 @ rd.Pq if colloc else Vq2          # "project solution back to GLL nodes", dg2D_euler_quad.jl:215
+            keep["e_Vq2"], keep["e_wq2"] = _f(V), _f(wq2)
+            e.Nq2, e.Vq2, e.wq2 = V.shape[0], _dp(keep["e_Vq2"]), _dp(keep["e_wq2"])
+        if boundary:
+            keep["e_Vf"], keep["e_wf"] = _f(rd.Vf), _f(rd.wf)
+            e.Vf, e.wf = _dp(keep["e_Vf"]), _dp(keep["e_wf"])
+        check(self.L.esdg_error_setup(self.ctx, C.byref(e)))
+
+    @staticmethod
+    def _par(par):
+        return None if par is None else (C.c_double * 6)(*[float(v) for v in par])
+
+    def l2_error(self, Qd, t, exact=0, par=None):
+        """(L2err, per-field sums of squares) against vortex (exact=0) or the Becker shock (exact=1, par) at time t,
+        dg2D_euler_quad.jl:214-233; local elements only (add the sums over ranks before the square root)."""
+        out = (C.c_double * 5)()
+        check(self.L.esdg_error_l2(self.ctx, C.c_void_p(Qd.data_ptr()), exact, self._par(par), float(t), out, self._stream()))
+        return out[0], list(out)[1:]
+
+    def nodal_error(self, Qd, t, exact=1, par=None):
+        """(L1err, Linferr, raw) of dg2D_CNS_modalESDG.jl:745-771."""
+        out = (C.c_double * 14)()
+        check(self.L.esdg_error_nodal(self.ctx, C.c_void_p(Qd.data_ptr()), exact, self._par(par), float(t), out, self._stream()))
+        return out[0], out[1], list(out)[2:]
+
+    def boundary_velocity_error(self, Qd, Jf):
+        """dg2D_CNS_convergence_test.jl:1055-1080 (Jf = 2/K1D there) -> (err as executed by Julia: the u_2 term only,
+        err as written: all three terms, the three sums); see include/esdg_hip.h."""
+        out = (C.c_double * 5)()
+        check(self.L.esdg_error_boundary_velocity(self.ctx, C.c_void_p(Qd.data_ptr()), float(Jf), out, self._stream()))
+        return out[0], out[1], list(out)[2:]
 
     def check_state(self, Qd):
         """(min rho, min p) over the local nodal values; the reference raises DomainError where these are <= 0."""

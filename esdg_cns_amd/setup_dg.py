@@ -711,3 +711,16 @@ def hex_driver_geometry(md, rd, hybrid=True, A3=None, a=0.0):
     md.J = np.asfortranarray(rd.Vq @ md.J)
     md.wJq = np.asfortranarray(rd.wq[:, None] * md.J)
     return md
+
+
+def error_quadrature(N, Nplus=2):
+    """(Vq2, wq2) of the error blocks of the drivers: LGL nodal values of degree N -> Gauss rule of degree N+Nplus
+    (`rq2,sq2,wq2 = quad_nodes_2D(N+2); Vq2 = vandermonde_2D(N,rq2,sq2)/VDM`, dg2D_euler_quad.jl:218-220).  Quadrature
+    nodes in quad_nodes_2D order (r fastest, Basis2DQuad.jl:110-116), nodal columns r fastest."""
+    x1, _ = gauss_lobatto_quad(0, 0, N)
+    g2, w2 = gauss_quad(0, 0, N + Nplus)
+    I2 = lagrange_interp_1D(x1, g2)
+    n2 = g2.size
+    Vq2 = np.einsum("ai,bj->baji", I2, I2).reshape(n2 * n2, (N + 1) ** 2)
+    wq2 = np.repeat(w2, n2) * np.tile(w2, n2)
+    return Vq2, wq2

@@ -77,13 +77,16 @@ def run(N=2, K1D=32, T=0.2, CFL=0.05, Ky=None, verbose=True):
         ok, err = integ.step()
         if verbose and integ.i % 20 == 0:
             print(f"i = {integ.i}, t = {integ.t}, dt = {integ.dt}, errEst = {err}")
-    Qn = eng.download(Qd)
-    Qex = exact_sol_viscous_shocktube(md.x, integ.t)
-    wJ = rd.wq[:, None] * (rd.Vq @ md.J)
-    L2 = np.sqrt(sum(np.sum(wJ * (rd.Vq @ (a - b)) ** 2) for a, b in zip(Qn, Qex)))
-    Linf = max(np.abs(a - b).max() for a, b in zip(Qn, Qex))
+    # errors against the exact solution at the final time, on the device: L1err / Linferr of :745-771 and an L2 error
+    # with the (N+2) Gauss rule as in the Euler driver
+    par = (V0, V1, V01, M0, KAPPA / M0 / CV, V_INF)
+    Vq2, wq2 = sd.error_quadrature(N)
+    eng.setup_errors(rd, md, Vq2, wq2)
+    L1, Linf, _ = eng.nodal_error(Qd, integ.t, exact=1, par=par)
+    L2, _ = eng.l2_error(Qd, integ.t, exact=1, par=par)
     if verbose:
-        print(f"t = {integ.t}: L2 error {L2:.3e}, Linf error {Linf:.3e} ({integ.i} attempted steps, {integ.n_rhs} RHS evaluations)")
+        print(f"N = {N}, K = {md.K}\nL1 error is {L1}\nLinf error is {Linf}")
+        print(f"t = {integ.t}: L2 error {L2:.3e} ({integ.i} attempted steps, {integ.n_rhs} RHS evaluations)")
     return L2, Linf, integ
 
 

@@ -36,20 +36,10 @@ def run(N=2, K1D=12, T=1.0, CFL=2.0, verbose=True):
     rhstest = timestep.lsrk45_run(eng, Qd, dt, Nsteps, rhstest_every=10)   # :196-212
     if verbose:
         print(f"Time step: {Nsteps} out of {Nsteps} with rhstest = {rhstest}")
-    Q = eng.download(Qd)
-    # "project solution back to GLL nodes" and error with an N+2 Gauss rule (:214-233)
-    Q = [rd.Pq @ q for q in Q]
-    x1, _ = sd.gauss_lobatto_quad(0, 0, N)
-    g2, w2 = sd.gauss_quad(0, 0, N + 2)
-    I2 = sd.lagrange_interp_1D(x1, g2)                               # LGL -> finer Gauss, 1D
-    n2 = g2.size
-    # quad_nodes_2D ordering: r fastest (Basis2DQuad.jl:110-116); nodal ordering: r fastest
-    Vq2 = np.einsum("ai,bj->baji", I2, I2).reshape(n2 * n2, (N + 1) ** 2)
-    wq2 = np.repeat(w2, n2) * np.tile(w2, n2)
-    wJq2 = wq2[:, None] * (Vq2 @ md.J)
-    xq2, yq2 = Vq2 @ md.x, Vq2 @ md.y
-    Qex = ph.primitive_to_conservative(*ph.vortex(xq2, yq2, T))
-    L2err = np.sqrt(sum(np.sum(wJq2 * (Vq2 @ q - qe) ** 2) for q, qe in zip(Q, Qex)))
+    # "project solution back to GLL nodes" and error with an N+2 Gauss rule (:214-233), evaluated on the device
+    Vq2, wq2 = sd.error_quadrature(N)
+    eng.setup_errors(rd, md, Vq2, wq2)
+    L2err, _ = eng.l2_error(Qd, T)
     if verbose:
         print(f"L2err at final time T = {T} is {L2err}\n")
     return L2err, rhstest

@@ -105,6 +105,8 @@ typedef struct {
   int64_t Kglobal;
   int32_t nranks, rank;
   const int64_t* rank_offsets; /* (nranks+1) element offsets of every rank; NULL if nranks==1 */
+  const double* vlid;    /* per mapB entry: lid velocity, read where bkind == 1 (BCTYPE 1).  NULL = 1 everywhere
+                          * (cavity_optimized.jl:147); dg2D_CNS_convergence_test.jl:76 passes (1+cos(pi*xlid))/2 */
 } esdg_mesh_t;
 
 typedef struct {
@@ -210,7 +212,45 @@ int esdg_viscous_entropy_test(esdg_ctx* ctx, const double* Q_dev, double* visc_t
 
 /* Literal drop-in with host arrays (Julia Matrix{Float64} per field): H2D, rhs, D2H.
  * PCIe-bound -- for validation, not for time stepping. nranks must be 1. */
-int esdg_rhs_host(esdg_ctx* ctx, const double* const* Q, double* const* rhs);  /* esdg_num_fields() pointers each */
+int esdg_rhs_host(esdg_ctx* ctx, const double* const* Q, double* const* rhs);
+
+/* ---- error functionals of the drivers, on the device (2D contexts) ------------------------ */
+/* What the scripts print after a run, without moving the state to the host.  Exact solutions: */
+enum {
+  ESDG_EXACT_VORTEX = 0, /* vortex(x,y,t), EntropyStableEuler.jl:21-35 (x0=5, y0=0, beta=5); par ignored */
+  ESDG_EXACT_BECKER = 1  /* exact_sol_viscous_shocktube, dg2D_CNS_modalESDG.jl:545-579 (bisection, max_iter 100,
+                          * tol 1e-14); par = (v_0, v_1, v_01, m_0, L_k = kappa/m_0/cv, v_inf) */
+};
+typedef struct {
+  int32_t Nq2;         /* nodes of the error quadrature per element ((N+3)^2 for the N+2 Gauss rule); 0 = none */
+  const double* Vq2;   /* (Nq2 x Np) column-major, state nodes -> error quadrature: vandermonde_2D(N,rq2,sq2)/VDM
+                        * (dg2D_euler_quad.jl:220).  Np = nodes of the state per element; the collocated Euler driver,
+                        * whose state lives at the Gauss nodes, folds its projection in: Vq2*Pq (:215) */
+  const double* wq2;   /* (Nq2) */
+  const double *x, *y; /* (Np x K) coordinates at the state's nodes (md.x, md.y; md.xq, md.yq when collocated) */
+  const double* J;     /* (Np x K) */
+  const double* Vf;    /* (Nfq x Np) column-major rd.Vf and (Nfq) rd.wf: boundary-velocity functional only, */
+  const double* wf;    /*   may be NULL */
+} esdg_err_ops_t;
+/* copies the arrays to the device (once per mesh); the esdg_error_* calls below need it */
+int esdg_error_setup(esdg_ctx* ctx, const esdg_err_ops_t* e);
+/* out[1+f] = sum_{elements, nodes} wq2*(Vq2*J) * (Vq2*Q_f - Qexact_f(Vq2*x, Vq2*y, t))^2 over the LOCAL elements,
+ * out[0] = sqrt(sum_f out[1+f])  = "L2err" of dg2D_euler_quad.jl:224-231 (sharded runs add out[1..4] over the ranks).
+ * Synchronises the stream. */
+int esdg_error_l2(esdg_ctx* ctx, const double* Q, int32_t exact, const double* par, double t, double* out5, void* stream);
+/* Nodal errors of dg2D_CNS_modalESDG.jl:745-771 over rho, rho*u, E at the state's nodes:
+ * out[0] = L1err  = sum_f sum|Qex_f-Q_f| / sum|Q_f|   (the script's uniform J cancels),
+ * out[1] = Linferr = sum_f max|Qex_f-Q_f| / max|Q_f|,
+ * out[2+4c..5+4c] = (sum|d|, sum|q|, max|d|, max|q|) of field c in (rho, rho*u, E) for reductions over ranks. */
+int esdg_error_nodal(esdg_ctx* ctx, const double* Q, int32_t exact, const double* par, double t, double* out14, void* stream);
+/* Boundary-velocity error of the lid-driven cavity, dg2D_CNS_convergence_test.jl:1055-1080, with
+ * u = Vf*(Q[2]./Q[1], Q[3]./Q[1]) and Jf = 2/K1D in the script:
+ *   out[2] = sum_{wall+lid nodes} Jf*wf*u_2^2, out[3] = sum_{wall} Jf*wf*u_1^2, out[4] = sum_{lid} Jf*wf*(u_1-vlid)^2
+ *   (vlid from esdg_mesh_t.vlid), out[1] = sqrt(out[2]+out[3]+out[4]) = the error as the script reads,
+ *   out[0] = sqrt(out[2]) = the error as Julia executes it: the statement `err = sum(...)` (:1075) is complete at its
+ *   line end, so the two continuation lines starting with `+sum(...)` (:1076-1077) are separate unary-plus expressions
+ *   and never reach `err` (quirk, reproduced for parity of the printed numbers). */
+int esdg_error_boundary_velocity(esdg_ctx* ctx, const double* Q, double Jf, double* out5, void* stream);  /* esdg_num_fields() pointers each */
 
 /* ---- halo exchange plan (element-index sharding) ---------------------------------------- */
 /* The reference's three x[mapP] gathers (QM/Uf+lam :496-511, VUf :776, sigma_f :813-814) become face-trace

@@ -36,7 +36,7 @@ class _CnsT(C.Structure):
                                       "rxJ", "sxJ", "ryJ", "syJ", "J", "wJq", "nxJ", "nyJ", "sJ")]
                 + [("mapP", _lp), ("Nb", C.c_int), ("mapB", _lp), ("bkind", _ip), ("BCTYPE", C.c_int),
                    ("Re", C.c_double), ("lambda_", C.c_double), ("mu", C.c_double), ("Pr", C.c_double),
-                   ("inviscid_dissp", C.c_int), ("viscous_dissp", C.c_int), ("inflow", C.c_double * 4)])
+                   ("inviscid_dissp", C.c_int), ("viscous_dissp", C.c_int), ("inflow", C.c_double * 4), ("vlid", _dp)])
 
 
 class _HexT(C.Structure):
@@ -369,6 +369,10 @@ class CnsOracle:
         t.inviscid_dissp, t.viscous_dissp = int(inviscid_dissp), int(viscous_dissp)
         for i in range(4):
             t.inflow[i] = float(getattr(p, "inflow", (0, 0, 0, 0))[i])
+        if getattr(p, "vlid", None) is not None:      # lid velocity as a function of x (convergence_test.jl:72-76)
+            xb = md.xf.flatten(order="F")[mapB - 1]
+            self.vlid = np.ascontiguousarray(p.vlid(xb), dtype=np.float64)
+            t.vlid = _d(self.vlid)
         self.t = t
 
     def rhs_inviscid(self, Q):

@@ -286,6 +286,9 @@ typedef struct {
   /* BCTYPE 4 = the boundary closures of the shock-tube driver (dg2D_CNS_modalESDG.jl:161-217): bkind 1 = Dirichlet
    * inflow with the state (rho,u,v,p) below, bkind 0 = copy of the interior value; lam = lamP = 0 on both; no penalty */
   double inflow[4];
+  /* lid velocity per mapB entry (read where bkind = 1): ones in cavity_optimized.jl:147 (NULL here),
+   * (1+cos(pi*xlid))/2 in dg2D_CNS_convergence_test.jl:76 */
+  const double* vlid;
 } oracle_cns_t;
 
 /* dg2D_CNS_cavity_optimized.jl:461-467: hard-coded gamma literals (quirk Q5) */
@@ -481,7 +484,7 @@ double oracle_cns_rhs_viscous(const oracle_cns_t* c, const double* Q, double* rh
     int lid = c->bkind[b];
     double vf2 = VUf[KNf + n], vf3 = VUf[2 * KNf + n], vf4 = VUf[3 * KNf + n];
     if (c->BCTYPE == 1) {
-      VUP[KNf + n] = lid ? -vf2 - 2 * 1.0 * vf4 : -vf2;
+      VUP[KNf + n] = lid ? -vf2 - 2 * (c->vlid ? c->vlid[b] : 1.0) * vf4 : -vf2;
       VUP[2 * KNf + n] = -vf3;
       VUP[3 * KNf + n] = vf4;
     } else if (c->BCTYPE == 2) {
@@ -572,8 +575,9 @@ double oracle_cns_rhs_viscous(const oracle_cns_t* c, const double* Q, double* rh
     if (c->BCTYPE == 1) {
       for (int f = 1; f <= 2; ++f) { sxP[f * KNf + n] = sxf[f * KNf + n]; syP[f * KNf + n] = syf[f * KNf + n]; }
       if (lid) {
-        sxP[3 * KNf + n] = -sxf[3 * KNf + n] + 2 * 1.0 * sxf[KNf + n];
-        syP[3 * KNf + n] = -syf[3 * KNf + n] + 2 * 1.0 * syf[KNf + n];
+        const double vl = c->vlid ? c->vlid[b] : 1.0;
+        sxP[3 * KNf + n] = -sxf[3 * KNf + n] + 2 * vl * sxf[KNf + n];
+        syP[3 * KNf + n] = -syf[3 * KNf + n] + 2 * vl * syf[KNf + n];
       } else {
         sxP[3 * KNf + n] = -sxf[3 * KNf + n];
         syP[3 * KNf + n] = -syf[3 * KNf + n];

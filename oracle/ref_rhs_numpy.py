@@ -88,14 +88,16 @@ class BCFuns:
     reference does (lid = boundary nodes with |y-1|<1e-12).  With an empty mapB (fully
     periodic mesh) every function is a no-op."""
 
-    def __init__(self, md, BCTYPE):
+    def __init__(self, md, BCTYPE, vlid=None):
         self.BCTYPE = BCTYPE
         mapB = np.asarray(md.mapB, dtype=np.int64)
         xb, yb = gather(md.xf, mapB), gather(md.yf, mapB)
         self.lid = mapB[np.abs(yb - 1) < 1e-12]
         self.wall = mapB[np.abs(yb - 1) >= 1e-12]
         self.boundary = np.concatenate([self.lid, self.wall])
-        self.vlid = np.ones(self.lid.size)
+        self.vlid = np.ones(self.lid.size)                 # cavity_optimized.jl:147
+        if vlid is not None:                               # dg2D_CNS_convergence_test.jl:72-76: a function of xlid
+            self.vlid = vlid(gather(md.xf, self.lid))
         self.nx = gather(md.nxJ, self.boundary) / gather(md.sJ, self.boundary)
         self.ny = gather(md.nyJ, self.boundary) / gather(md.sJ, self.boundary)
         self.shape = md.xf.shape

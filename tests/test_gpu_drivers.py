@@ -131,6 +131,25 @@ def test_shocktube_driver_tracks_the_exact_viscous_shock():
     assert rate > 2.0 and e2 < 5e-3     # measured: 1.76e-2 -> 2.51e-3 (rate 2.8); N=3: 4.1e-3 -> 2.0e-4 (rate 4.4)
 
 
+def test_convergence_test_driver_boundary_error_matches_oracle_functional():
+    """examples/dg2D_CNS_convergence_test.py (dg2D_CNS_convergence_test.jl on quads): cavity with the lid profile
+    (1+cos(pi x))/2, DOPRI45, boundary-velocity error on the device == the oracle's functional of the final state."""
+    import dg2D_CNS_convergence_test as drv
+    from esdg_cns_amd import engine
+    from oracle import oracle as orc
+    from oracle import ref_errors as re
+    N, K1D = 2, 6
+    ex, wr, integ = drv.run_one(N, K1D, T=0.01, CFL=0.05)
+    assert integ.t >= 0.01 and np.isfinite(ex) and 0 < ex < wr
+    Q = engine.RhsEngine.download(integ.Q)
+    p = orc.build_cns_problem(N, K1D, K1D, bc="cavity", BCTYPE=1)
+    rex, rwr, _ = re.boundary_velocity_error(Q, p.rd, p.md, K1D, drv.vlid)
+    print(f"convergence-test driver N={N} K1D={K1D}: err {ex:.6e} (oracle functional {rex:.6e}), all terms {wr:.6e}")
+    assert abs(ex - rex) <= 1e-11 * rex and abs(wr - rwr) <= 1e-11 * rwr
+    # the lid has started to drag the fluid: the state is no longer at rest
+    assert max(np.abs(Q[1]).max(), np.abs(Q[2]).max()) > 1e-4
+
+
 def test_pure_c_driver_on_the_c_abi_matches_python_path(tmp_path):
     """examples/c/dg2D_euler_quad.c: set-up (esdg_setup_*), engine and LSRK45 loop through the C ABI only, built with
     gcc against libesdg_hip.so and run as a child process; same numbers as the Python host path."""

@@ -110,6 +110,30 @@ def test_cns_wall_boundary_conditions_match_oracle(eng_mod, oracle_lib, BCTYPE, 
     assert ev <= 1e-9
 
 
+def test_cns_variable_lid_velocity_matches_oracle(eng_mod, oracle_lib):
+    """Per-node lid velocity (esdg_mesh_t.vlid): (1+cos(pi*xlid))/2 of dg2D_CNS_convergence_test.jl:72-76."""
+    from oracle import oracle as orc
+    vl = lambda x: (1 + np.cos(np.pi * x)) / 2
+    for N, Kx, Ky in [(3, 6, 5), (4, 4, 4)]:
+        p = orc.build_cns_problem(N, Kx, Ky, bc="cavity", BCTYPE=1)
+        p.vlid = vl
+        co = orc.CnsOracle(p)
+        rd, md, ops, Q = product_cavity_problem(N, Kx, Ky)
+        kw = dict(Re=p.Re, mu=p.mu, lam=p.lam, Pr=p.Pr, BCTYPE=1)
+        eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, vlid=vl, **kw)
+        ref = co.rhsRK(p.Q, compute_diag=False)[0]
+        got = _gpu_rhs(eng, Q)
+        err = rel_l2(got, ref)
+        floor = noise_floor(lambda q: co.rhsRK(q, compute_diag=False)[0], p.Q)
+        print(f"variable lid N={N}: err={err:.2e} oracle-noise-floor={floor:.2e}")
+        assert err <= max(TOL, 4 * floor), (err, floor)
+        ones = _gpu_rhs(eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, **kw), Q)
+        assert rel_l2(got, ones) > 1e-6
+        # vlid given as an array of ones reproduces the default bit for bit
+        same = _gpu_rhs(eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, vlid=1.0, **kw), Q)
+        assert all(np.array_equal(a, b) for a, b in zip(same, ones))
+
+
 @pytest.mark.parametrize("bc,BCTYPE", [("periodic", 1), ("cavity", 1), ("cavity", 3)])
 def test_rhs_inviscid_viscous_split_and_rhsRK_diagnostics(eng_mod, oracle_lib, bc, BCTYPE):
     """esdg_set_parts: 1 = rhs_inviscid! (:447), 2 = rhs_viscous! (:749) against the oracle's separate restatements, and

@@ -44,6 +44,23 @@ def test_cns_c_vs_numpy(oracle_lib, bc, BCTYPE):
     assert rel_l2(av[1:], bv[1:]) <= 1e-11 and np.abs(bv[0]).max() == 0.0
 
 
+def test_cns_variable_lid_velocity(oracle_lib):
+    """Lid velocity (1+cos(pi*xlid))/2 of dg2D_CNS_convergence_test.jl:72-76 (cavity_optimized uses ones, :147)."""
+    vl = lambda x: (1 + np.cos(np.pi * x)) / 2
+    p = orc.build_cns_problem(3, 5, 4, bc="cavity", BCTYPE=1)
+    base = orc.CnsOracle(p).rhsRK(p.Q)[0]
+    p.vlid = vl
+    co = orc.CnsOracle(p)
+    b = co.rhsRK(p.Q)[0]
+    a = rr.rhsRK(p.Q, p.rd, p.md, p.ops, rr.BCFuns(p.md, 1, vlid=vl), p.Re, p.lam, p.mu, p.Pr)[0]
+    floor = noise_floor(lambda q: co.rhsRK(q, False)[0], p.Q)
+    assert rel_l2(a, b) <= max(1e-12, 4 * floor), (rel_l2(a, b), floor)
+    assert rel_l2(b, base) > 1e-6          # the lid profile is felt
+    # only elements that touch the lid (top row) or their BR1 neighbours change
+    changed = np.abs(np.stack(b) - np.stack(base)).max(axis=(0, 1)) > 0
+    assert not changed[:5 * 2].any() and changed[-5:].all()
+
+
 def test_golden_vectors(oracle_lib):
     g = np.load(os.path.join(GOLD, "rhs_euler_N2_3x3.npz"))
     p = orc.build_euler_problem(2, 3, 3)
