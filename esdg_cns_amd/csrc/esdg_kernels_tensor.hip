@@ -28,14 +28,67 @@
 
 namespace esdg {
 
-constexpr int TW = 64;  // threads per workgroup = one wave
-constexpr int NWV = 4;  // waves per workgroup: each wave owns E elements and its own LDS slice; the 1D tables are shared
+constexpr int TW = 64;  // lanes per wave
 
-template <int N1> struct TCfg { static constexpr int E = (TW / (N1 * N1)) < (TW / (4 * N1)) ? (TW / (N1 * N1)) : (TW / (4 * N1)); };
-template <> struct TCfg<5> { static constexpr int E = 2; };
-template <> struct TCfg<6> { static constexpr int E = 1; };
-template <> struct TCfg<7> { static constexpr int E = 1; };
-template <> struct TCfg<8> { static constexpr int E = 1; };
+// Work decomposition.  A GROUP of GW consecutive waves shares E elements: lane t of the group owns volume node t % Nq
+// of element t / Nq (and face node t % Nfq of element t / Nfq), so an element may straddle two waves of its group.
+// N1 = 5 (N = 4): 5 elements on 125 of 128 lanes instead of 2 on 50 of 64; N1 = 6: 7 on 252 of 256 instead of 1 on 36
+// of 64.  A workgroup holds NWV waves = NWV/GW groups, each with its own LDS slice; the 1D tables are shared.  All
+// cross-lane traffic goes through LDS between __syncthreads(), so the mapping is free; only the ds_add_f64
+// accumulations need care (see kt_rhs).
+// Per kernel: GW = waves per group, NWV = waves per workgroup (same-box measurements, profiles/experiments/README.md):
+//   N1 = 5: kt_project gains 12 % from two-wave groups, kt_sigma and the inviscid kt_rhs lose 4-6 % (LDS-side bound:
+//   the LDS pipes do not care how many lanes of an instruction are idle), the viscous kt_rhs gains a few per cent.
+template <int N1> struct TCfg {
+  static constexpr int P_GW = 1, P_NWV = 4, S_GW = 1, S_NWV = 4;
+  static constexpr int r_gw(bool) { return 1; }
+  static constexpr int r_nwv(bool) { return 4; }
+};
+#ifndef ESDG_N5_CFG
+#define ESDG_N5_CFG 2, 4, 1, 4, 2, 2, 1, 4
+#endif
+template <> struct TCfg<5> {
+  static constexpr int cfg[8] = {ESDG_N5_CFG};   // P_GW, P_NWV, S_GW, S_NWV, R_GW/R_NWV viscous, R_GW/R_NWV inviscid
+  static constexpr int P_GW = cfg[0], P_NWV = cfg[1], S_GW = cfg[2], S_NWV = cfg[3];
+  static constexpr int r_gw(bool visc) { return visc ? cfg[4] : cfg[6]; }
+  static constexpr int r_nwv(bool visc) { return visc ? cfg[5] : cfg[7]; }
+};
+template <> struct TCfg<6> {
+  static constexpr int P_GW = 4, P_NWV = 4, S_GW = 4, S_NWV = 4;
+  static constexpr int r_gw(bool) { return 4; }
+  static constexpr int r_nwv(bool) { return 4; }
+};
+template <> struct TCfg<7> {   // kt_rhs: one element per wave is faster than 5 elements on 4 waves (A/B at N = 6)
+  static constexpr int P_GW = 4, P_NWV = 4, S_GW = 4, S_NWV = 4;
+  static constexpr int r_gw(bool) { return 1; }
+  static constexpr int r_nwv(bool) { return 4; }
+};
+
+template <int N1, int GW_> struct Grp {
+  static constexpr int GW = GW_;
+  static constexpr int GT = TW * GW;      // lanes per group
+  static constexpr int E = (GT / (N1 * N1)) < (GT / (4 * N1)) ? (GT / (N1 * N1)) : (GT / (4 * N1));   // elements per group
+  static_assert(E >= 1, "group does not hold an element");
+  // element e of a group straddles two waves (its lanes [e*Nq, (e+1)*Nq) cross a multiple of 64)
+  __host__ __device__ static constexpr bool strad(int e) { return (e * N1 * N1) / TW != ((e + 1) * N1 * N1 - 1) / TW; }
+  __host__ __device__ static constexpr int nstrad() {
+    int n = 0;
+    for (int e = 0; e < E; ++e) n += strad(e) ? 1 : 0;
+    return n;
+  }
+  static constexpr int NS = GW > 1 ? nstrad() : 0;
+};
+template <int N1, int GW_, int NWV> struct Wg {
+  static_assert(NWV % GW_ == 0, "workgroup = whole groups");
+  using G = Grp<N1, GW_>;
+  static constexpr int GW = GW_;
+  static constexpr int NG = NWV / GW;     // groups per workgroup
+  static constexpr int TPB = TW * NWV;    // threads per workgroup
+  static constexpr int EPB = G::E * NG;   // elements per workgroup
+};
+template <int N1> struct WgP : Wg<N1, TCfg<N1>::P_GW, TCfg<N1>::P_NWV> {};                              // kt_project
+template <int N1> struct WgS : Wg<N1, TCfg<N1>::S_GW, TCfg<N1>::S_NWV> {};                              // kt_sigma
+template <int N1, bool VISC> struct WgR : Wg<N1, TCfg<N1>::r_gw(VISC), TCfg<N1>::r_nwv(VISC)> {};        // kt_rhs
 
 namespace tdev {
 
@@ -194,14 +247,15 @@ __device__ __forceinline__ void viscous_stress(const double* v, const double* tx
 }
 
 // lane geometry -------------------------------------------------------------------------------
-template <int N1>
+template <int N1, int GW>
 struct Lane {
-  static constexpr int Nq = N1 * N1, Nfq = 4 * N1, E = TCfg<N1>::E;
-  int tid, wave, ev, q, a, b, ef, fn;
-  bool vin, fin;  // lane owns a volume-node / face-node slot of its wave
+  static constexpr int Nq = N1 * N1, Nfq = 4 * N1, E = Grp<N1, GW>::E, GT = Grp<N1, GW>::GT;
+  int tid, grp, ev, q, a, b, ef, fn;   // tid: lane within the group; grp: group within the workgroup
+  bool vin, fin;  // lane owns a volume-node / face-node slot of its group
   __device__ __forceinline__ Lane() {
-    tid = threadIdx.x & (TW - 1);
-    wave = threadIdx.x / TW;
+    tid = threadIdx.x & (GT - 1);
+    // a wave lies in one group: keep grp (and with it e0 and the LDS slice bases) in scalar registers
+    grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / GT));
     const int e = tid / Nq;
     q = tid - e * Nq;
     vin = tid < E * Nq;
@@ -224,24 +278,24 @@ __device__ __forceinline__ int node_of(int d, int i, int o) { return d == 0 ? i 
 template <int N1>
 __device__ __forceinline__ void stage_tables(const TensorTables& TT, double* sTab, int* sInt) {
   constexpr TensorLayout L(N1);
-  for (int i = threadIdx.x; i < L.NDBL; i += TW * NWV) sTab[i] = TT.dbl[i];
-  for (int i = threadIdx.x; i < L.NINT; i += TW * NWV) sInt[i] = TT.ints[i];
+  for (int i = threadIdx.x; i < L.NDBL; i += (int)blockDim.x) sTab[i] = TT.dbl[i];
+  for (int i = threadIdx.x; i < L.NINT; i += (int)blockDim.x) sInt[i] = TT.ints[i];
 }
 
 template <int N1>
 __device__ __forceinline__ void issue_state_loads(const double* __restrict__ Q, int64_t K, int64_t e0, bool active,
-                                                  double* x) {
+                                                  int tid, double* x) {
   constexpr int Nq = N1 * N1;
   x[0] = 1.0; x[1] = 0.0; x[2] = 0.0; x[3] = 1.0;
   if (active) {
 #pragma unroll
-    for (int f = 0; f < 4; ++f) x[f] = Q[(int64_t)f * K * Nq + e0 * Nq + (threadIdx.x & (TW - 1))];
+    for (int f = 0; f < 4; ++f) x[f] = Q[(int64_t)f * K * Nq + e0 * Nq + tid];
   }
 }
 
 // Uq = (IQ (x) IQ) Qn by sum factorisation; sA/sB: LDS scratch [E][4][Nq] each.  x -> U.
-template <int N1, bool MODAL>
-__device__ __forceinline__ void state_at_quad(const Lane<N1>& ln, const double* sTab, double* sA, double* sB,
+template <int N1, bool MODAL, class LN>
+__device__ __forceinline__ void state_at_quad(const LN& ln, const double* sTab, double* sA, double* sB,
                                               const double* x, double* U) {
   constexpr int Nq = N1 * N1;
   constexpr TensorLayout L(N1);
@@ -281,8 +335,8 @@ __device__ __forceinline__ void state_at_quad(const Lane<N1>& ln, const double* 
 }
 
 // out = (IP (x) IP) R by sum factorisation, then the coalesced store
-template <int N1, bool MODAL>
-__device__ __forceinline__ void store_rhs_from_quad(const Lane<N1>& ln, const double* sTab, double* __restrict__ rhs,
+template <int N1, bool MODAL, class LN>
+__device__ __forceinline__ void store_rhs_from_quad(const LN& ln, const double* sTab, double* __restrict__ rhs,
                                                     const LsrkFuse& lf, int64_t K, int64_t e0, bool active, double* sA,
                                                     double* sB, const double* R) {
   constexpr int Nq = N1 * N1;
@@ -321,7 +375,7 @@ __device__ __forceinline__ void store_rhs_from_quad(const Lane<N1>& ln, const do
   if (active) {
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-      const int64_t idx = (int64_t)f * K * Nq + e0 * Nq + (threadIdx.x & (TW - 1));
+      const int64_t idx = (int64_t)f * K * Nq + e0 * Nq + ln.tid;
       if (lf.Qw) {   // fused low-storage RK stage
         const double r = __builtin_fma(lf.a, lf.res[idx], lf.dt * out[f]);
         lf.res[idx] = r;
@@ -352,25 +406,27 @@ using namespace tdev;
 // (b u, b v, -b), b = 2 (gamma-1) beta, from the A_U record instead of reading a second trace buffer.
 // ---------------------------------------------------------------------------------------------
 template <int N1, bool MODAL, bool VISC>
-__global__ __launch_bounds__(TW * NWV) void kt_project(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
+__global__ __launch_bounds__(WgP<N1>::TPB) void kt_project(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                  double* __restrict__ A_U, double* __restrict__ A_v) {
-  constexpr int Nq = N1 * N1, Nfq = 4 * N1, E = TCfg<N1>::E;
+  using W = WgP<N1>;
+  constexpr int Nq = N1 * N1, Nfq = 4 * N1, E = W::G::E;
   constexpr TensorLayout L(N1);
   __shared__ double sTab[L.NDBL];
   __shared__ int sInt[L.NINT];
-  __shared__ double sA_[NWV * E * 4 * Nq];
-  __shared__ double sB_[NWV * E * 4 * Nq];
-  const Lane<N1> ln;
-  double* sA = sA_ + ln.wave * (E * 4 * Nq);
-  double* sB = sB_ + ln.wave * (E * 4 * Nq);
+  __shared__ double sA_[W::NG * E * 4 * Nq];
+  __shared__ double sB_[W::NG * E * 4 * Nq];
+  const Lane<N1, W::GW> ln;
+  double* sA = sA_ + ln.grp * (E * 4 * Nq);
+  double* sB = sB_ + ln.grp * (E * 4 * Nq);
   stage_tables<N1>(TT, sTab, sInt);
   __syncthreads();
-  const int64_t e0 = M.e_begin + ((int64_t)blockIdx.x * NWV + ln.wave) * E;
+  const int64_t e0 = M.e_begin + ((int64_t)blockIdx.x * W::NG + ln.grp) * E;
   const int nE = (int)max((int64_t)0, min((int64_t)E, M.e_begin + M.e_count - e0));
   const bool vactive = ln.tid < nE * Nq, factive = ln.tid < nE * Nfq;
+  const int64_t e0s = min(e0, M.e_begin + M.e_count - 1);   // in-range base for the geometry reads of idle lanes / idle groups
 
   double x[4];
-  issue_state_loads<N1>(Q, M.K, e0, vactive, x);
+  issue_state_loads<N1>(Q, M.K, e0, vactive, ln.tid, x);
   double U[4];
   state_at_quad<N1, MODAL>(ln, sTab, sA, sB, x, U);
   double qh[6], V[4];
@@ -461,8 +517,8 @@ __device__ __forceinline__ void face_jump_and_penalty(const double* vf, const do
 
 // face lanes: projected entropy variables at the face node by interpolation of the nodal ones (Vf*VU), half jump to
 // sDv (may be null), penalty (may be null).  bc: 0 interior/periodic, 1 wall, 2 lid, 3 inflow, 4 copy
-template <int N1>
-__device__ __forceinline__ void visc_face_jumps(const Lane<N1>& ln, const double* sTab, const int* sInt,
+template <int N1, class LN>
+__device__ __forceinline__ void visc_face_jumps(const LN& ln, const double* sTab, const int* sInt,
                                                 const double* sVn, const double* vPin, int bc, double vlid,
                                                 const double* gn, const Phys& ph, double* sDv, double* pn_out) {
   constexpr int Nq = N1 * N1, Nfq = 4 * N1;
@@ -487,8 +543,8 @@ __device__ __forceinline__ void visc_face_jumps(const Lane<N1>& ln, const double
 }
 
 // volume lanes: BR1 gradient of (v2,v3,v4) at the node and sigma = K(v) grad v
-template <int N1>
-__device__ __forceinline__ void visc_sigma(const Lane<N1>& ln, const double* sTab, const int* sInt,
+template <int N1, class LN>
+__device__ __forceinline__ void visc_sigma(const LN& ln, const double* sTab, const int* sInt,
                                            const TensorTables& TT, const Phys& ph, const double* g,
                                            const double* sVn, const double* sDv, double* sgx, double* sgy,
                                            double* gradx = nullptr, double* grady = nullptr) {
@@ -539,8 +595,8 @@ __device__ __forceinline__ void visc_sigma(const Lane<N1>& ln, const double* sTa
 }
 
 // face lanes: own normal stress (Ef*sigma_x)*nxJ + (Ef*sigma_y)*nyJ;  sS: [E][Nq][6]
-template <int N1>
-__device__ __forceinline__ void face_normal_stress(const Lane<N1>& ln, const double* sTab, const int* sInt,
+template <int N1, class LN>
+__device__ __forceinline__ void face_normal_stress(const LN& ln, const double* sTab, const int* sInt,
                                                    const double* sS, double nxJ, double nyJ, double* sn,
                                                    double* fx, double* fy) {
   constexpr int Nq = N1 * N1;
@@ -566,28 +622,32 @@ __device__ __forceinline__ void face_normal_stress(const Lane<N1>& ln, const dou
 // ---------------------------------------------------------------------------------------------
 // DIAG: also reduce visc_test = sum(wJq .* (VUx .* sigma_x + VUy .* sigma_y)) (rhs_viscous! :802-806) per workgroup
 template <int N1, bool DIAG>
-__global__ __launch_bounds__(TW * NWV) void kt_sigma(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
+__global__ __launch_bounds__(WgS<N1>::TPB) void kt_sigma(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                const double* __restrict__ A_U, double* __restrict__ B,
                                                double* __restrict__ SG, double* __restrict__ vt_partial) {
-  constexpr int Nq = N1 * N1, Nfq = 4 * N1, E = TCfg<N1>::E;
+  using W = WgS<N1>;
+  constexpr int Nq = N1 * N1, Nfq = 4 * N1, E = W::G::E;
   constexpr TensorLayout L(N1);
   __shared__ double sTab[L.NDBL];
   __shared__ int sInt[L.NINT];
-  __shared__ __align__(16) double sA_[NWV * E * 4 * Nq];   // interp scratch, then sVn [E][Nq][4]
-  __shared__ __align__(16) double sB_[NWV * E * 6 * Nq];   // interp scratch, then sS [E][Nq][6]
-  __shared__ double sDv_[NWV * E * 3 * Nfq];
-  const Lane<N1> ln;
-  double* sA = sA_ + ln.wave * (E * 4 * Nq);
-  double* sB = sB_ + ln.wave * (E * 6 * Nq);
-  double* sDv = sDv_ + ln.wave * (E * 3 * Nfq);
+  constexpr int NG = W::NG, TPB = W::TPB;
+  constexpr int nB = NG * E * 6 * Nq > TPB ? NG * E * 6 * Nq : TPB;   // also holds the DIAG reduction
+  __shared__ __align__(16) double sA_[NG * E * 4 * Nq];   // interp scratch, then sVn [E][Nq][4]
+  __shared__ __align__(16) double sB_[nB];                // interp scratch, then sS [E][Nq][6]
+  __shared__ double sDv_[NG * E * 3 * Nfq];
+  const Lane<N1, W::GW> ln;
+  double* sA = sA_ + ln.grp * (E * 4 * Nq);
+  double* sB = sB_ + ln.grp * (E * 6 * Nq);
+  double* sDv = sDv_ + ln.grp * (E * 3 * Nfq);
   stage_tables<N1>(TT, sTab, sInt);
   __syncthreads();
-  const int64_t e0 = M.e_begin + ((int64_t)blockIdx.x * NWV + ln.wave) * E;
+  const int64_t e0 = M.e_begin + ((int64_t)blockIdx.x * W::NG + ln.grp) * E;
   const int nE = (int)max((int64_t)0, min((int64_t)E, M.e_begin + M.e_count - e0));
   const bool vactive = ln.tid < nE * Nq, factive = ln.tid < nE * Nfq;
+  const int64_t e0s = min(e0, M.e_begin + M.e_count - 1);   // in-range base for the geometry reads of idle lanes / idle groups
 
   double x[4];
-  issue_state_loads<N1>(Q, M.K, e0, vactive, x);
+  issue_state_loads<N1>(Q, M.K, e0, vactive, ln.tid, x);
   double vP[3] = {0, 0, 0};
   if (factive) {
     const double* up = A_U + (int64_t)M.mapP[(e0 + ln.ef) * Nfq + ln.fn] * FAU_NC;   // (rho,u,v,beta,...)
@@ -609,13 +669,13 @@ __global__ __launch_bounds__(TW * NWV) void kt_sigma(TensorTables TT, MeshDev M,
     const int64_t nn = (e0 + (factive ? ln.ef : 0)) * Nfq + ln.fn;
     const int bc = (M.bc && factive) ? M.bc[nn] : 0;
     const double vlid = (bc == 2 && M.vlid) ? M.vlid[nn] : 1.0;
-    visc_face_jumps<N1>(ln, sTab, sInt, sA, vP, bc, vlid, M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1), ph, sDv, nullptr);
+    visc_face_jumps<N1>(ln, sTab, sInt, sA, vP, bc, vlid, M.geo + (e0s + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1), ph, sDv, nullptr);
   }
   __syncthreads();
   double vt = 0.0;
   if (ln.vin) {
     double sgx[3], sgy[3], gx[3], gy[3];
-    visc_sigma<N1>(ln, sTab, sInt, TT, ph, M.geo + (e0 + (vactive ? ln.ev : 0)) * GEO_STRIDE, sA, sDv, sgx, sgy,
+    visc_sigma<N1>(ln, sTab, sInt, TT, ph, M.geo + (e0s + (vactive ? ln.ev : 0)) * GEO_STRIDE, sA, sDv, sgx, sgy,
                    DIAG ? gx : nullptr, DIAG ? gy : nullptr);
     double2* r = reinterpret_cast<double2*>(sB + (ln.ev * Nq + ln.q) * 6);
     r[0] = make_double2(sgx[0], sgx[1]);
@@ -642,7 +702,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_sigma(TensorTables TT, MeshDev M,
     double* red = sB_;
     red[threadIdx.x] = vt;
     __syncthreads();
-    for (int w = TW * NWV / 2; w > 0; w >>= 1) {
+    for (int w = TPB / 2; w > 0; w >>= 1) {
       if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
       __syncthreads();
     }
@@ -655,9 +715,11 @@ __global__ __launch_bounds__(TW * NWV) void kt_sigma(TensorTables TT, MeshDev M,
 // ---------------------------------------------------------------------------------------------
 template <int N1, bool VISC>
 struct RhsLds {
-  static constexpr int Nq = N1 * N1, Nfq = 4 * N1, Nh = Nq + Nfq, E = TCfg<N1>::E;
+  using G = typename WgR<N1, VISC>::G;
+  static constexpr int Nq = N1 * N1, Nfq = 4 * N1, Nh = Nq + Nfq, E = G::E;
   static constexpr int nQh = E * Nh * 6;                 // prims+logs of all hybrid nodes; also interp scratch
-  static constexpr int nFlux = E * (4 * Nq + 4 * Nfq);   // sAcc + sG
+  static constexpr int nAcc1 = 4 * Nq + 4 * Nfq;         // accumulators of one element: sAcc[4][Nq] + sG[4][Nfq]
+  static constexpr int nFlux = (E + G::NS) * nAcc1; // sAcc + sG, and a second copy for every straddling element
   static constexpr int nVisc = VISC ? E * 3 * Nfq : 0;   // sSj(3) per face node (sVn and sS live in the sQh region)
   static_assert(!VISC || 6 * Nq <= 6 * Nh, "sS must fit in the sQh region");
   static constexpr int nR2 = nFlux > nVisc ? nFlux : nVisc;
@@ -665,7 +727,7 @@ struct RhsLds {
 };
 
 template <int N1, bool MODAL, bool VISC, bool WALLS>
-__global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, Phys ph, const double* Q,
+__global__ __launch_bounds__((WgR<N1, VISC>::TPB)) void kt_rhs(TensorTables TT, MeshDev M, Phys ph, const double* Q,
                                              const double* __restrict__ A_U, const double* __restrict__ SG,
                                              const double* __restrict__ B, double* rhs, LsrkFuse lf) {
   using LD = RhsLds<N1, VISC>;
@@ -675,23 +737,53 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
   constexpr TensorLayout L(N1);
   __shared__ double sTab[L.NDBL];
   __shared__ int sInt[L.NINT];
-  __shared__ __align__(16) double sQh_[NWV * LD::nQh];
-  __shared__ __align__(16) double sR2_[NWV * LD::nR2];
-  double* sQh = sQh_ + (threadIdx.x / TW) * LD::nQh;
-  double* sR2 = sR2_ + (threadIdx.x / TW) * LD::nR2;
-  double* sAcc = sR2;                  // [E][Nq][4]   partner contributions (volume nodes)
-  double* sG = sR2 + E * 4 * Nq;       // [E][Nfq][4]  face-node sums, then QF_f + wfac*flux_f
-  const Lane<N1> ln;
+  using W = WgR<N1, VISC>;
+  using G = typename W::G;
+  __shared__ __align__(16) double sQh_[W::NG * LD::nQh];
+  __shared__ __align__(16) double sR2_[W::NG * LD::nR2];
+  const Lane<N1, W::GW> ln;
+  double* sQh = sQh_ + ln.grp * LD::nQh;
+  double* sR2 = sR2_ + ln.grp * LD::nR2;
+  double* sAcc = sR2;                  // [E][4][Nq]   partner contributions (volume nodes)
+  double* sG = sR2 + E * 4 * Nq;       // [E][4][Nfq]  face-node sums, then QF_f + wfac*flux_f
+  // ds_add_f64 order is fixed within a wave but not between waves: an element whose lanes straddle two waves gets a
+  // second accumulator copy (sAcc2 | sG2) that the lanes of its second wave add into; the copies are summed in a fixed
+  // order afterwards, so the result does not depend on wave scheduling.
+  double* myAcc = sAcc + ln.ev * 4 * Nq;     // where this volume lane adds partner contributions
+  double* myG = sG + ln.ev * 4 * Nfq;
+  const double* acc2 = nullptr;              // second copy of this volume lane's element (null: not straddling)
+  double* zeroF2 = nullptr;                  // second sG copy this face lane initialises
+  if (G::NS > 0) {
+    double* sec = sR2 + E * LD::nAcc1;
+    int so_v = 0, so_f = 0;
+    bool sv = false, sf = false;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      if (G::strad(e)) {
+        if (e < ln.ev) ++so_v;
+        if (e < ln.ef) ++so_f;
+        if (e == ln.ev) sv = true;
+        if (e == ln.ef) sf = true;
+      }
+    }
+    if (sv && ln.vin) {
+      double* c2 = sec + so_v * LD::nAcc1;
+      acc2 = c2;
+      if (ln.tid / TW != (ln.ev * Nq) / TW) { myAcc = c2; myG = c2 + 4 * Nq; }
+    }
+    if (sf && ln.fin) zeroF2 = sec + so_f * LD::nAcc1 + 4 * Nq;
+  }
   stage_tables<N1>(TT, sTab, sInt);
   __syncthreads();
-  const int64_t e0 = M.e_begin + ((int64_t)blockIdx.x * NWV + ln.wave) * E;
+  const int64_t e0 = M.e_begin + ((int64_t)blockIdx.x * W::NG + ln.grp) * E;
   const int nE = (int)max((int64_t)0, min((int64_t)E, M.e_begin + M.e_count - e0));
   const bool vactive = ln.tid < nE * Nq, factive = ln.tid < nE * Nfq;
-  const double* g = M.geo + (e0 + (vactive ? ln.ev : 0)) * GEO_STRIDE;
+  const int64_t e0s = min(e0, M.e_begin + M.e_count - 1);   // in-range base for the geometry reads of idle lanes / idle groups
+  const double* g = M.geo + (e0s + (vactive ? ln.ev : 0)) * GEO_STRIDE;
 
   // ---- every global load of this workgroup is issued before any arithmetic -------------------
   double x[4];
-  issue_state_loads<N1>(Q, M.K, e0, vactive, x);
+  issue_state_loads<N1>(Q, M.K, e0, vactive, ln.tid, x);
   double qM[8], qP[8], pnr[3] = {0, 0, 0}, bPn[3] = {0, 0, 0}, bOwn[3] = {0, 0, 0};   // pnr: penalty tau*[[v]] of the face node
   int64_t mpk = 0;
   int bcf = 0;
@@ -731,6 +823,11 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     dq[2] = make_double2(qh[4], qh[5]);
 #pragma unroll
     for (int c = 0; c < 4; ++c) sAcc[(ln.ev * 4 + c) * Nq + ln.q] = 0.0;
+    if (G::NS > 0 && acc2) {
+      double* z = const_cast<double*>(acc2);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) z[c * Nq + ln.q] = 0.0;
+    }
   }
   // ---- face lanes: interface flux (euler_quad.jl:158-169 / update_flux! :308-324), kept in registers
   const bool inviscid = (ph.parts & 1) != 0;
@@ -739,7 +836,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     dq[0] = make_double2(qM[0], qM[1]);
     dq[1] = make_double2(qM[2], qM[3]);
     dq[2] = make_double2(qM[4], qM[5]);
-    const double* gn = M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
+    const double* gn = M.geo + (e0s + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
     if (VISC && ph.viscous_dissp) {
       // penalty tau*[[v]] (:817-837): own and neighbour projected entropy variables are the entropy variables of the
       // two trace states (see kt_project), so no interpolation of nodal values is needed here
@@ -773,6 +870,10 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     const double wf = inviscid ? sTab[L.WFAC + ln.fn] : 0.0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) sG[(ln.ef * 4 + c) * Nfq + ln.fn] = wf * (Fn[c] - LFc * dU[c]);
+    if (G::NS > 0 && zeroF2) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) zeroF2[c * Nfq + ln.fn] = 0.0;
+    }
   }
   __syncthreads();
 
@@ -796,7 +897,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
         const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
         double Fd[4];
         ec_flux_dir<MODAL>(qh, qj, cw * gx, cw * gy, Fd);
-        double* tgt = sAcc + ln.ev * 4 * Nq + pid;
+        double* tgt = myAcc + pid;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           acc[c] += Fd[c];
@@ -812,7 +913,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
         const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
         double vv[4];
         ec_flux_dir<MODAL>(qh, qj, cw * gx, cw * gy, vv);
-        double* tgt = sG + ln.ev * 4 * Nfq + f;
+        double* tgt = myG + f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] += vv[c];
         // all N1 lanes of the line add into the same face node: rotate the field order by the lane's
@@ -844,7 +945,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
       const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
       double Fd[4];
       ec_flux_dir<MODAL>(qh, qj, cw * gx, cw * gy, Fd);
-      double* tgt = sAcc + ln.ev * 4 * Nq + pid;
+      double* tgt = myAcc + pid;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         acc[c] += Fd[c];
@@ -860,7 +961,11 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     const double pd = sTab[L.PD + ln.q];
     double r[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) r[c] = pd * (acc[c] + sAcc[(ln.ev * 4 + c) * Nq + ln.q]);
+    for (int c = 0; c < 4; ++c) {
+      double part = sAcc[(ln.ev * 4 + c) * Nq + ln.q];
+      if (G::NS > 0 && acc2) part += acc2[c * Nq + ln.q];
+      r[c] = pd * (acc[c] + part);
+    }
 #pragma unroll 1
     for (int d = 0; d < 2; ++d) {
       const int pos = ln.pos(d), oth = ln.oth(d);
@@ -869,7 +974,11 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
         const int f = sInt[L.FN + (d * 2 + t) * N1 + oth];
         const double w = sTab[L.PF + (d * 2 + t) * N1 + pos] * sTab[L.PTF + (d * 2 + t) * N1 + oth];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) r[c] += w * sG[(ln.ev * 4 + c) * Nfq + f];
+        for (int c = 0; c < 4; ++c) {
+          double gf = sG[(ln.ev * 4 + c) * Nfq + f];
+          if (G::NS > 0 && acc2) gf += acc2[4 * Nq + c * Nfq + f];
+          r[c] += w * gf;
+        }
       }
     }
 #pragma unroll
@@ -907,7 +1016,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
     // stress jumps .5*((sxP-sxf)*nxJ + (syP-syf)*nyJ): the neighbour's normal stress from B carries
     // its own outward normal = minus ours (dg_div! :606)
     if (ln.fin) {
-      const double* gn = M.geo + (e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
+      const double* gn = M.geo + (e0s + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
       double sn[3], fx[3] = {0, 0, 0}, fy[3] = {0, 0, 0}, sj[3];
       if (WALLS) {
         face_normal_stress<N1>(ln, sTab, sInt, sS, gn[0], gn[1], sn, fx, fy);
@@ -936,7 +1045,7 @@ __global__ __launch_bounds__(TW * NWV) void kt_rhs(TensorTables TT, MeshDev M, P
       }
       // the penalty is lifted WITHOUT the 1/J of the divergence (:839-845, quirk Q3): fold it into the stress jump
       // as J*pn so one lifted array serves both (J*(1/J) differs from 1 by one rounding of the penalty only)
-      const double Jf = ph.viscous_dissp ? M.geo[(e0 + (factive ? ln.ef : 0)) * GEO_STRIDE + 4] : 0.0;
+      const double Jf = ph.viscous_dissp ? M.geo[(e0s + (factive ? ln.ef : 0)) * GEO_STRIDE + 4] : 0.0;
 #pragma unroll
       for (int c = 0; c < 3; ++c) sSj[(ln.ef * 3 + c) * Nfq + ln.fn] = sj[c] + Jf * pnr[c];
     }
@@ -1005,22 +1114,24 @@ int launch_project_tensor(int N1v, const TensorTables& TT, const MeshDev& M, con
   if (M.e_count <= 0) return 0;
   const bool modal = ph.formulation != 0, visc = ph.formulation == 1;
   ESDG_DISPATCH_N1(N1v, {
-    constexpr int E = TCfg<N1>::E;
-    const int nb = (int)((M.e_count + (int64_t)E * NWV - 1) / ((int64_t)E * NWV));
+    using W = WgP<N1>;
+    constexpr int EPB = W::EPB;
+    constexpr int TPB = W::TPB;
+    const int nb = (int)((M.e_count + EPB - 1) / EPB);
     if (!modal)
-      hipLaunchKernelGGL((kt_project<N1, false, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v);
+      hipLaunchKernelGGL((kt_project<N1, false, false>), dim3(nb), dim3(TPB), 0, s, TT, M, ph, Q, A_U, A_v);
     else if (visc)
-      hipLaunchKernelGGL((kt_project<N1, true, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v);
+      hipLaunchKernelGGL((kt_project<N1, true, true>), dim3(nb), dim3(TPB), 0, s, TT, M, ph, Q, A_U, A_v);
     else
-      hipLaunchKernelGGL((kt_project<N1, true, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, A_v);
+      hipLaunchKernelGGL((kt_project<N1, true, false>), dim3(nb), dim3(TPB), 0, s, TT, M, ph, Q, A_U, A_v);
   });
   return (int)hipGetLastError();
 }
 
 int sigma_tensor_blocks(int N1v, int64_t K) {
   ESDG_DISPATCH_N1(N1v, {
-    constexpr int E = TCfg<N1>::E;
-    return (int)((K + (int64_t)E * NWV - 1) / ((int64_t)E * NWV));
+    constexpr int EPB = WgS<N1>::EPB;
+    return (int)((K + EPB - 1) / EPB);
   });
   return 0;
 }
@@ -1029,12 +1140,14 @@ int launch_sigma_tensor(int N1v, const TensorTables& TT, const MeshDev& M, const
                         const double* A_U, double* B, double* SG, double* vt_partial, hipStream_t s) {
   if (M.e_count <= 0) return 0;
   ESDG_DISPATCH_N1(N1v, {
-    constexpr int E = TCfg<N1>::E;
-    const int nb = (int)((M.e_count + (int64_t)E * NWV - 1) / ((int64_t)E * NWV));
+    using W = WgS<N1>;
+    constexpr int EPB = W::EPB;
+    constexpr int TPB = W::TPB;
+    const int nb = (int)((M.e_count + EPB - 1) / EPB);
     if (vt_partial)
-      hipLaunchKernelGGL((kt_sigma<N1, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, B, SG, vt_partial);
+      hipLaunchKernelGGL((kt_sigma<N1, true>), dim3(nb), dim3(TPB), 0, s, TT, M, ph, Q, A_U, B, SG, vt_partial);
     else
-      hipLaunchKernelGGL((kt_sigma<N1, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, B, SG, vt_partial);
+      hipLaunchKernelGGL((kt_sigma<N1, false>), dim3(nb), dim3(TPB), 0, s, TT, M, ph, Q, A_U, B, SG, vt_partial);
   });
   return (int)hipGetLastError();
 }
@@ -1044,21 +1157,23 @@ int launch_rhs_tensor(int N1v, const TensorTables& TT, const MeshDev& M, const P
                       hipStream_t s) {
   if (M.e_count <= 0) return 0;
   const bool modal = ph.formulation != 0, visc = ph.formulation == 1;
+  // grid and workgroup shape depend on the instantiation (WgR<N1, VISC>)
+#define ESDG_LAUNCH_RHS(MODALv, VISCv, WALLSv)                                                                   \
+  do {                                                                                                          \
+    using W = WgR<N1, VISCv>;                                                                                   \
+    const int nb = (int)((M.e_count + W::EPB - 1) / W::EPB);                                                    \
+    hipLaunchKernelGGL((kt_rhs<N1, MODALv, VISCv, WALLSv>), dim3(nb), dim3(W::TPB), 0, s, TT, M, ph, Q, A_U, SG, \
+                       B, rhs, lf);                                                                             \
+  } while (0)
   ESDG_DISPATCH_N1(N1v, {
-    constexpr int E = TCfg<N1>::E;
-    const int nb = (int)((M.e_count + (int64_t)E * NWV - 1) / ((int64_t)E * NWV));
     const bool walls = M.bc != nullptr;
-    if (!modal)
-      hipLaunchKernelGGL((kt_rhs<N1, false, false, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
-    else if (visc && walls)
-      hipLaunchKernelGGL((kt_rhs<N1, true, true, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
-    else if (visc)
-      hipLaunchKernelGGL((kt_rhs<N1, true, true, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
-    else if (walls)
-      hipLaunchKernelGGL((kt_rhs<N1, true, false, true>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
-    else
-      hipLaunchKernelGGL((kt_rhs<N1, true, false, false>), dim3(nb), dim3(TW * NWV), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
+    if (!modal) ESDG_LAUNCH_RHS(false, false, false);
+    else if (visc && walls) ESDG_LAUNCH_RHS(true, true, true);
+    else if (visc) ESDG_LAUNCH_RHS(true, true, false);
+    else if (walls) ESDG_LAUNCH_RHS(true, false, true);
+    else ESDG_LAUNCH_RHS(true, false, false);
   });
+#undef ESDG_LAUNCH_RHS
   return (int)hipGetLastError();
 }
 
