@@ -169,7 +169,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_project(HexTables HT, MeshDev M,
   const int64_t nblk = (M.e_count + HNWV - 1) / HNWV;
   const int64_t blk = block_of(nblk, remap != 0);
   if (blk < 0) return;
-  const int lane = threadIdx.x & (HW - 1), wv = threadIdx.x / HW;
+  const int lane = threadIdx.x & (HW - 1), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / HW));   // wave-uniform: keep it scalar
   const int64_t e = M.e_begin + blk * HNWV + wv;
   const bool active = e < M.e_begin + M.e_count;
   const int64_t ec = active ? e : M.e_begin + M.e_count - 1;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
   const int64_t nblk = (M.e_count + HNWV - 1) / HNWV;
   const int64_t blk = block_of(nblk, remap != 0);
   if (blk < 0) return;
-  const int lane = threadIdx.x & (HW - 1), wv = threadIdx.x / HW;
+  const int lane = threadIdx.x & (HW - 1), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / HW));   // wave-uniform: keep it scalar
   const int64_t e = M.e_begin + blk * HNWV + wv;
   const bool active = e < M.e_begin + M.e_count;
   const int64_t ec = active ? e : M.e_begin + M.e_count - 1;

@@ -52,7 +52,7 @@ def test_euler_collocated_matches_oracle(eng_mod, oracle_lib, N, Kx, Ky):
         assert errw <= TOL, errw          # strict north-star bound where the reference is well conditioned
 
 
-@pytest.mark.parametrize("N,Kx,Ky", [(4, 12, 8), (3, 10, 10), (2, 7, 9), (1, 5, 5), (5, 4, 4)])
+@pytest.mark.parametrize("N,Kx,Ky", [(4, 12, 8), (3, 10, 10), (2, 7, 9), (1, 5, 5), (5, 4, 4), (4, 7, 3), (5, 5, 3), (6, 4, 3)])
 def test_cns_modal_matches_oracle(eng_mod, oracle_lib, N, Kx, Ky):
     from oracle import oracle as orc
     p = orc.build_cns_problem(N, Kx, Ky, bc="periodic")
@@ -84,7 +84,7 @@ def test_modal_euler_matches_oracle_inviscid(eng_mod, oracle_lib):
 
 
 @pytest.mark.parametrize("BCTYPE", [1, 2, 3])
-@pytest.mark.parametrize("N,Kx,Ky", [(3, 6, 5), (4, 4, 4)])
+@pytest.mark.parametrize("N,Kx,Ky", [(3, 6, 5), (4, 4, 4), (5, 4, 3)])
 def test_cns_wall_boundary_conditions_match_oracle(eng_mod, oracle_lib, BCTYPE, N, Kx, Ky):
     """Lid-driven cavity walls (init_BC_funs, dg2D_CNS_cavity_optimized.jl:135-265): adiabatic no-slip (1),
     isothermal (2), slip (3), lid on y=+1.  Low-Mach cavity states sit in the ill-conditioned window of the
