@@ -95,6 +95,25 @@ def cpu_baseline_hex(N, lf, budget_s=15.0):
             "rhs_evals_per_s_at_sample": 1.0 / dt}
 
 
+def usable_cpus():
+    """Host cores this process may actually use: affinity mask and cgroup CPU quota (a GPU box hands each job a share
+    of a 128-core host; 128 OpenMP threads on a 16-core share run slower than one)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                                   # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:                                               # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(N, formulation, budget_s=15.0):
     """Reference algorithm restated in C (oracle/oracle_rhs.c, the reference's loop structure: 825
     visited pairs/element in flux_differencing!), timed single-threaded like the Julia reference, on a
@@ -122,7 +141,7 @@ def cpu_baseline(N, formulation, budget_s=15.0):
     dt = (time.perf_counter() - t0) / n
     K, Np = p.md.K, (N + 1) ** 2
     # the same restatement with OpenMP over elements on every host core (variant ii)
-    nthr = int(orc.lib().oracle_get_max_threads())
+    nthr = min(int(orc.lib().oracle_get_max_threads()), usable_cpus())
     orc.lib().oracle_set_threads(nthr)
     fn()
     t1 = time.perf_counter()
@@ -243,17 +262,23 @@ def main():
     alg_bytes = 16.0 * nfld * Np * K_local       # read state once + write rhs once
     achieved = alg_bytes / (kdur_ms * 1e-3) / 1e9
     traffic = None
+    prof_us = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
             key = f"hex_N{N}_{Kx}x{Kx}x{args.kz_per_gpu}" if hexw else f"{args.formulation}_N{N}_{Kx}x{args.ky_per_gpu}"
-            traffic = json.load(open(pmc)).get(key, {}).get("k_rhs_hbm_bytes_per_launch")
+            rec = json.load(open(pmc)).get(key, {})
+            traffic = rec.get("k_rhs_hbm_bytes_per_launch")
+            prof_us = rec.get("k_rhs_rocprofv3_avg_us")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": "kh_rhs (last phase: surface flux + flux differencing + lift)" if hexw else
                 "k_rhs (last phase: flux differencing + viscous divergence)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "kernel_ms": kdur_ms,
+                # the same kernel under rocprofv3 --kernel-trace (committed profile): the profiler serialises dispatches
+                # and drops the L2 state between them, which costs these trace-coupled kernels 5-9 %
+                "kernel_ms_rocprofv3": None if prof_us is None else prof_us / 1e3,
                 "whole_rhs_frac": (alg_bytes * evals_per_s / 1e9) / HBM_PEAK_GBS}
 
     if hexw:

@@ -52,7 +52,7 @@ def test_euler_collocated_matches_oracle(eng_mod, oracle_lib, N, Kx, Ky):
         assert errw <= TOL, errw          # strict north-star bound where the reference is well conditioned
 
 
-@pytest.mark.parametrize("N,Kx,Ky", [(4, 12, 8), (3, 10, 10), (2, 7, 9), (1, 5, 5), (5, 4, 4), (4, 7, 3), (5, 5, 3), (6, 4, 3)])
+@pytest.mark.parametrize("N,Kx,Ky", [(4, 12, 8), (3, 10, 10), (2, 7, 9), (1, 5, 5), (5, 4, 4), (4, 7, 3), (5, 5, 3), (6, 6, 5)])
 def test_cns_modal_matches_oracle(eng_mod, oracle_lib, N, Kx, Ky):
     from oracle import oracle as orc
     p = orc.build_cns_problem(N, Kx, Ky, bc="periodic")

@@ -37,8 +37,22 @@ for k in sorted(set(f) | set(w)):
 dst = os.path.join(root, "profiles", "pmc_traffic.json")
 allj = json.load(open(dst)) if os.path.exists(dst) else {}
 rhs = [v for k, v in out.items() if "_rhs<" in k]
-allj[key] = {"source": f"gpurun_out/prof_{tag} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-             "kernels": out, "k_rhs_hbm_bytes_per_launch": rhs[0]["hbm_bytes_per_launch"] if rhs else None}
+# average kernel durations of the --kernel-trace --stats pass of the same command (profiles/<tag>_*_kernel_stats.csv)
+stats = os.path.join(src, "kernel_stats.csv")
+avg_us = {}
+if os.path.exists(stats):
+    for r in csv.DictReader(open(stats)):
+        n = r["Name"].split("(")[0].replace("void ", "")
+        if "esdg::" in n:
+            avg_us[n] = float(r["AverageNs"]) / 1e3
+for k in out:
+    if k in avg_us:
+        out[k]["rocprofv3_avg_us"] = avg_us[k]
+rhs_name = [k for k in out if "_rhs<" in k]
+allj[key] = {"source": f"gpurun_out/prof_{tag} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; durations from the "
+                       "--kernel-trace --stats pass)",
+             "kernels": out, "k_rhs_hbm_bytes_per_launch": rhs[0]["hbm_bytes_per_launch"] if rhs else None,
+             "k_rhs_rocprofv3_avg_us": avg_us.get(rhs_name[0]) if rhs_name else None}
 json.dump(allj, open(dst, "w"), indent=1)
 for k, v in out.items():
     print(f"{k:45s} fetch(raw) {v['fetch_bytes_raw']/1e6:9.1f} MB  x2 {v['fetch_bytes_x2']/1e6:9.1f} MB  write {v['write_bytes']/1e6:9.1f} MB")
