@@ -99,6 +99,7 @@ class RhsEngine:
 
         # halo plan
         self.nranks = nranks
+        self.group = group
         self.halo = None
         nn = L.esdg_halo_num_neighbors(ctx)
         self.xinfo = []
@@ -357,25 +358,49 @@ class RhsEngine:
     def _par(par):
         return None if par is None else (C.c_double * 6)(*[float(v) for v in par])
 
+    def _reduce(self, sums=None, maxs=None):
+        """Sum / max of per-rank partial results over the engine's process group (sharded meshes)."""
+        if self.nranks <= 1:
+            return sums, maxs
+        import torch.distributed as dist
+        dev = self.device if dist.get_backend(self.group) == "nccl" else "cpu"
+        res = []
+        for vals, op in ((sums, dist.ReduceOp.SUM), (maxs, dist.ReduceOp.MAX)):
+            if vals is None:
+                res.append(None)
+                continue
+            t = torch.tensor(vals, dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=op, group=self.group)
+            res.append(t.tolist())
+        return res[0], res[1]
+
     def l2_error(self, Qd, t, exact=0, par=None):
         """(L2err, per-field sums of squares) against vortex (exact=0) or the Becker shock (exact=1, par) at time t,
-        dg2D_euler_quad.jl:214-233; local elements only (add the sums over ranks before the square root)."""
+        dg2D_euler_quad.jl:214-233; on a sharded mesh the sums are added over the ranks before the square root."""
         out = (C.c_double * 5)()
         check(self.L.esdg_error_l2(self.ctx, C.c_void_p(Qd.data_ptr()), exact, self._par(par), float(t), out, self._stream()))
-        return out[0], list(out)[1:]
+        sums, _ = self._reduce(sums=list(out)[1:])
+        return float(np.sqrt(sum(sums))) if self.nranks > 1 else out[0], sums
 
     def nodal_error(self, Qd, t, exact=1, par=None):
-        """(L1err, Linferr, raw) of dg2D_CNS_modalESDG.jl:745-771."""
+        """(L1err, Linferr, raw) of dg2D_CNS_modalESDG.jl:745-771 (sums and maxima reduced over the ranks)."""
         out = (C.c_double * 14)()
         check(self.L.esdg_error_nodal(self.ctx, C.c_void_p(Qd.data_ptr()), exact, self._par(par), float(t), out, self._stream()))
-        return out[0], out[1], list(out)[2:]
+        raw = list(out)[2:]
+        if self.nranks <= 1:
+            return out[0], out[1], raw
+        sums, maxs = self._reduce(sums=[raw[4 * c + i] for c in range(3) for i in (0, 1)],
+                                  maxs=[raw[4 * c + i] for c in range(3) for i in (2, 3)])
+        raw = [v for c in range(3) for v in (sums[2 * c], sums[2 * c + 1], maxs[2 * c], maxs[2 * c + 1])]
+        return (sum(raw[4 * c] / raw[4 * c + 1] for c in range(3)), sum(raw[4 * c + 2] / raw[4 * c + 3] for c in range(3)), raw)
 
     def boundary_velocity_error(self, Qd, Jf):
         """dg2D_CNS_convergence_test.jl:1055-1080 (Jf = 2/K1D there) -> (err as executed by Julia: the u_2 term only,
         err as written: all three terms, the three sums); see include/esdg_hip.h."""
         out = (C.c_double * 5)()
         check(self.L.esdg_error_boundary_velocity(self.ctx, C.c_void_p(Qd.data_ptr()), float(Jf), out, self._stream()))
-        return out[0], out[1], list(out)[2:]
+        sums, _ = self._reduce(sums=list(out)[2:])
+        return float(np.sqrt(sums[0])), float(np.sqrt(sum(sums))), sums
 
     def check_state(self, Qd):
         """(min rho, min p) over the local nodal values; the reference raises DomainError where these are <= 0."""

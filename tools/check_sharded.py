@@ -68,11 +68,22 @@ eng.rhs_lsrk_fused(Q1, res, -0.41789, 0.37921, 1e-3)
 torch.cuda.synchronize()
 parts = [None] * world
 dist.all_gather_object(parts, (out.cpu().numpy(), Q1.cpu().numpy()))
+# error functionals reduce their partial sums over the ranks
+from esdg_cns_amd import setup_dg as sd  # noqa: E402
+func = None
+if args.formulation in ("cns", "euler"):
+    Vq2, wq2 = sd.error_quadrature(N)
+    eng.setup_errors(rd, md, Vq2, wq2)
+    func = eng.l2_error(Qd, 0.1)[0]
+elif args.formulation == "cavity":
+    eng.setup_errors(rd, md, boundary=True)
+    func = eng.boundary_velocity_error(Qd, 0.25)[1]
 ok = True
 if rank == 0:
     rdf, mdf, opsf, Qf = build(None)
     full = engine.RhsEngine(rdf, mdf, opsf, form, **kw)
     Qfd = full.upload(Qf)
+    Qfd0 = Qfd.clone()
     ref = full.rhs(Qfd).cpu().numpy()
     resf = torch.full_like(Qfd, 0.01)
     full.rhs_lsrk_fused(Qfd, resf, -0.41789, 0.37921, 1e-3)
@@ -83,6 +94,15 @@ if rank == 0:
     # the shard's geometry comes from its own host set-up; with mesh spacings that are not dyadic the BLAS products
     # there may differ from the full mesh's by an ulp, hence the round-off fallback
     ok = bitwise or rel < 1e-12
+    if func is not None:
+        if args.formulation == "cavity":
+            full.setup_errors(rdf, mdf, boundary=True)
+            fref = full.boundary_velocity_error(Qfd0, 0.25)[1]
+        else:
+            full.setup_errors(rdf, mdf, Vq2, wq2)
+            fref = full.l2_error(Qfd0, 0.1)[0]
+        ok = ok and abs(func - fref) <= 1e-12 * abs(fref)
+        print(f"  error functional sharded {func:.15e} vs single {fref:.15e}")
     lo, hi = eng.interior
     print(f"check_sharded {args.formulation} world={world} backend={args.backend}: "
           f"{'BITWISE EQUAL' if bitwise else ('EQUAL TO ROUND-OFF' if ok else 'MISMATCH')} "
