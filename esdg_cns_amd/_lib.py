@@ -70,6 +70,7 @@ SYMBOLS = {
     "esdg_rhs_phase_lsrk": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp]),
     "esdg_rhstest": (C.c_int, [_vp, _vp, _vp, c_double_p, _vp]),
     "esdg_check_state": (C.c_int, [_vp, _vp, c_double_p, _vp]),
+    "esdg_abi_sizeof": (C.c_int64, [C.c_char_p]),
     "esdg_error_setup": (C.c_int, [_vp, C.POINTER(esdg_err_ops_t)]),
     "esdg_error_l2": (C.c_int, [_vp, _vp, C.c_int32, c_double_p, C.c_double, c_double_p, _vp]),
     "esdg_error_nodal": (C.c_int, [_vp, _vp, C.c_int32, c_double_p, C.c_double, c_double_p, _vp]),
@@ -138,6 +139,10 @@ def lib():
             fn = getattr(L, name)      # AttributeError if the ABI and the header drifted apart
             fn.restype = res
             fn.argtypes = args
+        for st in (esdg_ops_t, esdg_mesh_t, esdg_phys_t, esdg_hex_ops_t, esdg_hex_mesh_t, esdg_err_ops_t):
+            want = L.esdg_abi_sizeof(st.__name__.encode())
+            if want != C.sizeof(st):
+                raise EsdgError(f"ABI drift: {st.__name__} is {want} bytes in libesdg_hip.so, {C.sizeof(st)} in _lib.py")
         _LIB = L
     return _LIB
 

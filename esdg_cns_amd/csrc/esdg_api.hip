@@ -498,6 +498,18 @@ extern "C" {
 const char* esdg_last_error(void) { return g_err.c_str(); }
 const char* esdg_version(void) { return "esdg_hip 0.1 (gfx950)"; }
 
+int64_t esdg_abi_sizeof(const char* name) {
+  if (!name) return -1;
+  const std::string n(name);
+  if (n == "esdg_ops_t") return (int64_t)sizeof(esdg_ops_t);
+  if (n == "esdg_mesh_t") return (int64_t)sizeof(esdg_mesh_t);
+  if (n == "esdg_phys_t") return (int64_t)sizeof(esdg_phys_t);
+  if (n == "esdg_hex_ops_t") return (int64_t)sizeof(esdg_hex_ops_t);
+  if (n == "esdg_hex_mesh_t") return (int64_t)sizeof(esdg_hex_mesh_t);
+  if (n == "esdg_err_ops_t") return (int64_t)sizeof(esdg_err_ops_t);
+  return -1;
+}
+
 int esdg_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

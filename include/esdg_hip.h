@@ -162,6 +162,10 @@ int esdg_num_fields(const esdg_ctx* ctx);   /* 4 (2D) or 5 (hex) */
 int esdg_destroy(esdg_ctx* ctx);
 const char* esdg_last_error(void);
 const char* esdg_version(void);
+/* sizeof of a public struct by name ("esdg_ops_t", "esdg_mesh_t", "esdg_phys_t", "esdg_hex_ops_t", "esdg_hex_mesh_t",
+ * "esdg_err_ops_t"), -1 if unknown: lets an FFI binding (Julia struct, ctypes.Structure) check its mirror of the
+ * layout at load time instead of corrupting memory */
+int64_t esdg_abi_sizeof(const char* struct_name);
 
 /* Scratch (face-trace buffers A/B, halo send buffers) is caller-owned device memory so the host
  * framework (torch / Julia) controls allocation; bind it once. */

@@ -1,0 +1,271 @@
+# ESDGHip.jl -- thin `ccall` layer over libesdg_hip.so (include/esdg_hip.h) for the reference's Julia drivers.
+#
+# STATUS: reviewed but UN-RUN source.  Julia is not available in the pipeline that builds and tests this repository;
+# the identical C ABI is exercised by the Python ctypes binding (esdg_cns_amd/_lib.py, engine.py) and by the C drivers
+# in examples/c/.  `__init__` checks every struct mirror below against the library (`esdg_abi_sizeof`), so a layout
+# mistake fails at load time instead of corrupting memory.  INTEGRATION.md shows the edits to each driver script.
+#
+# No CUDA.jl / AMDGPU.jl: device memory is handled by the library (esdg_dmalloc / esdg_memcpy_*), the state stays on
+# the device between right-hand-side evaluations.
+module ESDGHip
+
+export Engine, CnsEngine, HexEngine, upload!, download!, rhs!, rhsRK!, lsrk!, rhs_lsrk!, lsrk45_step!,
+       dopri45_attempt!, dopri45_next_dt, setup_errors!, l2_error, nodal_error, boundary_velocity_error, rhs, destroy!
+
+const LIB = joinpath(@__DIR__, "..", "esdg_cns_amd", "libesdg_hip.so")   # built by `python -m esdg_cns_amd.build`
+
+# ---- mirrors of the C structs (field order and types of include/esdg_hip.h) ------------------------------------
+struct OpsT
+    N::Int32; Np::Int32; Nq::Int32; Nfq::Int32
+    Qrhskew::Ptr{Float64}; Qshskew::Ptr{Float64}; Ph::Ptr{Float64}; wq::Ptr{Float64}; wf::Ptr{Float64}
+    Ef::Ptr{Float64}; Lf::Ptr{Float64}
+    Vq::Ptr{Float64}; Pq::Ptr{Float64}; VhP::Ptr{Float64}; LIFT::Ptr{Float64}
+    Vf::Ptr{Float64}; Dr::Ptr{Float64}; Ds::Ptr{Float64}
+end
+struct MeshT
+    K::Int64; geo_ld::Int32
+    rxJ::Ptr{Float64}; sxJ::Ptr{Float64}; ryJ::Ptr{Float64}; syJ::Ptr{Float64}
+    J::Ptr{Float64}; wJq::Ptr{Float64}; nxJ::Ptr{Float64}; nyJ::Ptr{Float64}; sJ::Ptr{Float64}
+    mapP::Ptr{Int64}; mapB::Ptr{Int64}; NmapB::Int64; bkind::Ptr{UInt8}
+    elem_offset::Int64; Kglobal::Int64; nranks::Int32; rank::Int32; rank_offsets::Ptr{Int64}
+    vlid::Ptr{Float64}
+end
+struct PhysT
+    formulation::Int32; lf_scale::Float64; inviscid_dissp::Int32; viscous_dissp::Int32; BCTYPE::Int32
+    Re::Float64; mu::Float64; lambda::Float64; Pr::Float64
+    inflow_rho::Float64; inflow_u::Float64; inflow_v::Float64; inflow_p::Float64
+end
+struct HexOpsT
+    N::Int32; Nq::Int32; Nfq::Int32
+    Qrhskew::Ptr{Float64}; Qshskew::Ptr{Float64}; Qthskew::Ptr{Float64}
+    Ph::Ptr{Float64}; Lf::Ptr{Float64}; Ef::Ptr{Float64}; wq::Ptr{Float64}; wf::Ptr{Float64}
+end
+struct HexMeshT
+    K::Int64; geo_ld::Int32
+    rxJ::Ptr{Float64}; sxJ::Ptr{Float64}; txJ::Ptr{Float64}; ryJ::Ptr{Float64}; syJ::Ptr{Float64}; tyJ::Ptr{Float64}
+    rzJ::Ptr{Float64}; szJ::Ptr{Float64}; tzJ::Ptr{Float64}
+    J::Ptr{Float64}; wJq::Ptr{Float64}; nxJ::Ptr{Float64}; nyJ::Ptr{Float64}; nzJ::Ptr{Float64}; sJ::Ptr{Float64}
+    mapP::Ptr{Int64}; elem_offset::Int64; Kglobal::Int64; nranks::Int32; rank::Int32; rank_offsets::Ptr{Int64}
+end
+struct ErrOpsT
+    Nq2::Int32; Vq2::Ptr{Float64}; wq2::Ptr{Float64}; x::Ptr{Float64}; y::Ptr{Float64}; J::Ptr{Float64}
+    Vf::Ptr{Float64}; wf::Ptr{Float64}
+end
+
+const EULER_COLLOCATED, CNS_MODAL, EULER_MODAL, EULER_HEX_COLLOCATED = Int32(0), Int32(1), Int32(2), Int32(3)
+const EXACT_VORTEX, EXACT_BECKER = Int32(0), Int32(1)
+
+check(rc) = rc == 0 || error(unsafe_string(ccall((:esdg_last_error, LIB), Cstring, ())))
+
+function __init__()
+    for (T, name) in ((OpsT, "esdg_ops_t"), (MeshT, "esdg_mesh_t"), (PhysT, "esdg_phys_t"), (HexOpsT, "esdg_hex_ops_t"),
+                      (HexMeshT, "esdg_hex_mesh_t"), (ErrOpsT, "esdg_err_ops_t"))
+        want = ccall((:esdg_abi_sizeof, LIB), Int64, (Cstring,), name)
+        want == sizeof(T) || error("ESDGHip: $name is $want bytes in libesdg_hip.so but $(sizeof(T)) here (ABI drift)")
+    end
+end
+
+dense(A) = Matrix{Float64}(A)          # rd/ops fields may be SparseMatrixCSC (SetupDG.jl:59-70)
+
+mutable struct Engine
+    ctx::Ptr{Cvoid}; ws::Ptr{Cvoid}; K::Int; Np::Int; nfld::Int
+    Qd::Ptr{Float64}; rhsd::Ptr{Float64}; resd::Ptr{Float64}     # device state [nfld][K][Np]
+    keep::Vector{Any}                                            # host arrays the create call read from
+end
+
+dmalloc(n) = ccall((:esdg_dmalloc, LIB), Ptr{Cvoid}, (Csize_t,), n)
+
+function finish_engine(ctx, K, Np, keep)
+    nfld = Int(ccall((:esdg_num_fields, LIB), Cint, (Ptr{Cvoid},), ctx))
+    nb = ccall((:esdg_workspace_bytes, LIB), Csize_t, (Ptr{Cvoid},), ctx)
+    ws = dmalloc(nb)
+    check(ccall((:esdg_bind_workspace, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), ctx, ws, nb))
+    n = nfld * K * Np * 8
+    e = Engine(ctx, ws, K, Np, nfld, Ptr{Float64}(dmalloc(n)), Ptr{Float64}(dmalloc(n)), Ptr{Float64}(dmalloc(n)), keep)
+    z = zeros(K * Np * nfld)                                    # resQ starts from zero (dg2D_euler_quad.jl:84)
+    check(ccall((:esdg_memcpy_h2d, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Csize_t), e.resd, z, n))
+    e
+end
+
+function destroy!(e::Engine)
+    for p in (e.Qd, e.rhsd, e.resd, e.ws)
+        ccall((:esdg_dfree, LIB), Cint, (Ptr{Cvoid},), p)
+    end
+    ccall((:esdg_destroy, LIB), Cint, (Ptr{Cvoid},), e.ctx)
+    e.ctx = C_NULL
+end
+
+"Euler-quad driver (examples/dg2D_euler_quad.jl, after line 91): Q lives at the Gauss nodes; LF factor .5 (:165)."
+function Engine(rd, md, ops, Ef; lf_scale = 0.5)
+    Qrhskew, Qshskew, _, _, _, Ph, Lf = ops                       # dg2D_euler_quad.jl:91
+    k = Any[dense(Qrhskew), dense(Qshskew), dense(Ph), Vector{Float64}(rd.wq), Vector{Float64}(rd.wf), dense(Ef), dense(Lf)]
+    Nq, Nfq = length(rd.wq), length(rd.wf)
+    o = OpsT(Int32(round(Int, sqrt(Nq)) - 1), Nq, Nq, Nfq, pointer.(k[1:7])...,
+             C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL)
+    m = MeshT(md.K, size(md.rxJ, 1), pointer(md.rxJ), pointer(md.sxJ), pointer(md.ryJ), pointer(md.syJ),
+              pointer(md.J), pointer(md.wJq), pointer(md.nxJ), pointer(md.nyJ), pointer(md.sJ),
+              pointer(md.mapP), C_NULL, 0, C_NULL, 0, md.K, 1, 0, C_NULL, C_NULL)
+    p = PhysT(EULER_COLLOCATED, lf_scale, 1, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+    ctx = Ref{Ptr{Cvoid}}()
+    GC.@preserve k md check(ccall((:esdg_create, LIB), Cint, (Ref{OpsT}, Ref{MeshT}, Ref{PhysT}, Ref{Ptr{Cvoid}}), o, m, p, ctx))
+    finish_engine(ctx[], md.K, Nq, k)
+end
+
+"""
+CNS drivers (dg2D_CNS_cavity_optimized.jl after line 90, dg2D_CNS_convergence_test.jl, dg2D_CNS_modalESDG.jl):
+`ops = (Qrhskew,Qshskew,VhP,Ph,LIFT,Vq)`, Q = LGL nodal values.  Walls: `md.mapB` with `lid[i] = 1` where the node
+lies on the lid (init_BC_funs :139-148) and optionally the lid velocity per mapB entry (`vlid`, convergence_test :76).
+BCTYPE = 4: `md.mapB = [leftwall; rightwall]`, `lid[i] = 1` on the inflow side, `inflow = (rhoL,uL,vL,pL)`,
+`viscous_dissp = false` (dg2D_CNS_modalESDG.jl:161-217).
+"""
+function CnsEngine(rd, md, ops; Re, mu, lambda, Pr, BCTYPE = 1, inviscid_dissp = true, viscous_dissp = true,
+                   lid = nothing, vlid = nothing, inflow = (0.0, 0.0, 0.0, 0.0), lf_scale = 0.25, formulation = CNS_MODAL)
+    Qrhskew, Qshskew, VhP, Ph, LIFT, Vq = ops
+    k = Any[dense(Qrhskew), dense(Qshskew), dense(Ph), Vector{Float64}(rd.wq), Vector{Float64}(rd.wf),
+            dense(Vq), dense(rd.Pq), dense(VhP), dense(LIFT), dense(rd.Vf), dense(rd.Dr), dense(rd.Ds)]
+    Np, Nq, Nfq = size(rd.Pq, 1), length(rd.wq), length(rd.wf)
+    o = OpsT(Int32(round(Int, sqrt(Np)) - 1), Np, Nq, Nfq, pointer(k[1]), pointer(k[2]), pointer(k[3]), pointer(k[4]), pointer(k[5]),
+             C_NULL, C_NULL, pointer(k[6]), pointer(k[7]), pointer(k[8]), pointer(k[9]), pointer(k[10]), pointer(k[11]), pointer(k[12]))
+    mapB = Vector{Int64}(md.mapB)
+    bk = lid === nothing ? UInt8[] : Vector{UInt8}(lid)
+    vl = vlid === nothing ? Float64[] : Vector{Float64}(vlid)
+    push!(k, mapB, bk, vl)
+    m = MeshT(md.K, size(md.rxJ, 1), pointer(md.rxJ), pointer(md.sxJ), pointer(md.ryJ), pointer(md.syJ),
+              pointer(md.J), pointer(md.wJq), pointer(md.nxJ), pointer(md.nyJ), pointer(md.sJ),
+              pointer(md.mapP), isempty(mapB) ? C_NULL : pointer(mapB), length(mapB), isempty(bk) ? C_NULL : pointer(bk),
+              0, md.K, 1, 0, C_NULL, isempty(vl) ? C_NULL : pointer(vl))
+    p = PhysT(formulation, lf_scale, Int32(inviscid_dissp), Int32(viscous_dissp), BCTYPE, Re, mu, lambda, Pr, inflow...)
+    ctx = Ref{Ptr{Cvoid}}()
+    GC.@preserve k md check(ccall((:esdg_create, LIB), Cint, (Ref{OpsT}, Ref{MeshT}, Ref{PhysT}, Ref{Ptr{Cvoid}}), o, m, p, ctx))
+    finish_engine(ctx[], md.K, Np, k)
+end
+
+"dg3D_euler_hex.jl after line 98; lf_scale = the literal 0*.25 of line 193"
+function HexEngine(rd, md, Qrhskew, Qshskew, Qthskew, Ph, Lf, Ef; lf_scale = 0.0)
+    k = Any[dense(Qrhskew), dense(Qshskew), dense(Qthskew), dense(Ph), dense(Lf), dense(Ef),
+            Vector{Float64}(rd.wq), Vector{Float64}(rd.wf)]
+    Nq, Nfq = length(rd.wq), length(rd.wf)
+    o = HexOpsT(Int32(round(Int, cbrt(Nq)) - 1), Nq, Nfq, pointer.(k)...)
+    m = HexMeshT(md.K, size(md.rxJ, 1), pointer.((md.rxJ, md.sxJ, md.txJ, md.ryJ, md.syJ, md.tyJ, md.rzJ, md.szJ, md.tzJ,
+                 md.J, md.wJq, md.nxJ, md.nyJ, md.nzJ, md.sJ))..., pointer(md.mapP), 0, md.K, 1, 0, C_NULL)
+    p = PhysT(EULER_HEX_COLLOCATED, lf_scale, 1, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+    ctx = Ref{Ptr{Cvoid}}()
+    GC.@preserve k md check(ccall((:esdg_create_hex, LIB), Cint, (Ref{HexOpsT}, Ref{HexMeshT}, Ref{PhysT}, Ref{Ptr{Cvoid}}), o, m, p, ctx))
+    finish_engine(ctx[], md.K, Nq, k)
+end
+
+# ---- state movement ------------------------------------------------------------------------------------------
+"upload the driver's Q (tuple/vector of nfld Matrix{Float64}) -- once, before the time loop"
+function upload!(e::Engine, Q)
+    nb = e.K * e.Np * 8
+    for f in 1:e.nfld
+        check(ccall((:esdg_memcpy_h2d, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Csize_t), e.Qd + (f - 1) * nb, Q[f], nb))
+    end
+end
+function download!(Q, e::Engine; from = e.Qd)
+    nb = e.K * e.Np * 8
+    for f in 1:e.nfld
+        check(ccall((:esdg_memcpy_d2h, LIB), Cint, (Ptr{Float64}, Ptr{Cvoid}, Csize_t), Q[f], from + (f - 1) * nb, nb))
+    end
+    Q
+end
+
+# ---- the hot path --------------------------------------------------------------------------------------------
+"device-resident `rhsQ,rhstest = rhs(Q,md,ops,euler_fluxes,compute_rhstest)` (dg2D_euler_quad.jl:141, hex :167): rhs -> e.rhsd"
+function rhs!(e::Engine; compute_rhstest = false)
+    check(ccall((:esdg_rhs, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), e.ctx, e.Qd, e.rhsd, C_NULL))
+    compute_rhstest || return 0.0
+    diag = zeros(2)
+    check(ccall((:esdg_rhstest, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                e.ctx, e.Qd, e.rhsd, diag, C_NULL))
+    diag[1]
+end
+
+"`rhsQ,rhstest,rhstest_visc = rhsRK!(...)` (dg2D_CNS_cavity_optimized.jl:955-972): rhs -> e.rhsd, returns the two scalars"
+function rhsRK!(e::Engine; compute_rhstest = false)
+    rhstest = rhs!(e; compute_rhstest = compute_rhstest)
+    compute_rhstest || return 0.0, 0.0
+    # rhstest_visc = sum(wJq .* v .* rhs_viscous) + visc_test (:962-969): the viscous part alone goes to a scratch buffer
+    scratch = Ptr{Float64}(dmalloc(e.nfld * e.K * e.Np * 8))
+    check(ccall((:esdg_set_parts, LIB), Cint, (Ptr{Cvoid}, Cint), e.ctx, 2))
+    check(ccall((:esdg_rhs, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), e.ctx, e.Qd, scratch, C_NULL))
+    check(ccall((:esdg_set_parts, LIB), Cint, (Ptr{Cvoid}, Cint), e.ctx, 3))
+    d = zeros(2); vt = zeros(1)
+    check(ccall((:esdg_rhstest, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                e.ctx, e.Qd, scratch, d, C_NULL))
+    check(ccall((:esdg_viscous_entropy_test, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), e.ctx, e.Qd, vt, C_NULL))
+    ccall((:esdg_dfree, LIB), Cint, (Ptr{Cvoid},), scratch)
+    rhstest, d[1] + vt[1]
+end
+
+"resQ = a*resQ + dt*rhsQ ; Q += b*resQ  (dg2D_euler_quad.jl:204-205) on the device"
+lsrk!(e::Engine, a, b, dt) = check(ccall((:esdg_lsrk_update, LIB), Cint,
+    (Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble, Cdouble, Int64, Ptr{Cvoid}),
+    e.Qd, e.resd, e.rhsd, a, b, dt, e.nfld * e.K * e.Np, C_NULL))
+
+"RHS fused with the RK stage that consumes it (no rhs array is written)"
+rhs_lsrk!(e::Engine, a, b, dt) = check(ccall((:esdg_rhs_lsrk, LIB), Cint,
+    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble, Cdouble, Ptr{Cvoid}), e.ctx, e.Qd, e.resd, a, b, dt, C_NULL))
+
+"the five stages of dg2D_euler_quad.jl:200-206 in one call"
+lsrk45_step!(e::Engine, dt) = check(ccall((:esdg_lsrk45_step, LIB), Cint,
+    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cdouble, Ptr{Cvoid}), e.ctx, e.Qd, e.resd, dt, C_NULL))
+
+"""
+Stages 2..7 and the Hairer estimate of one DOPRI45 attempt (cavity_optimized.jl:1002-1021).  `k` = 7 device state
+buffers (Ptr{Float64}), k[1] = rhs(Q) on entry (FSAL).  Returns errEst; the candidate state is in `Qtmp`.
+"""
+function dopri45_attempt!(e::Engine, Qtmp::Ptr{Float64}, k::Vector{Ptr{Float64}}, dt; errTol = 1e-5)
+    err = zeros(1)
+    check(ccall((:esdg_dopri45_attempt, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Ptr{Float64}}, Cdouble, Cdouble, Ptr{Float64}, Ptr{Cvoid}),
+                e.ctx, e.Qd, Qtmp, k, dt, errTol, err, C_NULL))
+    err[1]
+end
+dopri45_next_dt(dt, dt0, errEst, prevErrEst, i) =
+    ccall((:esdg_dopri45_next_dt, LIB), Cdouble, (Cdouble, Cdouble, Cdouble, Cdouble, Int64), dt, dt0, errEst, prevErrEst, i)
+
+# ---- error blocks of the scripts (INTEGRATION.md section 2c) ----------------------------------------------------
+"Vq2: (Nq2 x Np) state nodes -> error quadrature (fold Pq in when Q lives at the Gauss nodes); x, y, J at the state's nodes"
+function setup_errors!(e::Engine, x, y, J; Vq2 = nothing, wq2 = nothing, Vf = nothing, wf = nothing)
+    k = Any[dense(x), dense(y), dense(J)]
+    pv(a) = a === nothing ? Ptr{Float64}(C_NULL) : (push!(k, Array{Float64}(a)); pointer(k[end]))
+    o = ErrOpsT(Vq2 === nothing ? 0 : size(Vq2, 1), pv(Vq2), pv(wq2), pointer(k[1]), pointer(k[2]), pointer(k[3]), pv(Vf), pv(wf))
+    GC.@preserve k check(ccall((:esdg_error_setup, LIB), Cint, (Ptr{Cvoid}, Ref{ErrOpsT}), e.ctx, o))
+end
+function l2_error(e::Engine, t; exact = EXACT_VORTEX, par = nothing)
+    out = zeros(5)
+    check(ccall((:esdg_error_l2, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}, Cdouble, Ptr{Float64}, Ptr{Cvoid}),
+                e.ctx, e.Qd, exact, par === nothing ? C_NULL : Vector{Float64}(par), t, out, C_NULL))
+    out[1]
+end
+"(L1err, Linferr) of dg2D_CNS_modalESDG.jl:745-771; par = [v_0, v_1, v_01, m_0, kappa/m_0/cv, v_inf]"
+function nodal_error(e::Engine, t, par; exact = EXACT_BECKER)
+    out = zeros(14)
+    check(ccall((:esdg_error_nodal, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}, Cdouble, Ptr{Float64}, Ptr{Cvoid}),
+                e.ctx, e.Qd, exact, Vector{Float64}(par), t, out, C_NULL))
+    out[1], out[2]
+end
+"err of dg2D_CNS_convergence_test.jl:1055-1080: (as the script executes it, with all three terms)"
+function boundary_velocity_error(e::Engine, Jf)
+    out = zeros(5)
+    check(ccall((:esdg_error_boundary_velocity, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cdouble, Ptr{Float64}, Ptr{Cvoid}),
+                e.ctx, e.Qd, Jf, out, C_NULL))
+    out[1], out[2]
+end
+
+# ---- literal drop-in with host arrays (PCIe-bound; validation only) -------------------------------------------
+"`rhs(Q, md, ops, flux_fun, compute_rhstest)` of the Euler drivers with an engine in place of (md, ops): returns (rhsQ, rhstest)"
+function rhs(e::Engine, Q, flux_fun = nothing, compute_rhstest = false)
+    out = [similar(Q[1]) for _ in 1:e.nfld]
+    qp, op = pointer.(collect(Q)), pointer.(out)
+    GC.@preserve Q out check(ccall((:esdg_rhs_host, LIB), Cint, (Ptr{Cvoid}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}), e.ctx, qp, op))
+    rhstest = 0.0
+    if compute_rhstest
+        upload!(e, Q)
+        rhstest = rhs!(e; compute_rhstest = true)
+    end
+    Tuple(out), rhstest
+end
+
+end # module

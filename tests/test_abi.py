@@ -55,3 +55,48 @@ def test_error_codes_and_messages():
     plan = C.c_void_p()
     rc = L.esdg_halo_plan_create(None, 4, 8, 0, 4, 1, None, C.byref(plan))
     assert rc == -1 and b"bad halo plan" in L.esdg_last_error()
+
+
+def test_struct_layouts_match_the_library():
+    """ctypes mirrors of the public structs have the library's sizes (checked again at every load), and their field
+    offsets follow the natural C layout of the header's declaration order."""
+    from esdg_cns_amd import _lib
+    L = _lib.lib()
+    for st in (_lib.esdg_ops_t, _lib.esdg_mesh_t, _lib.esdg_phys_t, _lib.esdg_hex_ops_t, _lib.esdg_hex_mesh_t, _lib.esdg_err_ops_t):
+        assert L.esdg_abi_sizeof(st.__name__.encode()) == C.sizeof(st), st.__name__
+    assert L.esdg_abi_sizeof(b"no_such_struct") == -1
+    # field names and order of the header == those of the binding
+    src = open(os.path.join(ROOT, "include", "esdg_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    for st in (_lib.esdg_ops_t, _lib.esdg_mesh_t, _lib.esdg_phys_t, _lib.esdg_hex_ops_t, _lib.esdg_hex_mesh_t, _lib.esdg_err_ops_t):
+        end = src.index("} " + st.__name__ + ";")
+        body = src[src.rindex("typedef struct {", 0, end) + len("typedef struct {"):end]
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                names.append(re.sub(r"[\*\s]", " ", part).split()[-1])
+        mine = [f[0].rstrip("_") for f in st._fields_]
+        assert names == mine, (st.__name__, names, mine)
+
+
+def test_julia_shim_mirrors_the_header():
+    """julia/ESDGHip.jl cannot be run here (no Julia in the pipeline); what can be checked statically is: its struct
+    mirrors list the header's fields in the header's order with matching widths, and every symbol it ccalls is declared
+    in include/esdg_hip.h."""
+    from esdg_cns_amd import _lib
+    jl = open(os.path.join(ROOT, "julia", "ESDGHip.jl")).read()
+    pairs = {"OpsT": _lib.esdg_ops_t, "MeshT": _lib.esdg_mesh_t, "PhysT": _lib.esdg_phys_t, "HexOpsT": _lib.esdg_hex_ops_t,
+             "HexMeshT": _lib.esdg_hex_mesh_t, "ErrOpsT": _lib.esdg_err_ops_t}
+    width = {"Int32": 4, "Int64": 8, "Float64": 8}
+    for name, st in pairs.items():
+        body = re.search(r"^struct " + name + r"\n(.*?)^end", jl, flags=re.S | re.M).group(1)
+        fields = re.findall(r"([A-Za-z_0-9]+)::([A-Za-z0-9{}]+)", body)
+        assert [f for f, _ in fields] == [f[0].rstrip("_") for f in st._fields_], name
+        for (f, t), cf in zip(fields, st._fields_):
+            size = 8 if t.startswith("Ptr{") else width[t]
+            assert size == C.sizeof(cf[1]), (name, f, t)
+    called = set(re.findall(r"\(:(esdg_[a-z0-9_]+), LIB\)", jl))
+    assert len(called) > 20 and called <= set(_declared_functions()), called - set(_declared_functions())
