@@ -42,6 +42,8 @@ class HaloExchanger:
         self._backend = None
 
     def start(self, ws_bytes, xch):
+        """Post the sends/receives of exchange `xch` (an index or a list of indices: exchanges produced by the same phase
+        go out as ONE batch, i.e. one RCCL group call).  Returns a token for wait()."""
         import torch.distributed as dist
         if self._backend is None:
             self._backend = dist.get_backend(self.group)
@@ -49,26 +51,31 @@ class HaloExchanger:
         if staged:
             torch.cuda.current_stream(ws_bytes.device).synchronize()
         ops, copies = [], []
-        for peer, so, sb, ro, rb in self.segments[xch]:
-            if rb:
-                dst = ws_bytes[ro:ro + rb]
-                buf = torch.empty(rb, dtype=torch.uint8) if staged else dst
-                if staged:
-                    copies.append((dst, buf))
-                ops.append(dist.P2POp(dist.irecv, buf, peer, self.group))
-            if sb:
-                src = ws_bytes[so:so + sb]
-                ops.append(dist.P2POp(dist.isend, src.cpu() if staged else src, peer, self.group))
+        for x in ([xch] if isinstance(xch, int) else list(xch)):
+            for peer, so, sb, ro, rb in self.segments[x]:
+                if rb:
+                    dst = ws_bytes[ro:ro + rb]
+                    buf = torch.empty(rb, dtype=torch.uint8) if staged else dst
+                    if staged:
+                        copies.append((dst, buf))
+                    ops.append(dist.P2POp(dist.irecv, buf, peer, self.group))
+                if sb:
+                    src = ws_bytes[so:so + sb]
+                    ops.append(dist.P2POp(dist.isend, src.cpu() if staged else src, peer, self.group))
         works = dist.batch_isend_irecv(ops) if ops else []
-        return (works, copies)
+        return [works, copies, False]
 
     @staticmethod
     def wait(pending):
-        works, copies = pending
+        """Idempotent: exchanges posted in one batch share their token."""
+        if pending[2]:
+            return
+        works, copies = pending[0], pending[1]
         for w in works:
             w.wait()
         for dst, buf in copies:
             dst.copy_(buf)
+        pending[2] = True
 
 
 class RhsEngine:
@@ -307,8 +314,10 @@ class RhsEngine:
                 ranged(ph, hi, self.K - hi)
                 for x in outgoing:
                     check(L.esdg_halo_pack(ctx, x, self._stream()))
-            for x in outgoing:
-                pending[x] = self.halo.start(self.ws, x)
+            if outgoing:                                         # one batch (one RCCL group) per producing phase
+                tok = self.halo.start(self.ws, outgoing)
+                for x in outgoing:
+                    pending[x] = tok
             if overlap and ph == 0:
                 ranged(ph, lo, hi - lo)                          # interior of phase 0 overlaps the first exchange
 
