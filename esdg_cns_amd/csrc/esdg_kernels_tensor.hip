@@ -733,7 +733,7 @@ __global__ __launch_bounds__((WgR<N1, VISC>::TPB)) void kt_rhs(TensorTables TT, 
   using LD = RhsLds<N1, VISC>;
   constexpr int Nq = LD::Nq, Nfq = LD::Nfq, Nh = LD::Nh, E = LD::E, NF = N1 / 2;
   constexpr int NFULL = (N1 - 1) / 2;   // full circulant rounds per direction (the antipodal round of even N1 is separate)
-  constexpr int UNR_K = VISC ? (NFULL > 0 ? NFULL : 1) : 1, UNR_T = VISC ? 2 : 1;
+  constexpr int UNR_K = VISC ? (NFULL > 0 ? NFULL : 1) : 1, UNR_T = VISC ? 2 : 1, UNR_D = N1 <= 4 ? 2 : 1;
   constexpr TensorLayout L(N1);
   __shared__ double sTab[L.NDBL];
   __shared__ int sInt[L.NINT];
@@ -880,7 +880,7 @@ __global__ __launch_bounds__((WgR<N1, VISC>::TPB)) void kt_rhs(TensorTables TT, 
   // ---- flux differencing along the tensor lines (sparse_hadamard_sum :102-138 / flux_differencing! :326-348)
   double acc[4] = {0, 0, 0, 0};
   if (ln.vin && inviscid && !(ph.dbg & 1)) {
-#pragma unroll 1
+#pragma unroll UNR_D   // both directions inlined up to N1 = 4 (N=3: -1 %); from N1 = 5 it costs the viscous kernel an occupancy step (+5 %)
     for (int d = 0; d < 2; ++d) {
       const int op = d == 0 ? TT.op0 : TT.op1;
       const double gx = 2 * g[op], gy = 2 * g[2 + op];
