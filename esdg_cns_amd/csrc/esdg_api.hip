@@ -459,7 +459,7 @@ struct esdg_ctx {
   // device storage
   DevBuf d_pair_ij, d_pair_c, d_inc_ptr, d_inc, d_Ef_i, d_Ef_v, d_Ph_i, d_Ph_v, d_Lf_i, d_Lf_v, d_Dr_i, d_Dr_v, d_Ds_i,
       d_Ds_v, d_Vq, d_Pq, d_geo, d_mapP, d_bc, d_vlid, d_wJq, d_sendlist, d_partial;
-  DevBuf t_dbl, t_int, d_stamps, d_G9, d_Jq, d_nrm;
+  DevBuf t_dbl, t_int, d_G9, d_Jq, d_nrm;
   DevBuf e_Vq2, e_wq2, e_x, e_y, e_J, e_Vf, e_wf;   // error functionals (esdg_error_setup)
   ErrDev E{};
   bool have_err = false;
@@ -764,12 +764,6 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   c->M.vlid = vlid.empty() ? nullptr : c->d_vlid.as<double>();
   set_interior(c, pl.mapP, K, Nfq);
   c->M.wJq = mesh->wJq ? c->d_wJq.as<double>() : nullptr;
-  c->M.stamps = nullptr;
-  if (c->ph.dbg & 8) {
-    if ((rc = c->d_stamps.alloc(4096 * 16 * 8)) != 0) return rc;
-    HIP_TRY(hipMemset(c->d_stamps.p, 0, 4096 * 16 * 8));
-    c->M.stamps = static_cast<unsigned long long*>(c->d_stamps.p);
-  }
 
   // ---- workspace layout ---------------------------------------------------------------------
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -933,7 +927,6 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
   c->M.nrm = curved ? c->d_nrm.as<double>() : nullptr;
   set_interior(c, pl.mapP, K, Nfq);
   c->M.wJq = mesh->wJq ? c->d_wJq.as<double>() : nullptr;
-  c->M.stamps = nullptr;
 
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t nodes = (size_t)(K * Nfq + c->nghost);
@@ -1314,12 +1307,6 @@ int esdg_debug_log(const double* x_dev, double* y_dev, int64_t n, void* stream) 
   return ESDG_OK;
 }
 
-/* diagnostic: read back the s_memtime section stamps (ESDG_DBG & 8) */
-int esdg_debug_stamps(esdg_ctx* ctx, unsigned long long* out, int n) {
-  if (!ctx || !ctx->M.stamps || n > 4096 * 16) return fail(ESDG_ERR_STATE, "stamps not enabled");
-  HIP_TRY(hipMemcpy(out, ctx->M.stamps, (size_t)n * 8, hipMemcpyDeviceToHost));
-  return ESDG_OK;
-}
 
 // ---- halo plan -------------------------------------------------------------------------------
 int esdg_halo_num_neighbors(const esdg_ctx* ctx) { return ctx ? (int)ctx->nbr_rank.size() : 0; }

@@ -72,7 +72,6 @@ struct MeshDev {
   const double* G9;
   const double* Jq;
   const double* nrm;
-  unsigned long long* stamps;  // diagnostic builds only (ESDG_DBG & 8): [4096][16] s_memtime deltas
 };
 
 // optional fusion of the low-storage RK update into the last phase (esdg_rhs_lsrk):
@@ -88,7 +87,8 @@ struct Phys {
   double lf_scale;
   int inviscid_dissp, viscous_dissp, BCTYPE;
   double Re, mu, lambda, Pr;
-  int dbg;  // timing-ablation mask from ESDG_DBG (diagnostic builds only; 0 in normal use)
+  int dbg;  // timing-ablation mask from the ESDG_DBG environment variable (1: skip the volume flux differencing, 2: skip the
+            // viscous stage, 16: hex workgroup remap off); 0 in normal use
   double inflow_q[6];   // BCTYPE 4: Dirichlet state as a trace record (rho,u,v,beta,log rho,log beta)
   double inflow_vv[3];  //           and its entropy variables (v2,v3,v4) = v_ufun(...)[2:4]
   int parts;  // bit 0: inviscid terms (rhs_inviscid!), bit 1: viscous terms (rhs_viscous!); 3 = rhsRK!
