@@ -621,7 +621,10 @@ __device__ __forceinline__ void face_normal_stress(const LN& ln, const double* s
 // phase 1 (CNS): sigma = K(v) grad v, normal stress traces -> B
 // ---------------------------------------------------------------------------------------------
 // DIAG: also reduce visc_test = sum(wJq .* (VUx .* sigma_x + VUy .* sigma_y)) (rhs_viscous! :802-806) per workgroup
-template <int N1, bool DIAG>
+// DIVV (meshes without walls): instead of sigma itself, store the volume part of its divergence,
+//   (rxJ Dr + sxJ Ds) sigma_x + (ryJ Dr + syJ Ds) sigma_y   (3 numbers per node instead of 6),
+// which is all the last phase needs of sigma at the nodes (its face part comes from the normal-stress traces B)
+template <int N1, bool DIAG, bool DIVV>
 __global__ __launch_bounds__(WgS<N1>::TPB) void kt_sigma(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                const double* __restrict__ A_U, double* __restrict__ B,
                                                double* __restrict__ SG, double* __restrict__ vt_partial) {
@@ -681,7 +684,7 @@ __global__ __launch_bounds__(WgS<N1>::TPB) void kt_sigma(TensorTables TT, MeshDe
     r[0] = make_double2(sgx[0], sgx[1]);
     r[1] = make_double2(sgx[2], sgy[0]);
     r[2] = make_double2(sgy[1], sgy[2]);
-    if (vactive) {   // sigma at the Gauss nodes, kept for the divergence in the last phase: SG[6][K][Nq], coalesced
+    if (!DIVV && vactive) {   // sigma at the Gauss nodes, kept for the divergence in the last phase: SG[6][K][Nq], coalesced
       const int64_t n = e0 * Nq + ln.tid, KN = M.K * Nq;
       SG[n] = sgx[0]; SG[KN + n] = sgx[1]; SG[2 * KN + n] = sgx[2];
       SG[3 * KN + n] = sgy[0]; SG[4 * KN + n] = sgy[1]; SG[5 * KN + n] = sgy[2];
@@ -690,6 +693,30 @@ __global__ __launch_bounds__(WgS<N1>::TPB) void kt_sigma(TensorTables TT, MeshDe
       vt = M.wJq[(e0 + ln.ev) * Nq + ln.q] * (gx[0] * sgx[0] + gx[1] * sgx[1] + gx[2] * sgx[2] + gy[0] * sgy[0] + gy[1] * sgy[1] + gy[2] * sgy[2]);
   }
   __syncthreads();
+  if (DIVV && ln.vin) {   // volume part of div sigma (dg_div! :590-611 without the lift), from sigma in LDS
+    const double* g = M.geo + (e0s + (vactive ? ln.ev : 0)) * GEO_STRIDE;
+    double dv[3] = {0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int op = d == 0 ? TT.op0 : TT.op1;
+      const double gx = g[op], gy = g[2 + op];
+      const int pos = ln.pos(d), oth = ln.oth(d);
+#pragma unroll
+      for (int j = 0; j < N1; ++j) {
+        const double w = sTab[L.DG + (d * N1 + pos) * N1 + j];
+        const double2* r = reinterpret_cast<const double2*>(sB + (ln.ev * Nq + (d == 0 ? j + N1 * oth : oth + N1 * j)) * 6);
+        const double2 s0 = r[0], s1 = r[1], s2 = r[2];
+        const double wx = w * gx, wy = w * gy;
+        dv[0] += wx * s0.x + wy * s1.y;
+        dv[1] += wx * s0.y + wy * s2.x;
+        dv[2] += wx * s1.x + wy * s2.y;
+      }
+    }
+    if (vactive) {   // SG[3][K][Nq], coalesced
+      const int64_t n = e0 * Nq + ln.tid, KN = M.K * Nq;
+      SG[n] = dv[0]; SG[KN + n] = dv[1]; SG[2 * KN + n] = dv[2];
+    }
+  }
   if (factive) {
     const double* gn = M.geo + (e0 + ln.ef) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
     double sn[3], fx[3], fy[3];
@@ -1000,19 +1027,25 @@ __global__ __launch_bounds__((WgR<N1, VISC>::TPB)) void kt_rhs(TensorTables TT, 
     // sigma = K(v) grad v at the Gauss nodes was computed (and its face traces exchanged) by phase 1: reload it
     // instead of recomputing gradient and stress (HBM has headroom here, the LDS does not)
     double* sSj = sR2;                       // [E][3][Nfq]  stress jump (+ J * penalty, see below)
-    double* sS = sQh;                        // [E][Nq][6]   in the dead primitive region
-    double2 sg0 = make_double2(0, 0), sg1 = sg0, sg2 = sg0;
-    if (vactive) {
+    double* sS = sQh;                        // [E][Nq][6]   in the dead primitive region (WALLS only)
+    double dv[3] = {0, 0, 0};                // divergence of sigma at this node
+    if (WALLS) {   // sigma itself: the wall closures need its face values split into x and y parts
+      double2 sg0 = make_double2(0, 0), sg1 = sg0, sg2 = sg0;
+      if (vactive) {
+        const int64_t n = e0 * Nq + ln.tid, KN = M.K * Nq;
+        sg0 = make_double2(SG[n], SG[KN + n]);
+        sg1 = make_double2(SG[2 * KN + n], SG[3 * KN + n]);
+        sg2 = make_double2(SG[4 * KN + n], SG[5 * KN + n]);
+      }
+      if (ln.vin) {
+        double2* r = reinterpret_cast<double2*>(sS + (ln.ev * Nq + ln.q) * 6);
+        r[0] = sg0; r[1] = sg1; r[2] = sg2;
+      }
+      __syncthreads();
+    } else if (vactive) {   // phase 1 stored the volume part of the divergence (kt_sigma<.., DIVV>)
       const int64_t n = e0 * Nq + ln.tid, KN = M.K * Nq;
-      sg0 = make_double2(SG[n], SG[KN + n]);
-      sg1 = make_double2(SG[2 * KN + n], SG[3 * KN + n]);
-      sg2 = make_double2(SG[4 * KN + n], SG[5 * KN + n]);
+      dv[0] = SG[n]; dv[1] = SG[KN + n]; dv[2] = SG[2 * KN + n];
     }
-    if (ln.vin) {
-      double2* r = reinterpret_cast<double2*>(sS + (ln.ev * Nq + ln.q) * 6);
-      r[0] = sg0; r[1] = sg1; r[2] = sg2;
-    }
-    __syncthreads();
     // stress jumps .5*((sxP-sxf)*nxJ + (syP-syf)*nyJ): the neighbour's normal stress from B carries
     // its own outward normal = minus ours (dg_div! :606)
     if (ln.fin) {
@@ -1052,14 +1085,13 @@ __global__ __launch_bounds__((WgR<N1, VISC>::TPB)) void kt_rhs(TensorTables TT, 
     __syncthreads();
     // divergence + penalty (dg_div! :590-611, penalty :817-845: NOT scaled by 1/J, quirk Q3)
     if (ln.vin) {
-      double dv[3] = {0, 0, 0};
 #pragma unroll 1
       for (int d = 0; d < 2; ++d) {
         const int op = d == 0 ? TT.op0 : TT.op1;
         const double gx = g[op], gy = g[2 + op];
         const int pos = ln.pos(d), oth = ln.oth(d);
 #pragma unroll 1
-        for (int j = 0; j < N1; ++j) {
+        for (int j = 0; WALLS && j < N1; ++j) {
           const double w = sTab[L.DG + (d * N1 + pos) * N1 + j];
           const double2* r = reinterpret_cast<const double2*>(sS + (ln.ev * Nq + (d == 0 ? j + N1 * oth : oth + N1 * j)) * 6);
           const double2 s0 = r[0], s1 = r[1], s2 = r[2];
@@ -1144,10 +1176,15 @@ int launch_sigma_tensor(int N1v, const TensorTables& TT, const MeshDev& M, const
     constexpr int EPB = W::EPB;
     constexpr int TPB = W::TPB;
     const int nb = (int)((M.e_count + EPB - 1) / EPB);
-    if (vt_partial)
-      hipLaunchKernelGGL((kt_sigma<N1, true>), dim3(nb), dim3(TPB), 0, s, TT, M, ph, Q, A_U, B, SG, vt_partial);
+    const bool divv = M.bc == nullptr;   // must match WALLS of launch_rhs_tensor: kt_rhs<.., WALLS = false> reads the divergence form
+    if (vt_partial && divv)
+      hipLaunchKernelGGL((kt_sigma<N1, true, true>), dim3(nb), dim3(TPB), 0, s, TT, M, ph, Q, A_U, B, SG, vt_partial);
+    else if (vt_partial)
+      hipLaunchKernelGGL((kt_sigma<N1, true, false>), dim3(nb), dim3(TPB), 0, s, TT, M, ph, Q, A_U, B, SG, vt_partial);
+    else if (divv)
+      hipLaunchKernelGGL((kt_sigma<N1, false, true>), dim3(nb), dim3(TPB), 0, s, TT, M, ph, Q, A_U, B, SG, vt_partial);
     else
-      hipLaunchKernelGGL((kt_sigma<N1, false>), dim3(nb), dim3(TPB), 0, s, TT, M, ph, Q, A_U, B, SG, vt_partial);
+      hipLaunchKernelGGL((kt_sigma<N1, false, false>), dim3(nb), dim3(TPB), 0, s, TT, M, ph, Q, A_U, B, SG, vt_partial);
   });
   return (int)hipGetLastError();
 }
