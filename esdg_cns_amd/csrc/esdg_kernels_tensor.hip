@@ -696,12 +696,12 @@ __global__ __launch_bounds__(WgS<N1>::TPB) void kt_sigma(TensorTables TT, MeshDe
   if (DIVV && ln.vin) {   // volume part of div sigma (dg_div! :590-611 without the lift), from sigma in LDS
     const double* g = M.geo + (e0s + (vactive ? ln.ev : 0)) * GEO_STRIDE;
     double dv[3] = {0, 0, 0};
-#pragma unroll
+#pragma unroll 1   // rolled: unrolled, the hoisted LDS reads cost 30-60 VGPRs and two occupancy steps (+3 % per RHS)
     for (int d = 0; d < 2; ++d) {
       const int op = d == 0 ? TT.op0 : TT.op1;
       const double gx = g[op], gy = g[2 + op];
       const int pos = ln.pos(d), oth = ln.oth(d);
-#pragma unroll
+#pragma unroll 1
       for (int j = 0; j < N1; ++j) {
         const double w = sTab[L.DG + (d * N1 + pos) * N1 + j];
         const double2* r = reinterpret_cast<const double2*>(sB + (ln.ev * Nq + (d == 0 ? j + N1 * oth : oth + N1 * j)) * 6);
