@@ -701,10 +701,13 @@ __global__ __launch_bounds__(WgS<N1>::TPB) void kt_sigma(TensorTables TT, MeshDe
       const int op = d == 0 ? TT.op0 : TT.op1;
       const double gx = g[op], gy = g[2 + op];
       const int pos = ln.pos(d), oth = ln.oth(d);
+      // walk the tensor line with pointer steps (no index arithmetic in the loop)
+      const double* wp = sTab + L.DG + (d * N1 + pos) * N1;
+      const double2* r = reinterpret_cast<const double2*>(sB + (ln.ev * Nq + (d == 0 ? N1 * oth : oth)) * 6);
+      const int step = d == 0 ? 3 : 3 * N1;   // in double2
 #pragma unroll 1
-      for (int j = 0; j < N1; ++j) {
-        const double w = sTab[L.DG + (d * N1 + pos) * N1 + j];
-        const double2* r = reinterpret_cast<const double2*>(sB + (ln.ev * Nq + (d == 0 ? j + N1 * oth : oth + N1 * j)) * 6);
+      for (int j = 0; j < N1; ++j, r += step) {
+        const double w = wp[j];
         const double2 s0 = r[0], s1 = r[1], s2 = r[2];
         const double wx = w * gx, wy = w * gy;
         dv[0] += wx * s0.x + wy * s1.y;
