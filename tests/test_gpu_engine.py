@@ -116,6 +116,39 @@ def test_full_size_properties_cns_512(E):
     assert abs(ec.rhstest(Qd, r2)) < 1e-9                            # entropy conservative without LF
 
 
+@pytest.mark.parametrize("form,N,Kx,Ky", [("cns", 4, 9, 7), ("cns", 3, 7, 6), ("cns", 5, 5, 5), ("cns", 2, 8, 5), ("euler", 4, 9, 7),
+                                          ("euler", 6, 4, 4)])
+def test_ranged_launches_match_the_full_launch(E, form, N, Kx, Ky):
+    """esdg_rhs_phase_range (what the halo-overlap schedule is built from): every phase run piecewise over an uneven
+    partition of the elements, pieces in arbitrary order, must equal the one-launch evaluation.  Pieces start at arbitrary
+    elements, so elements land in different lanes / groups than in the full launch: bit-equal where an element's lanes
+    share one wave, equal to round-off where the group mapping lets elements straddle waves."""
+    build = product_euler_problem if form == "euler" else product_cns_problem
+    code = E.EULER_COLLOCATED if form == "euler" else E.CNS_MODAL
+    rd, md, ops, Q = build(N, Kx, Ky)
+    eng = E.RhsEngine(rd, md, ops, code)
+    Qd = eng.upload(Q)
+    ref = eng.rhs(Qd).clone()
+    K = Kx * Ky
+    rng = np.random.default_rng(K + N)
+    cuts = sorted(set([0, K] + [int(c) for c in rng.integers(1, K, size=4)]))
+    pieces = [(a, b - a) for a, b in zip(cuts[:-1], cuts[1:])]
+    out = torch.full_like(Qd, float("nan"))
+    for ph in range(eng.nphases):
+        for i in rng.permutation(len(pieces)):
+            e0, n = pieces[i]
+            E.check(eng.L.esdg_rhs_phase_range(eng.ctx, ph, e0, n, C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    rel = float((out - ref).abs().max() / ref.abs().max())
+    print(f"ranged {form} N={N}: pieces {pieces}, max rel diff {rel:.2e}")
+    assert rel <= 1e-13
+    if N in (2, 3) or (form == "euler" and N == 4):      # one-wave groups: the arithmetic does not depend on the slot
+        assert torch.equal(out, ref)
+    with pytest.raises(Exception):                        # a range past the mesh is refused
+        E.check(eng.L.esdg_rhs_phase_range(eng.ctx, 0, K - 1, 2, C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr()), None))
+
+
 def test_trailing_idle_waves_read_no_geometry_past_the_mesh(E):
     """N=2 at 512x512: 262144 elements are not a multiple of the 20 elements a workgroup takes, so the last workgroup
     has waves without elements.  Their lanes used to form geometry addresses from an element index past the mesh
