@@ -85,7 +85,7 @@ def shocktube_errors(Q, md, T, par):
     rho, rhou, _, E = Q
     Linferr = (np.max(np.abs(ex[0] - rho)) / np.max(np.abs(rho)) + np.max(np.abs(ex[1] - rhou)) / np.max(np.abs(rhou))
                + np.max(np.abs(ex[3] - E)) / np.max(np.abs(E)))
-    J = md.J.flatten(order="F")[0]      # "J = J[1] # TODO: assume uniform mesh"
+    J = md.J.flatten(order="F")[0]      # the script takes the first entry of J: it assumes a uniform mesh (:767)
     L1err = (np.sum(J * np.abs(ex[0] - rho)) / np.sum(J * np.abs(rho)) + np.sum(J * np.abs(ex[1] - rhou)) / np.sum(J * np.abs(rhou))
              + np.sum(J * np.abs(ex[3] - E)) / np.sum(J * np.abs(E)))
     return L1err, Linferr
