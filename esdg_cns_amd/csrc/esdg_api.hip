@@ -556,6 +556,8 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   c->ph.viscous_dissp = phys->viscous_dissp;
   c->ph.BCTYPE = phys->BCTYPE;
   c->ph.Re = phys->Re; c->ph.mu = phys->mu; c->ph.lambda = phys->lambda; c->ph.Pr = phys->Pr;
+  c->ph.kappa = phys->Pr != 0.0 ? 1.4 * phys->mu / phys->Pr : 0.0;
+  c->ph.inv_Re = phys->Re != 0.0 ? 1.0 / phys->Re : 0.0;
   for (double& x : c->ph.inflow_q) x = 1.0;
   for (double& x : c->ph.inflow_vv) x = 0.0;
   if (phys->BCTYPE == 4 && mesh->NmapB > 0) {   // Dirichlet state and VL = v_ufun(rhoL, rhoL uL, rhoL vL, EL) (modalESDG.jl:187-188)
@@ -830,6 +832,7 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
   c->ph.lf_scale = phys->lf_scale;
   c->ph.inviscid_dissp = 1; c->ph.viscous_dissp = 0; c->ph.BCTYPE = 0;
   c->ph.Re = c->ph.mu = c->ph.lambda = c->ph.Pr = 0.0;
+  c->ph.kappa = c->ph.inv_Re = 0.0;
   c->ph.dbg = 0;
   c->ph.parts = 3;
   if (const char* env = getenv("ESDG_DBG")) c->ph.dbg = atoi(env);

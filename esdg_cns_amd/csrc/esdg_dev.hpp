@@ -87,6 +87,7 @@ struct Phys {
   double lf_scale;
   int inviscid_dissp, viscous_dissp, BCTYPE;
   double Re, mu, lambda, Pr;
+  double kappa, inv_Re;   // 1.4*mu/Pr and 1/Re, computed once on the host (a per-lane fp64 division costs ~15 instructions)
   int dbg;  // timing-ablation mask from the ESDG_DBG environment variable (1: skip the volume flux differencing, 2: skip the
             // viscous stage, 16: hex workgroup remap off); 0 in normal use
   double inflow_q[6];   // BCTYPE 4: Dirichlet state as a trace record (rho,u,v,beta,log rho,log beta)

@@ -504,7 +504,7 @@ __device__ __forceinline__ void face_jump_and_penalty(const double* vf, const do
   for (int c = 0; c < 3; ++c) dV[c] = vP[c] - vf[c];
   if (pn_out) {
     const double iv4 = rcp_refined(vf[2]);
-    const double tau = -iv4 / ph.Re;
+    const double tau = -iv4 * ph.inv_Re;
     pn_out[0] = tau * dV[0]; pn_out[1] = tau * dV[1]; pn_out[2] = tau * dV[2];
     if (bc) {   // :827-837
       const double a2 = .5 * (vP[0] + vf[0]), a3 = .5 * (vP[1] + vf[1]);
@@ -587,7 +587,7 @@ __device__ __forceinline__ void visc_sigma(const LN& ln, const double* sTab, con
   for (int c = 0; c < 3; ++c) { tx[c] *= iJ; ty[c] *= iJ; }
   const double* r = sVn + ln.ev * 3 * Nq + ln.q;
   const double v[3] = {r[0], r[Nq], r[2 * Nq]};
-  viscous_stress(v, tx, ty, -ph.lambda, ph.mu, 1.4 * ph.mu / ph.Pr, sgx, sgy);
+  viscous_stress(v, tx, ty, -ph.lambda, ph.mu, ph.kappa, sgx, sgy);
   if (gradx) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) { gradx[c] = tx[c]; grady[c] = ty[c]; }
