@@ -27,7 +27,7 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 lr = int(os.environ.get("LOCAL_RANK", "0"))
 torch.cuda.set_device(lr % torch.cuda.device_count())
 if args.backend == "nccl":
-    dist.init_process_group("nccl", device_id=torch.device("cuda", lr))
+    dist.init_process_group("nccl", device_id=torch.device("cuda", lr % torch.cuda.device_count()))
 else:
     dist.init_process_group(args.backend)
 
