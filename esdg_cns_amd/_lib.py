@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libesdg_hip.so")
+# ESDG_HIP_LIB: another build of the same library (A/B variants under esdg_cns_amd/variants/, tools/); default in-tree
+LIB_PATH = os.environ.get("ESDG_HIP_LIB") or os.path.join(_HERE, "libesdg_hip.so")
 
 c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)
@@ -86,6 +87,14 @@ SYMBOLS = {
     "esdg_rhs_phase_range": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int64, _vp, _vp, _vp]),
     "esdg_rhs_phase_range_lsrk": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int64, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp]),
     "esdg_halo_pack": (C.c_int, [_vp, C.c_int, _vp]),
+    "esdg_comm_unique_id": (C.c_int, [_vp]),
+    "esdg_comm_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "esdg_comm_set_loopback": (C.c_int, [_vp, C.c_int]),
+    "esdg_comm_size": (C.c_int, [_vp]),
+    "esdg_comm_destroy": (C.c_int, [_vp]),
+    "esdg_halo_exchange": (C.c_int, [_vp, C.c_int, _vp]),
+    "esdg_halo_wait": (C.c_int, [_vp, C.c_int, _vp]),
+    "esdg_comm_allreduce": (C.c_int, [_vp, c_double_p, C.c_int, C.c_int, _vp]),
     "esdg_halo_plan_create": (C.c_int, [c_int64_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, c_int64_p, C.POINTER(_vp)]),
     "esdg_halo_plan_destroy": (C.c_int, [_vp]),
     "esdg_halo_plan_num_neighbors": (C.c_int, [_vp]),
@@ -118,6 +127,7 @@ SYMBOLS = {
     "esdg_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
     "esdg_device_synchronize": (C.c_int, []),
     "esdg_device_count": (C.c_int, []),
+    "esdg_set_device": (C.c_int, [C.c_int]),
 }
 
 _LIB = None

@@ -5,7 +5,12 @@
 namespace esdg {
 namespace devmath {
 
+// Accuracy-attribution builds (tools/parity_truth.py): -DESDG_IEEE_DIV makes every quotient an
+// IEEE division, -DESDG_LIBM_LOG uses the device library's log; neither is a product configuration.
 __device__ __forceinline__ double rcp_refined(double x) {
+#ifdef ESDG_IEEE_DIV
+  return 1.0 / x;
+#endif
   double r = __builtin_amdgcn_rcp(x);
   double e = __builtin_fma(-x, r, 1.0);
   r = __builtin_fma(r, e, r);
@@ -18,6 +23,9 @@ __device__ __forceinline__ double rcp_refined(double x) {
 // v_rcp_f64: ~40 VALU instructions instead of the ~100 of the device-library log (its double-double
 // path).  Five logs per face/volume lane made the library log 2/3 of the phase-0 kernel.
 __device__ __forceinline__ double log_pos(double x) {
+#ifdef ESDG_LIBM_LOG
+  return ::log(x);
+#endif
   double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
   int e = __builtin_amdgcn_frexp_exp(x);
   const bool lo = m < 0.70710678118654752440;

@@ -130,6 +130,41 @@ class RhsEngine:
         # overlap exchanges with the interior elements (tensor / hex kernels); ESDG_NO_OVERLAP=1 restores phase-by-phase
         import os
         self.overlap = bool(L.esdg_uses_tensor_kernels(ctx)) and os.environ.get("ESDG_NO_OVERLAP", "0") != "1"
+        # "torch": exchanges through torch.distributed P2P driven from Python (HaloExchanger; gloo in the CPU tests);
+        # "rccl": the library's own RCCL transport and schedule (attach_rccl), the path a Julia / C host uses
+        self.transport = "torch"
+
+    def attach_rccl(self, group=None, loopback=False):
+        """Attach the library's RCCL communicator (esdg_comm_init): afterwards rhs_into / rhs_lsrk_fused hand the whole
+        sharded evaluation -- overlapped phases, packs, grouped ncclSend/ncclRecv on the library's comm stream -- to
+        esdg_rhs / esdg_rhs_lsrk.  The 128-byte ncclUniqueId is created on rank 0 and broadcast through `group`
+        (any torch.distributed backend; only the bootstrap uses it).  loopback=True: one-GPU rehearsal, see
+        include/esdg_hip.h:esdg_comm_set_loopback."""
+        L, ctx = self.L, self.ctx
+        idb = (C.c_ubyte * 128)()
+        if loopback:
+            check(L.esdg_comm_set_loopback(ctx, 1))
+            check(L.esdg_comm_unique_id(idb))
+            check(L.esdg_comm_init(ctx, idb, 0, 1))
+        else:
+            import torch.distributed as dist
+            rank = dist.get_rank(group)
+            on_dev = dist.get_backend(group) == "nccl"
+            t = torch.zeros(128, dtype=torch.uint8, device=self.device if on_dev else "cpu")
+            if rank == 0:
+                check(L.esdg_comm_unique_id(idb))
+                t.copy_(torch.frombuffer(bytearray(bytes(idb)), dtype=torch.uint8))
+            dist.broadcast(t, src=0, group=group)
+            raw = bytes(t.cpu().numpy().tobytes())
+            check(L.esdg_comm_init(ctx, C.create_string_buffer(raw, 128), rank, dist.get_world_size(group)))
+        self.transport = "rccl"
+        return int(L.esdg_comm_size(ctx))
+
+    def allreduce(self, vals, op="sum"):
+        """Sum / max / min of a few host doubles over the ranks of the library's communicator (esdg_comm_allreduce)."""
+        a = (C.c_double * len(vals))(*[float(v) for v in vals])
+        check(self.L.esdg_comm_allreduce(self.ctx, a, len(vals), {"sum": 0, "max": 1, "min": 2}[op], self._stream()))
+        return list(a)
 
     def _create_hex(self, L, rd, md, ops, lf_scale, rank, nranks, rank_offsets):
         """esdg_create_hex from the arrays examples/dg3D_euler_hex.jl holds when it calls `rhs` (:167)."""
@@ -325,7 +360,7 @@ class RhsEngine:
         """One RHS evaluation, state resident on device; asynchronous on torch's current stream."""
         assert Qd.is_contiguous() and out.is_contiguous() and Qd.dtype == torch.float64
         L, ctx, s = self.L, self.ctx, self._stream()
-        if self.halo is None:
+        if self.halo is None or self.transport == "rccl":
             check(L.esdg_rhs(ctx, C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr()), s))
             return out
         q, o = C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr())
@@ -454,7 +489,7 @@ class RhsEngine:
         L, ctx, s = self.L, self.ctx, self._stream()
         q, r = C.c_void_p(Qd.data_ptr()), C.c_void_p(resd.data_ptr())
         a, b, dt = float(a), float(b), float(dt)
-        if self.halo is None:
+        if self.halo is None or self.transport == "rccl":
             check(L.esdg_rhs_lsrk(ctx, q, r, a, b, dt, s))
             return
         self._phases(lambda ph: check(L.esdg_rhs_phase_lsrk(ctx, ph, q, r, a, b, dt, self._stream())),

@@ -35,7 +35,8 @@ typedef enum {
   ESDG_ERR_STRUCTURE = -2,  /* operators are not tensor-product-sparse / mesh not affine */
   ESDG_ERR_NO_DEVICE = -3,  /* no HIP device or HIP runtime error */
   ESDG_ERR_ALLOC = -4,
-  ESDG_ERR_STATE = -5       /* call order (e.g. workspace not bound) */
+  ESDG_ERR_STATE = -5,      /* call order (e.g. workspace not bound) */
+  ESDG_ERR_COMM = -6        /* RCCL error, or halo plans of two ranks disagree */
 } esdg_status;
 
 typedef struct esdg_ctx esdg_ctx;
@@ -286,6 +287,34 @@ int esdg_rhs_phase_range_lsrk(esdg_ctx* ctx, int phase, int64_t e_begin, int64_t
                               double a, double b, double dt, void* stream);
 int esdg_halo_pack(esdg_ctx* ctx, int xch, void* stream);
 
+/* ---- RCCL transport inside the library --------------------------------------------------------------------------
+ * No reference counterpart: the reference is single-process; this is the "RCCL halo exchange over xGMI for
+ * mapP face neighbours once per RK stage" of the north star, reachable from a Julia or C host without torch.
+ * One process per GPU.  Bootstrap: ONE rank calls esdg_comm_unique_id and hands the ESDG_COMM_ID_BYTES bytes to the
+ * others by whatever the host has (MPI_Bcast, a file, torch.distributed); every rank then calls esdg_comm_init with its
+ * shard's rank / nranks (must equal esdg_mesh_t.rank / .nranks; collective: ncclCommInitRank).  esdg_comm_init also
+ * cross-checks the halo plan with every neighbour (send count of one side == receive count of the other).
+ * With a communicator attached, esdg_rhs / esdg_rhs_lsrk / esdg_lsrk45_step / esdg_dopri45_attempt work on a sharded
+ * context: they run the overlapped schedule described at esdg_interior_range, the exchanges as grouped
+ * ncclSend/ncclRecv (one group per producing phase) on an internal comm stream, ordered against `stream` with events.
+ * esdg_halo_exchange / esdg_halo_wait are that schedule's two transport steps for hosts that drive the phases
+ * themselves: post everything phase `phase` produced (its packed buffers must be complete on `stream`); make
+ * `stream` wait for everything that must have landed before `phase`.
+ * esdg_comm_allreduce: sum (op 0) / max (op 1) / min (op 2) of n <= 64 host doubles over the ranks, in place
+ * (rhstest, DOPRI error norm, dt; synchronises `stream`).
+ * esdg_comm_set_loopback(ctx, 1) before esdg_comm_init(ctx, id, 0, 1): one-GPU rehearsal of the transport -- every
+ * neighbour is this rank itself, a segment sent towards neighbour n is received as the ghost data of neighbour n+1
+ * (cyclic), which for a strip that is periodic by itself is exactly what the real neighbours would send. */
+#define ESDG_COMM_ID_BYTES 128
+int esdg_comm_unique_id(void* id_out);
+int esdg_comm_init(esdg_ctx* ctx, const void* id, int rank, int nranks);
+int esdg_comm_set_loopback(esdg_ctx* ctx, int on);
+int esdg_comm_size(const esdg_ctx* ctx);   /* ranks in the communicator as RCCL reports them (ncclCommCount); 0 = none */
+int esdg_comm_destroy(esdg_ctx* ctx);
+int esdg_halo_exchange(esdg_ctx* ctx, int phase, void* stream);
+int esdg_halo_wait(esdg_ctx* ctx, int phase, void* stream);
+int esdg_comm_allreduce(esdg_ctx* ctx, double* host_vals, int n, int op, void* stream);
+
 /* Host-only construction of the same plan (no GPU needed; used by the gloo CPU tests and by
  * hosts that want to inspect the partition).  mapP: (Nfq x K) 1-based GLOBAL indices of the local
  * elements.  Offsets/counts are in face nodes; ghost slot g lives at local index K*Nfq + g. */
@@ -362,6 +391,8 @@ int esdg_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
 int esdg_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
 int esdg_device_synchronize(void);
 int esdg_device_count(void);
+/* hipSetDevice for hosts that run one process per GPU without another HIP-aware runtime (call before esdg_create) */
+int esdg_set_device(int device);
 
 #ifdef __cplusplus
 }

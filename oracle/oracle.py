@@ -15,18 +15,21 @@ from . import ref_setup as rs
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LIBQ = None
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 _lp = C.POINTER(C.c_int64)
 
 
-def build(force=False):
-    """Compile oracle/liboracle.so with gcc (idempotent)."""
-    so = os.path.join(_HERE, "liboracle.so")
+def build(force=False, quad=False):
+    """Compile oracle/liboracle.so (Float64) or oracle/liboracle_quad.so (binary128 truth evaluator) with gcc
+    (idempotent)."""
+    name = "liboracle_quad.so" if quad else "liboracle.so"
+    so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "oracle_rhs.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", name], stdout=subprocess.DEVNULL)
     return so
 
 
@@ -47,10 +50,8 @@ class _HexT(C.Structure):
                 + [("mapP", _lp), ("lf_scale", C.c_double)])
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        L = C.CDLL(build())
+def _declare(L):
+    if True:
         L.oracle_logmean.restype = C.c_double
         L.oracle_logmean.argtypes = [C.c_double] * 4
         L.oracle_euler_fluxes_2d.argtypes = [_dp] * 6
@@ -75,8 +76,26 @@ def lib():
         L.oracle_hex_rhs.argtypes = [C.POINTER(_HexT), _dp, C.c_int, _dp]
         L.oracle_set_threads.argtypes = [C.c_int]
         L.oracle_get_max_threads.restype = C.c_int
-        _LIB = L
+        L.oracle_real_bits.restype = C.c_int
+    return L
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = _declare(C.CDLL(build()))
+        assert _LIB.oracle_real_bits() == 64
     return _LIB
+
+
+def lib_quad():
+    """The truth evaluator: the same C statements compiled with -DORACLE_QUAD (IEEE binary128 arithmetic on the same
+    double inputs, result rounded to double once).  Same symbols and signatures as lib()."""
+    global _LIBQ
+    if _LIBQ is None:
+        _LIBQ = _declare(C.CDLL(build(quad=True)))
+        assert _LIBQ.oracle_real_bits() == 128
+    return _LIBQ
 
 
 def _d(a):
@@ -262,9 +281,11 @@ def build_cns_problem(N, Kx, Ky, bc="periodic", BCTYPE=1, Re=1000.0, Pr=.71, she
         rho, u, v, pr = shocktube_state(md.x, md.y)
     else:                                                          # smooth non-trivial cavity state
         x, y = md.x, md.y
+        # phases: no exact zero of a velocity component on an element interface -- the LF wavespeed's
+        # sqrt(|u_n|) (quirk Q1) turns the 1e-17 round-off of such a zero into 3e-9
         rho = 1.0 + .2 * np.exp(-10 * (x ** 2 + y ** 2))
-        u = .1 * np.sin(np.pi * x) * np.cos(np.pi * y)
-        v = -.1 * np.cos(np.pi * x) * np.sin(np.pi * y)
+        u = .1 * np.sin(np.pi * x + .3) * np.cos(np.pi * y + .2)
+        v = -.1 * np.cos(np.pi * x + .3) * np.sin(np.pi * y + .2)
         pr = (1 / (.3 ** 2 * ph.GAMMA)) * rho ** ph.GAMMA
     p.Q = [np.asfortranarray(q) for q in ph.primitive_to_conservative(rho, u, v, pr)]
     p.rd, p.md, p.ops, p.VX, p.VY, p.EToV, p.N = rd, md, ops, VX, VY, EToV, N
@@ -305,8 +326,9 @@ def build_hex_problem(N, Kx, Ky=None, Kz=None, A3=None, grade=0.0, a=0.0):
 class EulerOracle:
     """C restatement of `rhs` (examples/dg2D_euler_quad.jl:141-194) bound to one problem."""
 
-    def __init__(self, p):
+    def __init__(self, p, quad=False):
         md, ops = p.md, p.ops
+        self.L = lib_quad() if quad else lib()     # quad: the binary128 truth evaluator (same statements)
         self.K, self.Nq, self.Nfq = md.K, ops["Ph"].shape[0], ops["Lf"].shape[1]
         rowptr = [0]
         col = []
@@ -324,7 +346,7 @@ class EulerOracle:
     def rhs_stacked(self, Qs, lf_scale=.5, compute_rhstest=False):
         out = np.zeros_like(Qs)
         a = self.a
-        rt = lib().oracle_euler_rhs(self.K, self.Nq, self.Nfq, _d(Qs), _d(a["Ef"]), _d(a["Qr"]), _d(a["Qs"]),
+        rt = self.L.oracle_euler_rhs(self.K, self.Nq, self.Nfq, _d(Qs), _d(a["Ef"]), _d(a["Qr"]), _d(a["Qs"]),
                                     self.rowptr.ctypes.data_as(_ip), self.col.ctypes.data_as(_ip), _d(a["Ph"]),
                                     _d(a["Lf"]), _d(a["rxJ"]), _d(a["sxJ"]), _d(a["ryJ"]), _d(a["syJ"]), _d(a["J"]),
                                     _d(a["wJq"]), _d(a["nxJ"]), _d(a["nyJ"]), _d(a["sJ"]),
@@ -339,8 +361,9 @@ class EulerOracle:
 class CnsOracle:
     """C restatement of rhs_inviscid!/rhs_viscous!/rhsRK! (dg2D_CNS_cavity_optimized.jl) bound to one problem."""
 
-    def __init__(self, p, inviscid_dissp=True, viscous_dissp=True):
+    def __init__(self, p, inviscid_dissp=True, viscous_dissp=True, quad=False):
         md, rd, ops = p.md, p.rd, p.ops
+        self.L = lib_quad() if quad else lib()     # quad: the binary128 truth evaluator (same statements)
         c = np.ascontiguousarray
         self.K = md.K
         self.Np = rd.Pq.shape[0]
@@ -378,19 +401,19 @@ class CnsOracle:
     def rhs_inviscid(self, Q):
         Qs = stack(Q)
         out = np.zeros_like(Qs)
-        lib().oracle_cns_rhs_inviscid(C.byref(self.t), _d(Qs), _d(out))
+        self.L.oracle_cns_rhs_inviscid(C.byref(self.t), _d(Qs), _d(out))
         return unstack(out)
 
     def rhs_viscous(self, Q):
         Qs = stack(Q)
         out = np.zeros_like(Qs)
-        rt = lib().oracle_cns_rhs_viscous(C.byref(self.t), _d(Qs), _d(out))
+        rt = self.L.oracle_cns_rhs_viscous(C.byref(self.t), _d(Qs), _d(out))
         return unstack(out), rt
 
     def rhsRK_stacked(self, Qs, compute_diag=False):
         out = np.zeros_like(Qs)
         diag = np.zeros(2)
-        lib().oracle_cns_rhsRK(C.byref(self.t), _d(Qs), _d(out), int(compute_diag), _d(diag))
+        self.L.oracle_cns_rhsRK(C.byref(self.t), _d(Qs), _d(out), int(compute_diag), _d(diag))
         return out, diag
 
     def rhsRK(self, Q, compute_diag=True):
@@ -401,8 +424,9 @@ class CnsOracle:
 class HexOracle:
     """C restatement of `rhs` (examples/dg3D_euler_hex.jl:167-222) bound to one problem."""
 
-    def __init__(self, p, lf_scale=0.0):
+    def __init__(self, p, lf_scale=0.0, quad=False):
         md, ops = p.md, p.ops
+        self.L = lib_quad() if quad else lib()     # quad: the binary128 truth evaluator (same statements)
         c = np.ascontiguousarray
         rowptr, col = [0], []
         for ids in ops["Qnzids"]:
@@ -429,7 +453,7 @@ class HexOracle:
 
     def rhs_stacked(self, Qs, compute_rhstest=False):
         out = np.zeros_like(Qs)
-        rt = lib().oracle_hex_rhs(C.byref(self.t), _d(Qs), int(compute_rhstest), _d(out))
+        rt = self.L.oracle_hex_rhs(C.byref(self.t), _d(Qs), int(compute_rhstest), _d(out))
         return out, rt
 
     def rhs(self, Q, compute_rhstest=False):

@@ -250,3 +250,18 @@ def test_whole_step_c_entry_points_match_the_python_loops():
         prev = e.value
         assert ok == hist[i][0] and abs(e.value - hist[i][1]) <= 1e-12 * max(1.0, hist[i][1]) and abs(dtc - hist[i][2]) <= 1e-15 * dt0 + 1e-12 * dtc
     assert torch.equal(Qa, Qb) and abs(t - integ.t) < 1e-15
+
+
+def test_pure_c_sharded_driver_over_the_library_rccl_transport(tmp_path):
+    """examples/c/dg2D_CNS_sharded.c in its one-GPU mode: rank 0's strip of an 8-rank CNS mesh through esdg_comm_init
+    (loopback) / esdg_rhs on the sharded context, no torch and no Python in the process; it compares the result with the
+    same strip as a stand-alone periodic mesh and exits non-zero on a mismatch."""
+    import subprocess
+    exe = str(tmp_path / "cns_sharded_c")
+    lib = os.path.join(ROOT, "esdg_cns_amd")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c", "dg2D_CNS_sharded.c"),
+                           "-o", exe, "-L", lib, "-lesdg_hip", "-lm", "-Wl,-rpath," + lib])
+    for args in (["1", "4", "32", "4"], ["1", "3", "24", "2"]):
+        out = subprocess.check_output([exe] + args, text=True, timeout=300)
+        print(out.strip())
+        assert "OK" in out and "RCCL comm size 1" in out

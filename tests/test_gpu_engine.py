@@ -241,3 +241,181 @@ def test_check_state_reports_min_density_and_pressure(E):
     ph_ = 0.4 * (Qh[4] - .5 * (Qh[1] ** 2 + Qh[2] ** 2 + Qh[3] ** 2) / Qh[0])
     mr, mp = engh.check_state(engh.upload(Qh))
     assert abs(mr - Qh[0].min()) < 1e-15 and abs(mp - ph_.min()) < 1e-14
+
+
+def test_full_size_properties_euler_256(E):
+    """BASELINE config 2 (2D Euler, N=4, 256x256, collocated EC flux differencing) at its exact size: free stream,
+    conservation, entropy conservation with the LF term off (|rhstest| ~ round-off), entropy decay with it on."""
+    rd, md, ops, Q = product_euler_problem(4, 256, 256)
+    eng = E.RhsEngine(rd, md, ops, E.EULER_COLLOCATED)
+    one = np.ones_like(Q[0])
+    from esdg_cns_amd import physics as ph
+    from common import perturb
+    Qc = [np.asfortranarray(q) for q in ph.primitive_to_conservative(1.1 * one, .3 * one, -.2 * one, .9 * one)]
+    r = eng.rhs(eng.upload(Qc))
+    assert float(r.abs().max()) < 1e-11 / float(md.J.min())             # free-stream preservation
+    Qp = perturb(Q)
+    rh = eng.download(eng.rhs(eng.upload(Qp)))
+    wJ = md.wJq
+    scale = max(float(np.abs(wJ * x).sum()) for x in rh)
+    for x in rh:                                                          # discrete conservation
+        assert abs(float((wJ * x).sum())) <= 2e-9 * max(scale, 1.0)
+    Qd, Qpd = eng.upload(Q), eng.upload(Qp)
+    rt = eng.rhstest(Qpd, eng.rhs(Qpd))
+    assert rt < 0                                   # LF dissipation: entropy decays (on the smooth vortex at this
+    r = eng.rhs(Qd)                                 # resolution the interface jumps, and with them the LF term, are ~1e-12)
+    ec = E.RhsEngine(rd, md, ops, E.EULER_COLLOCATED, inviscid_dissp=False, lf_scale=0.0)
+    r2 = ec.rhs(Qd)
+    rt0 = ec.rhstest(Qd, r2)
+    print(f"cfg2 euler N=4 256x256: rhstest with LF {rt:.3e}, without {rt0:.3e}")
+    assert abs(rt0) < 1e-9                                                 # entropy conservative without LF
+    assert torch.equal(eng.rhs(Qd), r)                                     # run-to-run bitwise
+
+
+def _strip_periodic_state(x, y, LY):
+    """Smooth state with period 15 in x and LY in y (one strip of the sharded box is then periodic on its own)."""
+    from esdg_cns_amd import physics as ph
+    cx, cy = 2 * np.pi * x / 15.0, 2 * np.pi * (y - y.min()) / LY
+    rho = 1 + .2 * np.sin(cx + .3) * np.cos(cy + .1)
+    u = .4 + .1 * np.cos(cx - .2) * np.sin(cy + .4)
+    v = -.3 + .1 * np.sin(cx + .5) * np.sin(cy - .3)
+    p = 1 + .15 * np.cos(cx + .7) * np.cos(cy + .2)
+    return [np.asfortranarray(q) for q in ph.primitive_to_conservative(rho, u, v, p)]
+
+
+def test_cfg4_rank0_strip_of_the_8_rank_mesh(E):
+    """BASELINE config 4 (2D CNS, N=4, 2048x2048 over 8 GPUs): rank 0's shard -- the 2048x256 strip, 524 288 elements,
+    with its ghost slots, send lists and pack kernels -- run on one GPU.  Its neighbours (ranks 1 and 7) are replaced by a
+    local copy: for a state that is periodic over the strip, what rank 0 would receive from rank 1 is what it sends to
+    rank 7 and vice versa (both sides order a segment by global node id, i.e. by x).  The result must equal, bit for bit,
+    the same strip run as a stand-alone periodic mesh; free stream / conservation / entropy sign are checked on it."""
+    from esdg_cns_amd import setup_dg as sd
+    N, Kx, Kyr, nr = 4, 2048, 256, 8
+    LY = 10.0 * Kyr / Kx                                     # strip height when the elements stay square (bench.py scaling)
+
+    def build(Ky_total, e0, e1):
+        VX, VY, EToV = sd.uniform_quad_mesh(Kx, Ky_total)
+        VX = 15 * (1 + VX) / 2
+        VY = 5 * VY * (Ky_total / Kx)
+        rd = sd.init_reference_quad(N)
+        md = sd.init_mesh((VX, VY), EToV, rd, elem_range=(e0, e1))
+        sd.make_periodic(md, rd)
+        md.mapB = np.zeros(0, dtype=np.int64)
+        ops = sd.cns_ops(rd)
+        sd.interp_geofacs_to_hybrid(md, ops["Vh"])
+        return rd, md, ops
+
+    rd, md, ops = build(Kyr * nr, 0, Kx * Kyr)               # rank 0 of the 8-rank mesh
+    offsets = np.array([Kx * Kyr * r for r in range(nr + 1)], dtype=np.int64)
+    sh = E.RhsEngine(rd, md, ops, E.CNS_MODAL, rank=0, nranks=nr, rank_offsets=offsets)
+    assert sh.halo is not None and sh.K == 524288
+    peers = sorted(s[0] for s in sh.halo.segments[0])
+    assert peers == [1, 7]
+    Q = _strip_periodic_state(md.x, md.y, LY)
+    Qd, out = sh.upload(Q), sh.new_state()
+    del Q
+    for ph in range(sh.nphases):
+        E.check(sh.L.esdg_rhs_phase(sh.ctx, ph, C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr()), None))
+        for x, (after, before, nc) in enumerate(sh.xinfo):
+            if after != ph:
+                continue
+            seg = {s[0]: s for s in sh.halo.segments[x]}
+            for a, b in ((1, 7), (7, 1)):                    # received from a := sent to b
+                _, so, sb, _, _ = seg[b]
+                _, _, _, ro, rb = seg[a]
+                assert sb == rb and sb == Kx * (N + 1) * nc * 8
+                sh.ws[ro:ro + rb] = sh.ws[so:so + sb]
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+
+    # the same strip as a stand-alone periodic mesh: the shard's own arrays (identical inputs) with the periodic strip's mapP
+    _, md1s, _ = build(Kyr, 0, Kx * Kyr)
+    import copy
+    rd1, ops1, md1 = rd, ops, copy.copy(md)
+    md1.mapP, md1.elem_offset, md1.Kglobal = md1s.mapP, 0, md.K
+    del md1s
+    one = E.RhsEngine(rd1, md1, ops1, E.CNS_MODAL)
+    Q1, Qd1 = None, Qd
+    ref = one.rhs(Qd1)
+    assert torch.equal(out, ref)                             # the shard reproduces the stand-alone strip to the bit
+    # properties at the shard's size
+    rh = one.download(ref)
+    wJ = md1.wJq
+    scale = max(float(np.abs(wJ * (rd1.Vq @ x)).sum()) for x in rh)
+    noq = E.RhsEngine(rd1, md1, ops1, E.CNS_MODAL, viscous_dissp=False)
+    rn = noq.download(noq.rhs(Qd1))
+    for x in rn:                                             # conservation (no penalty term, quirk Q3)
+        assert abs(float((wJ * (rd1.Vq @ x)).sum())) <= 2e-9 * max(scale, 1.0)
+    assert one.rhstest(Qd1, ref) < 0                         # LF + viscous dissipation
+    c = np.ones((rd.Pq.shape[0], md.K))
+    from esdg_cns_amd import physics as ph
+    Qc = [np.asfortranarray(q) for q in ph.primitive_to_conservative(1.1 * c, .3 * c, -.2 * c, .9 * c)]
+    r = sh.new_state()
+    Qcd = sh.upload(Qc)
+    for phs in range(sh.nphases):
+        E.check(sh.L.esdg_rhs_phase(sh.ctx, phs, C.c_void_p(Qcd.data_ptr()), C.c_void_p(r.data_ptr()), None))
+        for x, (after, before, nc) in enumerate(sh.xinfo):
+            if after == phs:
+                seg = {s[0]: s for s in sh.halo.segments[x]}
+                for a, b in ((1, 7), (7, 1)):
+                    sh.ws[seg[a][3]:seg[a][3] + seg[a][4]] = sh.ws[seg[b][1]:seg[b][1] + seg[b][2]]
+    assert float(r.abs().max()) < 1e-11 / float(md.J.min())   # free stream through the ghost slots
+
+
+@pytest.mark.parametrize("form,N,Kx,Kyr", [("cns", 4, 24, 3), ("cns", 3, 16, 2), ("euler", 4, 20, 2)])
+def test_rccl_transport_inside_the_library_loopback(E, form, N, Kx, Kyr):
+    """The library's own RCCL transport and sharded schedule (esdg_comm_init / esdg_rhs on a sharded context: overlapped
+    phases, packs, grouped ncclSend/ncclRecv on the comm stream) executed for real on one GPU: rank 0's strip of an 8-rank
+    mesh with the communicator in loopback (every neighbour is this rank; what goes to the rank below comes back in as the
+    ghost data of the rank above).  For a strip-periodic state that is what ranks 1 and 7 would send, so the result must
+    equal the stand-alone periodic strip bit for bit -- also through the fused LSRK stage."""
+    from esdg_cns_amd import setup_dg as sd
+    nr = 8
+    LY = 10.0 * Kyr / Kx
+
+    def build(Ky_total, e0, e1):
+        VX, VY, EToV = sd.uniform_quad_mesh(Kx, Ky_total)
+        VX = 15 * (1 + VX) / 2
+        VY = 5 * VY * (Ky_total / Kx)
+        rd = sd.init_reference_quad(N) if form == "cns" else sd.init_reference_quad(N, sd.gauss_quad(0, 0, N))
+        md = sd.init_mesh((VX, VY), EToV, rd, elem_range=(e0, e1))
+        sd.make_periodic(md, rd)
+        md.mapB = np.zeros(0, dtype=np.int64)
+        ops = sd.cns_ops(rd) if form == "cns" else sd.euler_quad_ops(rd)
+        sd.interp_geofacs_to_hybrid(md, ops["Vh"])
+        return rd, md, ops
+
+    code = E.CNS_MODAL if form == "cns" else E.EULER_COLLOCATED
+    rd, md, ops = build(Kyr * nr, 0, Kx * Kyr)
+    offsets = np.array([Kx * Kyr * r for r in range(nr + 1)], dtype=np.int64)
+    sh = E.RhsEngine(rd, md, ops, code, rank=0, nranks=nr, rank_offsets=offsets)
+    assert sh.attach_rccl(loopback=True) == 1 and sh.transport == "rccl"
+    xs, ys = (md.x, md.y) if form == "cns" else (md.xq, md.yq)
+    Q = _strip_periodic_state(xs, ys, LY)
+    import copy
+    _, md1s, _ = build(Kyr, 0, Kx * Kyr)                   # the stand-alone periodic strip: the shard's own arrays, its mapP
+    md1 = copy.copy(md)
+    md1.mapP, md1.elem_offset, md1.Kglobal = md1s.mapP, 0, md.K
+    one = E.RhsEngine(rd, md1, ops, code)
+    Qd = sh.upload(Q)
+    # the overlapped schedule launches element ranges, so elements land in other lanes / groups than in the one-launch
+    # evaluation: bit-equal wherever the kernels' arithmetic does not depend on the slot (see test_ranged_launches_*)
+    same_inputs = not (form == "cns" and N == 4)
+    for rep in range(3):                                   # repeated evaluations reuse buffers, events and the comm stream
+        got, ref = sh.rhs(Qd), one.rhs(Qd)
+        torch.cuda.synchronize()
+        rel = float((got - ref).abs().max() / ref.abs().max())
+        assert rel <= 1e-11, rel
+        if same_inputs:
+            assert torch.equal(got, ref)
+    # fused low-storage stage through the same transport
+    q1, q2 = Qd.clone(), Qd.clone()
+    r1, r2 = torch.zeros_like(Qd), torch.zeros_like(Qd)
+    for k in range(3):
+        sh.rhs_lsrk_fused(q1, r1, -0.4 * k, 0.3, 1e-3)
+        one.rhs_lsrk_fused(q2, r2, -0.4 * k, 0.3, 1e-3)
+    torch.cuda.synchronize()
+    assert float((q1 - q2).abs().max()) <= 1e-12 * float(q2.abs().max())
+    if same_inputs:
+        assert torch.equal(q1, q2)
+    assert sh.allreduce([1.5, -2.0], "sum") == [1.5, -2.0] and sh.allreduce([3.0], "max") == [3.0]
