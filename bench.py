@@ -1,23 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X RHS engine (contract: see the task statement).
 
-A "step" is ONE explicit-RK right-hand-side evaluation (all phases of the hot path + halo exchange)
-over the whole mesh with the state resident in HBM.  Workload at N=1: BASELINE.json configs[2],
-"2D compressible Navier-Stokes, N=4, 512x512 quads, 1 MI355X" -- the configuration the metric and
-the >=40 %-of-HBM-roofline target are quoted on: modal ESDG CNS algorithm of
-examples/CompressibleNS/dg2D_CNS_cavity_optimized.jl (rhsRK!) on the reference quad element,
-periodic isentropic-vortex box, Re=1000, both dissipations on.  For N>1 GPUs the mesh grows in y
-(512 x 512N elements, one horizontal strip of 512x512 per rank = weak scaling) and the three face-trace
-exchanges per RHS go over RCCL (torch.distributed "nccl").
+A "step" is ONE explicit-RK right-hand-side evaluation (all phases of the hot path + halo exchange) over the whole mesh
+with the state resident in HBM.
 
---formulation hex runs BASELINE.json configs[4] per GPU instead: 3D hexahedral Euler, N=3, 128x128x16 elements per
-GPU (z-slabs of the 128^3 box; `rhs` of examples/dg3D_euler_hex.jl, LF factor 0 as in the reference unless --lf).
+  --gpus 1 (default): BASELINE.json configs[2], "2D compressible Navier-Stokes, N=4, 512x512 quads, 1 MI355X" -- the
+      configuration the metric and the >=40 %-of-HBM-roofline target are quoted on: modal ESDG CNS algorithm of
+      examples/CompressibleNS/dg2D_CNS_cavity_optimized.jl (rhsRK!) on the reference quad element, periodic isentropic-vortex
+      box, Re=1000, both dissipations on.
+  --gpus N > 1: BASELINE.json configs[3]'s per-GPU load, one horizontal strip of 2048x256 elements per rank (N = 8 IS
+      "2D CNS N=4, 2048x2048 quads sharded across 8xMI355X"; weak scaling in between), the three face-trace exchanges per
+      RHS over the library's own RCCL transport (esdg_comm_init; --transport torch drives torch.distributed P2P instead).
+      `python bench.py --gpus N` launches its N ranks itself (a torch.distributed.run child, before this process touches
+      a GPU); under an existing launcher (WORLD_SIZE set) it just runs as one rank.
+  --formulation hex: BASELINE.json configs[4] per GPU, 3D hexahedral Euler, N=3, 128x128x16 elements per GPU (z-slabs of
+      the 128^3 box; `rhs` of examples/dg3D_euler_hex.jl, LF factor 0 as in the reference unless --lf).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,8 +31,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 fp64 lanes x 2 x 2.4 GHz
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 fp64 lanes x 2 flop x 2.4 GHz
+PREWARM_EVALS = 200           # untimed RHS evaluations before the warm-up steps (GPU clock ramp), see run()
+REPS = 5                      # repetitions of the K-step timed region (the first one is the contract's; median/min reported)
 
 
 def build_problem(N, Kx, Ky_total, e0, e1, formulation):
@@ -35,7 +42,7 @@ def build_problem(N, Kx, Ky_total, e0, e1, formulation):
     from esdg_cns_amd import setup_dg as sd
     VX, VY, EToV = sd.uniform_quad_mesh(Kx, Ky_total)
     VX = 15 * (1 + VX) / 2
-    VY = 5 * VY * (Ky_total / Kx)          # keep square elements of the 512^2 box as the mesh grows in y
+    VY = 5 * VY * (Ky_total / Kx)          # keep square elements as the mesh grows in y
     if formulation == "euler":
         rd = sd.init_reference_quad(N, sd.gauss_quad(0, 0, N))
         ops = sd.euler_quad_ops(rd)
@@ -70,47 +77,6 @@ def build_hex_problem(N, Kx, Ky, Kz_total, e0, e1, curve=0.0):
     return rd, md, ops, Q
 
 
-def cpu_baseline_hex(N, lf, budget_s=15.0):
-    """oracle_hex_rhs (C restatement of dg3D_euler_hex.jl:122-222: 1344 flux evaluations per element at N=3), one
-    thread, on a 12^3 sample of the same periodic box."""
-    from oracle import oracle as orc
-    Ks = 12
-    p = orc.build_hex_problem(N, Ks)
-    orc.lib().oracle_set_threads(1)
-    o = orc.HexOracle(p, lf)
-    Qs = orc.stack(p.Q)
-    o.rhs_stacked(Qs)
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        o.rhs_stacked(Qs)
-        n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 50:
-            break
-    dt = (time.perf_counter() - t0) / n
-    K, Np = p.md.K, (N + 1) ** 3
-    nthr = min(int(orc.lib().oracle_get_max_threads()), usable_cpus())   # OpenMP over elements on the usable host cores
-    orc.lib().oracle_set_threads(nthr)
-    o.rhs_stacked(Qs)
-    t1 = time.perf_counter()
-    m = 0
-    while True:
-        o.rhs_stacked(Qs)
-        m += 1
-        if time.perf_counter() - t1 > 5.0 or m >= 50:
-            break
-    dtm = (time.perf_counter() - t1) / m
-    orc.lib().oracle_set_threads(1)
-    return {"value": K * Np / dt, "unit": "DOF updates/s", "cores": 1, "kind": "port",
-            "sample": f"hex N={N} {Ks}^3 periodic box, {n} RHS evals of oracle/oracle_rhs.c:oracle_hex_rhs "
-                      f"(C restatement of the Julia reference, 1 thread), {dt * 1e3:.1f} ms/eval",
-            "rhs_evals_per_s_at_sample": 1.0 / dt,
-            "all_cores": {"value": K * Np / dtm, "cores": nthr, "ms_per_eval": dtm * 1e3}}
-
-
-PREWARM_EVALS = 200   # untimed RHS evaluations before the warm-up steps (GPU clock ramp), see main()
-
-
 def usable_cpus():
     """Host cores this process may actually use: affinity mask and cgroup CPU quota (a GPU box hands each job a share
     of a 128-core host; 128 OpenMP threads on a 16-core share run slower than one)."""
@@ -130,69 +96,126 @@ def usable_cpus():
     return max(1, n)
 
 
-def cpu_baseline(N, formulation, budget_s=15.0):
-    """Reference algorithm restated in C (oracle/oracle_rhs.c, the reference's loop structure: 825
-    visited pairs/element in flux_differencing!), timed single-threaded like the Julia reference, on a
-    bounded sample of the same workload (same N, same vortex box, fewer elements)."""
+def _time_evals(fn, min_evals, budget_s, max_evals=50):
+    fn()                                                   # untimed first call (page faults, thread start-up)
+    ts = []
+    t_end = time.perf_counter() + budget_s
+    while len(ts) < min_evals or (time.perf_counter() < t_end and len(ts) < max_evals):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return ts
+
+
+def cpu_baseline(N, formulation, lf, rd, md, ops, Q, hexw):
+    """The reference algorithm restated in C (oracle/oracle_rhs.c: the reference's loop structure, 825 visited pairs per
+    element in flux_differencing!, 1344 in the hex sparse_hadamard_sum), timed on the SAME workload the GPU ran (same
+    arrays): >= 3 single-threaded evaluations (the Julia reference is single-threaded), then OpenMP over elements on the
+    usable host cores.  The reference itself (Julia) cannot run on this box."""
     from oracle import oracle as orc
-    Ks = 96
-    p = orc.build_cns_problem(N, Ks, Ks, bc="periodic") if formulation == "cns" else orc.build_euler_problem(N, Ks, Ks)
-    orc.lib().oracle_set_threads(1)
-    if formulation == "cns":
-        o = orc.CnsOracle(p)
-        Qs = orc.stack(p.Q)
-        fn = lambda: o.rhsRK_stacked(Qs, False)
+    sample = f"the full GPU workload ({md.K} elements)"
+    if hexw:
+        # the oracle wants the nine metric arrays at all Nh hybrid nodes of every element (9 x 160 x K doubles); the GPU
+        # workload keeps one row per affine element, so the hex baseline runs on a bounded 12^3 sample of the same box
+        ps = orc.build_hex_problem(N, 12)
+        rd, md, ops, Q = ps.rd, ps.md, ps.ops, ps.Q
+        sample = f"a 12^3-element sample of the same periodic box ({md.K} elements)"
+    p = orc.Problem()
+    p.rd, p.md, p.ops, p.Q, p.N = rd, md, dict(ops), Q, N
+    p.Re, p.mu, p.lam, p.Pr, p.BCTYPE = 1000.0, 1e-3, -2e-3 / 3, .71, 1
+    o = p.ops
+    if formulation == "euler" and "Qrsids" not in o:       # dg2D_euler_quad.jl:64
+        o["Qrsids"] = []
+        for i in range(o["Qrh_sparse"].shape[0]):
+            a = list(np.nonzero(o["Qrh_sparse"][i])[0] + 1)
+            o["Qrsids"].append(a + [j for j in list(np.nonzero(o["Qsh_sparse"][i])[0] + 1) if j not in a])
+    if hexw and "Qnzids" not in o:                         # dg3D_euler_hex.jl:57-64
+        for a, b in (("Qrh_sparse", "Qrhskew"), ("Qsh_sparse", "Qshskew"), ("Qth_sparse", "Qthskew")):
+            M = np.array(o[b], dtype=float)
+            M[np.abs(M) < 1e-12] = 0.0
+            o[a] = M
+        o["Qnzids"] = []
+        for i in range(o["Qrh_sparse"].shape[0]):
+            ids = []
+            for M in (o["Qrh_sparse"], o["Qsh_sparse"], o["Qth_sparse"]):
+                ids += [j for j in list(np.nonzero(M[i])[0] + 1) if j not in ids]
+            o["Qnzids"].append(ids)
+    L = orc.lib()
+    Qs = orc.stack(Q)
+    if hexw:
+        oc = orc.HexOracle(p, lf)
+        fn = lambda: oc.rhs_stacked(Qs)
+        what = "oracle_hex_rhs"
+    elif formulation == "cns":
+        oc = orc.CnsOracle(p)
+        fn = lambda: oc.rhsRK_stacked(Qs, False)
+        what = "oracle_cns_rhsRK"
     else:
-        o = orc.EulerOracle(p)
-        Qs = orc.stack(p.Q)
-        fn = lambda: o.rhs_stacked(Qs)
-    fn()
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        fn()
-        n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 50:
-            break
-    dt = (time.perf_counter() - t0) / n
-    K, Np = p.md.K, (N + 1) ** 2
-    # the same restatement with OpenMP over elements on every host core (SURVEY.md section 8d, variant ii)
-    nthr = min(int(orc.lib().oracle_get_max_threads()), usable_cpus())
-    orc.lib().oracle_set_threads(nthr)
-    fn()
-    t1 = time.perf_counter()
-    m = 0
-    while True:
-        fn()
-        m += 1
-        if time.perf_counter() - t1 > 5.0 or m >= 50:
-            break
-    dtm = (time.perf_counter() - t1) / m
-    orc.lib().oracle_set_threads(1)
-    return {"value": K * Np / dt, "unit": "DOF updates/s", "cores": 1, "kind": "port",
-            "sample": f"{formulation} N={N} {Ks}x{Ks} periodic vortex box, {n} RHS evals of oracle/oracle_rhs.c "
-                      f"(C restatement of the Julia reference, 1 thread), {dt * 1e3:.1f} ms/eval",
-            "rhs_evals_per_s_at_sample": 1.0 / dt,
-            "all_cores": {"value": K * Np / dtm, "cores": nthr, "ms_per_eval": dtm * 1e3}}
+        oc = orc.EulerOracle(p)
+        fn = lambda: oc.rhs_stacked(Qs)
+        what = "oracle_euler_rhs"
+    L.oracle_set_threads(1)
+    t1 = _time_evals(fn, 3, 20.0)
+    nthr = min(int(L.oracle_get_max_threads()), usable_cpus())
+    L.oracle_set_threads(nthr)
+    tm = _time_evals(fn, 3, 5.0)
+    L.oracle_set_threads(1)
+    dof = md.K * Q[0].shape[0]
+    med = float(np.median(t1))
+    return {"value": dof / med, "unit": "DOF updates/s", "cores": 1, "kind": "port",
+            "sample": f"{sample}, {len(t1)} evaluations of oracle/oracle_rhs.c:{what} "
+                      f"(C restatement of the Julia reference's loop structure, 1 thread): median {med * 1e3:.0f} ms, "
+                      f"min {min(t1) * 1e3:.0f} ms per evaluation",
+            "rhs_evals_per_s": 1.0 / med,
+            "all_cores": {"value": dof / float(np.median(tm)), "cores": nthr, "ms_per_eval": float(np.median(tm)) * 1e3,
+                          "evals": len(tm)}}
 
 
-def main():
+def kernel_source_hash():
+    """sha256 over the kernel sources: the PMC-derived fields of profiles/pmc_traffic.json carry the hash of the sources
+    they were measured on and are dropped (null + pmc_stale) when the kernels have changed since."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "esdg_cns_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--N", type=int, default=None, help="degree (default 4; 3 for hex)")
-    ap.add_argument("--kx", type=int, default=None, help="elements in x (default 512; 128 for hex, also used for y)")
-    ap.add_argument("--ky-per-gpu", type=int, default=512, help="element rows per GPU (weak scaling, 2D)")
+    ap.add_argument("--kx", type=int, default=None, help="elements in x (default 512 on one GPU, 2048 on several; 128 for hex, also y)")
+    ap.add_argument("--ky-per-gpu", type=int, default=None, help="element rows per GPU (default 512 on one GPU, 256 on several)")
     ap.add_argument("--kz-per-gpu", type=int, default=16, help="element layers per GPU (weak scaling, hex)")
     ap.add_argument("--lf", type=float, default=0.0, help="hex: LF factor (the reference has 0*.25)")
     ap.add_argument("--hex-curve", type=float, default=0.0, help="hex: amplitude a of the script's curved mapping (0 = affine)")
     ap.add_argument("--formulation", choices=["cns", "euler", "hex"], default="cns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
-                    "rehearse the multi-rank logic on one GPU: traces are staged through the host)")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the process group (nccl = RCCL; gloo only to "
+                    "rehearse the multi-rank logic on fewer GPUs: traces are then staged through the host)")
+    ap.add_argument("--transport", choices=["rccl", "torch"], default=None,
+                    help="halo transport: rccl = the library's own communicator and schedule (default with --backend nccl), "
+                         "torch = torch.distributed P2P driven from Python (default with --backend gloo)")
+    ap.add_argument("--oversubscribe", action="store_true", help="rehearsal: allow more ranks than GPUs (recorded in the JSON)")
+    ap.add_argument("--master-port", type=int, default=29577)
+    return ap.parse_args(argv)
 
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` as typed: start the N ranks as a torch.distributed.run child (fresh processes; this one has
+    not touched a GPU) and pass their output and exit code on."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def run(args):
     import torch
     import torch.distributed as dist
     from esdg_cns_amd import engine
@@ -200,22 +223,34 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()                        # does not initialise the GPU
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        sys.exit(2)
-    ndev = torch.cuda.device_count()
-    torch.cuda.set_device(local_rank % max(ndev, 1))
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    oversub = world > max(ndev, 1)
+    if oversub and not args.oversubscribe:
+        if rank == 0:
+            print(f"bench.py: {world} ranks but {ndev} visible GPU(s); pass --oversubscribe for a rehearsal", file=sys.stderr)
+        return 3
+    if oversub and args.backend == "nccl":
+        if rank == 0:
+            print("bench.py: RCCL needs one GPU per rank; use --backend gloo for an oversubscribed rehearsal", file=sys.stderr)
+        return 3
+    dev = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev)
+    transport = args.transport or ("rccl" if args.backend == "nccl" else "torch")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank % max(ndev, 1)))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(args.backend)
 
     hexw = args.formulation == "hex"
     N = args.N if args.N is not None else (3 if hexw else 4)
-    Kx = args.kx if args.kx is not None else (128 if hexw else 512)
+    Kx = args.kx if args.kx is not None else (128 if hexw else (512 if world == 1 else 2048))
+    kyr = args.ky_per_gpu if args.ky_per_gpu is not None else (512 if world == 1 else 256)
     if hexw:
         Kz_total = args.kz_per_gpu * world
         rank_offsets = np.array([Kx * Kx * args.kz_per_gpu * r for r in range(world + 1)], dtype=np.int64)   # z-slabs
@@ -225,19 +260,19 @@ def main():
                                rank_offsets=rank_offsets)
         K_total = Kx * Kx * Kz_total
     else:
-        Ky_total = args.ky_per_gpu * world
-        rows = [args.ky_per_gpu * r for r in range(world + 1)]
-        rank_offsets = np.array([Kx * r for r in rows], dtype=np.int64)   # elements are numbered x-fastest
+        Ky_total = kyr * world
+        rank_offsets = np.array([Kx * kyr * r for r in range(world + 1)], dtype=np.int64)   # elements are numbered x-fastest
         e0, e1 = int(rank_offsets[rank]), int(rank_offsets[rank + 1])
         rd, md, ops, Q = build_problem(N, Kx, Ky_total, e0, e1, args.formulation)
         form = engine.CNS_MODAL if args.formulation == "cns" else engine.EULER_COLLOCATED
         eng = engine.RhsEngine(rd, md, ops, form, rank=rank, nranks=world, rank_offsets=rank_offsets)
         K_total = Kx * Ky_total
+    rccl_ranks = 0
+    if world > 1 and transport == "rccl":
+        rccl_ranks = eng.attach_rccl()
     Qd = eng.upload(Q)
     out = eng.new_state()
-    Np = eng.Np
-    K_local = eng.K
-    nfld = eng.nfld
+    Np, K_local, nfld = eng.Np, eng.K, eng.nfld
 
     def sync_all():
         torch.cuda.synchronize()
@@ -246,90 +281,122 @@ def main():
             torch.cuda.synchronize()
 
     # Clock ramp: an idle MI355X needs some tens of milliseconds of load before it reaches its sustained clocks (measured:
-    # the first ~50 evaluations run up to 25 % slower; 20 steps after 3 warm-ups 1.04 ms, after 50 warm-ups 0.92 ms).
-    # A fixed number of untimed evaluations (the same on every rank) precedes the W warm-up steps so that the timed
-    # region measures sustained throughput whatever W the caller picks; reported as config.prewarm_evals.
+    # the first ~50 evaluations run up to 25 % slower).  A fixed number of untimed evaluations (the same on every rank)
+    # precedes the W warm-up steps so that the timed region measures sustained throughput whatever W the caller picks;
+    # reported as config.prewarm_evals.
     for _ in range(PREWARM_EVALS):
         eng.rhs_into(Qd, out)
     sync_all()
     for _ in range(args.warmup):
         eng.rhs_into(Qd, out)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.rhs_into(Qd, out)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    reps = []
+    for _ in range(REPS):                                    # reps[0] is the contract's timed region of exactly K steps
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.rhs_into(Qd, out)
+        sync_all()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        reps.append(el)
+    elapsed = reps[0]
     ms_per_step = elapsed / args.steps * 1e3
     evals_per_s = args.steps / elapsed
     value = K_total * Np * evals_per_s
 
-    # --- roofline of the dominant kernel (last phase: k_rhs), timed live with events on the launch stream
+    # --- per-phase kernel durations, live, with events on the launch stream (one-launch phases, no exchange) ---------
     import ctypes as C
-    last = eng.nphases - 1
+    nph = eng.nphases
     nrep = 20
     stream = torch.cuda.current_stream()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nrep)]
-    for a, b in evs:
-        for ph in range(last):
-            engine.check(eng.L.esdg_rhs_phase(eng.ctx, ph, C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr()), eng._stream()))
-        a.record(stream)
-        engine.check(eng.L.esdg_rhs_phase(eng.ctx, last, C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr()), eng._stream()))
-        b.record(stream)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(nph + 1)] for _ in range(nrep)]
+    q, o = C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr())
+    for ev in evs:
+        ev[0].record(stream)
+        for ph in range(nph):
+            engine.check(eng.L.esdg_rhs_phase(eng.ctx, ph, q, o, eng._stream()))
+            ev[ph + 1].record(stream)
     torch.cuda.synchronize()
-    kdur_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    phase_ms = [float(np.mean([ev[ph].elapsed_time(ev[ph + 1]) for ev in evs])) for ph in range(nph)]
+    kdur_ms = phase_ms[-1]
     alg_bytes = 16.0 * nfld * Np * K_local       # read state once + write rhs once
     achieved = alg_bytes / (kdur_ms * 1e-3) / 1e9
-    traffic = None
-    prof_us = None
+
+    # --- PMC-derived figures (rocprofv3 passes of this command, tools/profile_round.sh -> profiles/pmc_traffic.json) ----
+    traffic = whole_traffic = prof_us = valu_frac = whole_valu_frac = fp64_flops = None
+    pmc_stale = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            key = f"hex_N{N}_{Kx}x{Kx}x{args.kz_per_gpu}" if hexw else f"{args.formulation}_N{N}_{Kx}x{args.ky_per_gpu}"
+            key = f"hex_N{N}_{Kx}x{Kx}x{args.kz_per_gpu}" if hexw else f"{args.formulation}_N{N}_{Kx}x{kyr}"
             rec = json.load(open(pmc)).get(key, {})
-            traffic = rec.get("k_rhs_hbm_bytes_per_launch")
-            prof_us = rec.get("k_rhs_rocprofv3_avg_us")
+            pmc_stale = bool(rec) and rec.get("kernel_src_sha") != kernel_source_hash()
+            if rec and not pmc_stale:
+                traffic = rec.get("k_rhs_hbm_bytes_per_launch")
+                prof_us = rec.get("k_rhs_rocprofv3_avg_us")
+                whole_traffic = rec.get("whole_rhs_hbm_bytes")
+                fp64_flops = rec.get("k_rhs_fp64_flops_per_launch")
+                if fp64_flops:
+                    valu_frac = fp64_flops / (kdur_ms * 1e-3) / (FP64_VALU_PEAK_TFLOPS * 1e12)
+                if rec.get("whole_rhs_fp64_flops"):
+                    whole_valu_frac = rec["whole_rhs_fp64_flops"] / (sum(phase_ms) * 1e-3) / (FP64_VALU_PEAK_TFLOPS * 1e12)
         except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "kernel": "kh_rhs (last phase: surface flux + flux differencing + lift)" if hexw else
-                "k_rhs (last phase: flux differencing + viscous divergence)",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel_ms": kdur_ms,
-                # the same kernel's average under rocprofv3 --kernel-trace --stats (committed profile of this command,
-                # profiles/*_kernel_stats.csv): agrees with the live figure to 1-2 % on one box
-                "kernel_ms_rocprofv3": None if prof_us is None else prof_us / 1e3,
-                "whole_rhs_frac": (alg_bytes * evals_per_s / 1e9) / HBM_PEAK_GBS}
+            pass
+    kname = "kh_rhs (last phase: surface flux + flux differencing + lift)" if hexw else \
+        "kt_rhs (last phase: flux differencing + viscous divergence)"
+    roofline = {
+        # the binding roof is fp64 VALU issue, not HBM (SQ counters, profiles/): `frac` stays the HBM figure the north star
+        # names, `valu_frac` is the counted fp64 flops of the same kernel against the fp64 vector peak
+        "bound": "fp64-valu", "kernel": kname,
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic, "kernel_ms": kdur_ms, "phase_ms": phase_ms,
+        # the same kernel's average under rocprofv3 --kernel-trace --stats (committed profile of this command)
+        "kernel_ms_rocprofv3": None if prof_us is None else prof_us / 1e3,
+        "whole_rhs_frac": (alg_bytes * evals_per_s / 1e9) / HBM_PEAK_GBS,
+        "whole_rhs_traffic": whole_traffic,
+        "valu_peak_tflops": FP64_VALU_PEAK_TFLOPS, "fp64_flops_per_launch": fp64_flops, "valu_frac": valu_frac,
+        "whole_rhs_valu_frac": whole_valu_frac, "pmc_stale": pmc_stale, "kernel_src_sha": kernel_source_hash()}
 
     if hexw:
         workload = f"euler3d_hex_N{N}_{Kx}x{Kx}x{Kz_total}_periodic_box_lf{args.lf:g}" + (f"_curved{args.hex_curve:g}" if args.hex_curve else "")
+        metric = f"element-DOF updates/sec (RHS evals/s) at N={N}, 3D hex Euler"
     else:
         workload = (f"{args.formulation}2d_N{N}_{Kx}x{Ky_total}_quads_periodic_vortex"
                     + ("_Re1000_inviscid+viscous_dissipation" if args.formulation == "cns" else ""))
+        metric = f"element-DOF updates/sec (RHS evals/s) at N={N}, 2D {'CNS' if args.formulation == 'cns' else 'Euler'} quad mesh"
+    per = sorted(r / args.steps * 1e3 for r in reps)
     result = {
-        "metric": "element-DOF updates/sec (RHS evals/s) at N=4, 2D CNS quad mesh" if not hexw else
-                  "element-DOF updates/sec (RHS evals/s) at N=3, 3D hex Euler",
-        "value": value, "unit": "DOF updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": metric, "value": value, "unit": "DOF updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": workload,
-                   "elements": K_total, "elements_per_gpu": K_local, "Np": Np, "nfields": nfld,
-                   "parallelism": f"element-{'slabs' if hexw else 'strips'} x{world}", "prewarm_evals": PREWARM_EVALS},
+        "config": {"workload": workload, "elements": K_total, "elements_per_gpu": K_local, "Np": Np, "nfields": nfld,
+                   "parallelism": f"element-{'slabs' if hexw else 'strips'} x{world}", "prewarm_evals": PREWARM_EVALS,
+                   "backend": args.backend if world > 1 else None, "transport": transport if world > 1 else None,
+                   "rccl_ranks": rccl_ranks, "visible_gpus": ndev, "oversubscribed": oversub},
         "rhs_evals_per_s": evals_per_s, "elements_per_s": K_total * evals_per_s,
+        "ms_per_step_median": per[len(per) // 2], "ms_per_step_min": per[0], "ms_per_step_reps": [r / args.steps * 1e3 for r in reps],
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline_hex(N, args.lf) if hexw else cpu_baseline(N, args.formulation)
+        result["cpu_baseline"] = cpu_baseline(N, args.formulation, args.lf, rd, md, ops, Q, hexw)
     elif rank == 0:
         result["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    sys.exit(run(args))
 
 
 if __name__ == "__main__":

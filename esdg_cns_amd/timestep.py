@@ -20,7 +20,10 @@ def lsrk45_run_graph(eng, Qd, dt, nsteps):
     """Nsteps LSRK45 steps replayed from ONE captured HIP graph of a full step (5 fused RHS + RK stages = 10-15 kernel
     launches); bitwise equal to lsrk45_run.  Measured on BASELINE cfg1 (256 elements): 66 us/step either way -- the
     loop is bound by the execution latency of ten dependent ~6 us kernels, not by host launch cost, so the graph is
-    an option for hosts with slow launch paths rather than a speed-up here.  Unsharded meshes, fixed dt."""
+    an option for hosts with slow launch paths rather than a speed-up here.  Unsharded meshes, fixed dt.
+    The graph holds the device addresses of Qd and of the low-storage residual: both are kept alive ON the returned
+    graph object (g.esdg_buffers), otherwise the residual would go back to torch's caching allocator on return and any
+    later allocation could alias it between replays."""
     if eng.halo is not None or not eng.L.esdg_uses_tensor_kernels(eng.ctx):
         raise ValueError("graph capture needs an unsharded mesh on the tensor kernels")
     rk4a, rk4b, _ = sd.rk45_coeffs()
@@ -37,6 +40,7 @@ def lsrk45_run_graph(eng, Qd, dt, nsteps):
         for k in range(5):
             eng.rhs_lsrk_fused(Qd, resd, rk4a[k], rk4b[k], dt)
     # the capture itself does not execute: Qd/resd are untouched so far
+    g.esdg_buffers = (Qd, resd)                         # lifetime of the captured addresses = lifetime of the graph
     for _ in range(nsteps):
         g.replay()
     return g
@@ -108,11 +112,9 @@ class Dopri45:
             self.Q.copy_(self.Qtmp)
             self.t += self.dt
             self.k[0], self.k[6] = self.k[6], self.k[0]  # FSAL (:1025)
-        order = 5
-        dtnew = .8 * self.dt * (.9 / err) ** (.4 / (order + 1))
-        if self.i > 0:
-            dtnew *= (self.prev_err / max(1e-14, err)) ** (.3 / (order + 1))
-        self.dt = max(min(10 * self.dt0, dtnew), 1e-9)
+        # P / PI controller (:1027-1037) in the library's guarded form: err == 0 gives Inf in the reference (then
+        # min(10 dt0, .)), a ZeroDivisionError in plain Python
+        self.dt = float(L.esdg_dopri45_next_dt(self.dt, self.dt0, err, self.prev_err, self.i))
         self.prev_err = err
         self.i += 1
         return accepted, err

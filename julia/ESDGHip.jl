@@ -10,7 +10,9 @@
 module ESDGHip
 
 export Engine, CnsEngine, HexEngine, upload!, download!, rhs!, rhsRK!, lsrk!, rhs_lsrk!, lsrk45_step!,
-       dopri45_attempt!, dopri45_next_dt, setup_errors!, l2_error, nodal_error, boundary_velocity_error, rhs, destroy!
+       dopri45_attempt!, dopri45_next_dt, setup_errors!, l2_error, nodal_error, boundary_velocity_error, rhs, destroy!,
+       Setup, setup_uniform_quad_mesh, setup_uniform_hex_mesh, setup_quad, setup_hex, setup_array, setup_map, setup_destroy!,
+       set_device, device_count, comm_unique_id, comm_init!, comm_size, comm_allreduce, comm_destroy!, halo_exchange!, halo_wait!
 
 const LIB = joinpath(@__DIR__, "..", "esdg_cns_amd", "libesdg_hip.so")   # built by `python -m esdg_cns_amd.build`
 
@@ -67,6 +69,22 @@ end
 
 dense(A) = Matrix{Float64}(A)          # rd/ops fields may be SparseMatrixCSC (SetupDG.jl:59-70)
 
+"""
+Element-index sharding of one engine (one process per GPU): the local elements are the global elements
+`rank_offsets[rank+1]+1 : rank_offsets[rank+2]` (0-based offsets, length nranks+1), `md` holds only those and `md.mapP`
+GLOBAL 1-based indices into (Nfq x Kglobal) -- what `setup_quad(...; e_begin, e_end)` produces.  `NoShard` = one rank.
+"""
+struct Shard
+    rank::Int; nranks::Int; rank_offsets::Vector{Int64}; Kglobal::Int
+end
+const NoShard = Shard(0, 1, Int64[], 0)
+"(elem_offset, Kglobal, nranks, rank, rank_offsets) of esdg_mesh_t / esdg_hex_mesh_t"
+function shard_fields(s::Shard, K, keep)
+    s.nranks == 1 && return (Int64(0), Int64(K), Int32(1), Int32(0), Ptr{Int64}(C_NULL))
+    push!(keep, s.rank_offsets)
+    (s.rank_offsets[s.rank + 1], Int64(s.Kglobal), Int32(s.nranks), Int32(s.rank), pointer(s.rank_offsets))
+end
+
 mutable struct Engine
     ctx::Ptr{Cvoid}; ws::Ptr{Cvoid}; K::Int; Np::Int; nfld::Int
     Qd::Ptr{Float64}; rhsd::Ptr{Float64}; resd::Ptr{Float64}     # device state [nfld][K][Np]
@@ -96,7 +114,7 @@ function destroy!(e::Engine)
 end
 
 "Euler-quad driver (examples/dg2D_euler_quad.jl, after line 91): Q lives at the Gauss nodes; LF factor .5 (:165)."
-function Engine(rd, md, ops, Ef; lf_scale = 0.5)
+function Engine(rd, md, ops, Ef; lf_scale = 0.5, shard = NoShard)
     Qrhskew, Qshskew, _, _, _, Ph, Lf = ops                       # dg2D_euler_quad.jl:91
     k = Any[dense(Qrhskew), dense(Qshskew), dense(Ph), Vector{Float64}(rd.wq), Vector{Float64}(rd.wf), dense(Ef), dense(Lf)]
     Nq, Nfq = length(rd.wq), length(rd.wf)
@@ -104,7 +122,7 @@ function Engine(rd, md, ops, Ef; lf_scale = 0.5)
              C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL)
     m = MeshT(md.K, size(md.rxJ, 1), pointer(md.rxJ), pointer(md.sxJ), pointer(md.ryJ), pointer(md.syJ),
               pointer(md.J), pointer(md.wJq), pointer(md.nxJ), pointer(md.nyJ), pointer(md.sJ),
-              pointer(md.mapP), C_NULL, 0, C_NULL, 0, md.K, 1, 0, C_NULL, C_NULL)
+              pointer(md.mapP), C_NULL, 0, C_NULL, shard_fields(shard, md.K, k)..., C_NULL)
     p = PhysT(EULER_COLLOCATED, lf_scale, 1, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
     ctx = Ref{Ptr{Cvoid}}()
     GC.@preserve k md check(ccall((:esdg_create, LIB), Cint, (Ref{OpsT}, Ref{MeshT}, Ref{PhysT}, Ref{Ptr{Cvoid}}), o, m, p, ctx))
@@ -119,7 +137,8 @@ BCTYPE = 4: `md.mapB = [leftwall; rightwall]`, `lid[i] = 1` on the inflow side, 
 `viscous_dissp = false` (dg2D_CNS_modalESDG.jl:161-217).
 """
 function CnsEngine(rd, md, ops; Re, mu, lambda, Pr, BCTYPE = 1, inviscid_dissp = true, viscous_dissp = true,
-                   lid = nothing, vlid = nothing, inflow = (0.0, 0.0, 0.0, 0.0), lf_scale = 0.25, formulation = CNS_MODAL)
+                   lid = nothing, vlid = nothing, inflow = (0.0, 0.0, 0.0, 0.0), lf_scale = 0.25, formulation = CNS_MODAL,
+                   shard = NoShard)
     Qrhskew, Qshskew, VhP, Ph, LIFT, Vq = ops
     k = Any[dense(Qrhskew), dense(Qshskew), dense(Ph), Vector{Float64}(rd.wq), Vector{Float64}(rd.wf),
             dense(Vq), dense(rd.Pq), dense(VhP), dense(LIFT), dense(rd.Vf), dense(rd.Dr), dense(rd.Ds)]
@@ -133,7 +152,7 @@ function CnsEngine(rd, md, ops; Re, mu, lambda, Pr, BCTYPE = 1, inviscid_dissp =
     m = MeshT(md.K, size(md.rxJ, 1), pointer(md.rxJ), pointer(md.sxJ), pointer(md.ryJ), pointer(md.syJ),
               pointer(md.J), pointer(md.wJq), pointer(md.nxJ), pointer(md.nyJ), pointer(md.sJ),
               pointer(md.mapP), isempty(mapB) ? C_NULL : pointer(mapB), length(mapB), isempty(bk) ? C_NULL : pointer(bk),
-              0, md.K, 1, 0, C_NULL, isempty(vl) ? C_NULL : pointer(vl))
+              shard_fields(shard, md.K, k)..., isempty(vl) ? C_NULL : pointer(vl))
     p = PhysT(formulation, lf_scale, Int32(inviscid_dissp), Int32(viscous_dissp), BCTYPE, Re, mu, lambda, Pr, inflow...)
     ctx = Ref{Ptr{Cvoid}}()
     GC.@preserve k md check(ccall((:esdg_create, LIB), Cint, (Ref{OpsT}, Ref{MeshT}, Ref{PhysT}, Ref{Ptr{Cvoid}}), o, m, p, ctx))
@@ -141,13 +160,13 @@ function CnsEngine(rd, md, ops; Re, mu, lambda, Pr, BCTYPE = 1, inviscid_dissp =
 end
 
 "dg3D_euler_hex.jl after line 98; lf_scale = the literal 0*.25 of line 193"
-function HexEngine(rd, md, Qrhskew, Qshskew, Qthskew, Ph, Lf, Ef; lf_scale = 0.0)
+function HexEngine(rd, md, Qrhskew, Qshskew, Qthskew, Ph, Lf, Ef; lf_scale = 0.0, shard = NoShard)
     k = Any[dense(Qrhskew), dense(Qshskew), dense(Qthskew), dense(Ph), dense(Lf), dense(Ef),
             Vector{Float64}(rd.wq), Vector{Float64}(rd.wf)]
     Nq, Nfq = length(rd.wq), length(rd.wf)
     o = HexOpsT(Int32(round(Int, cbrt(Nq)) - 1), Nq, Nfq, pointer.(k)...)
     m = HexMeshT(md.K, size(md.rxJ, 1), pointer.((md.rxJ, md.sxJ, md.txJ, md.ryJ, md.syJ, md.tyJ, md.rzJ, md.szJ, md.tzJ,
-                 md.J, md.wJq, md.nxJ, md.nyJ, md.nzJ, md.sJ))..., pointer(md.mapP), 0, md.K, 1, 0, C_NULL)
+                 md.J, md.wJq, md.nxJ, md.nyJ, md.nzJ, md.sJ))..., pointer(md.mapP), shard_fields(shard, md.K, k)...)
     p = PhysT(EULER_HEX_COLLOCATED, lf_scale, 1, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
     ctx = Ref{Ptr{Cvoid}}()
     GC.@preserve k md check(ccall((:esdg_create_hex, LIB), Cint, (Ref{HexOpsT}, Ref{HexMeshT}, Ref{PhysT}, Ref{Ptr{Cvoid}}), o, m, p, ctx))
@@ -253,6 +272,122 @@ function boundary_velocity_error(e::Engine, Jf)
                 e.ctx, e.Qd, Jf, out, C_NULL))
     out[1], out[2]
 end
+
+# ---- set-up inside the library (INTEGRATION.md section 3) -------------------------------------------------------
+# The reference's build_periodic_boundary_maps is O(Nbfaces^2) (src/node_map_functions.jl:66-128) and connect_mesh sorts
+# all faces: neither gets to 2048^2 elements.  esdg_setup_* (csrc/esdg_setup.cpp) builds the same RefElemData / MeshData /
+# driver operators in O(K log K), for an element range when the mesh is sharded; arrays come back by the SetupDG field
+# names (column-major, maps 1-based Int64), ready for `Engine` / `CnsEngine` / `HexEngine` through `setup_fill`.
+mutable struct Setup
+    h::Ptr{Cvoid}
+end
+setup_error() = unsafe_string(ccall((:esdg_setup_last_error, LIB), Cstring, ()))
+scheck(rc) = rc == 0 || error(setup_error())
+
+"uniform_quad_mesh(Kx,Ky) (src/UniformQuadMesh.jl:25-50): (VX, VY, EToV) on [-1,1]^2, EToV (K x 4), 1-based"
+function setup_uniform_quad_mesh(Kx, Ky)
+    VX, VY = zeros((Kx + 1) * (Ky + 1)), zeros((Kx + 1) * (Ky + 1))
+    EToV = zeros(Int64, Kx * Ky, 4)
+    scheck(ccall((:esdg_setup_uniform_quad_mesh, LIB), Cint, (Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}), Kx, Ky, VX, VY, EToV))
+    VX, VY, EToV
+end
+"uniform_hex_mesh(Kx,Ky,Kz) (src/UniformHexMesh.jl:25-80): (VX, VY, VZ, EToV), EToV (K x 8)"
+function setup_uniform_hex_mesh(Kx, Ky, Kz)
+    n = (Kx + 1) * (Ky + 1) * (Kz + 1)
+    VX, VY, VZ = zeros(n), zeros(n), zeros(n)
+    EToV = zeros(Int64, Kx * Ky * Kz, 8)
+    scheck(ccall((:esdg_setup_uniform_hex_mesh, LIB), Cint, (Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}),
+                 Kx, Ky, Kz, VX, VY, VZ, EToV))
+    VX, VY, VZ, EToV
+end
+"init_reference_quad + init_mesh + periodic patch + driver operators for elements e_begin+1:e_end (0-based range; e_end <= 0: all)"
+function setup_quad(N, formulation, VX, VY, EToV; periodic = true, e_begin = 0, e_end = 0)
+    h = Ref{Ptr{Cvoid}}()
+    scheck(ccall((:esdg_setup_quad, LIB), Cint,
+                 (Cint, Cint, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int64}, Int64, Cint, Int64, Int64, Ref{Ptr{Cvoid}}),
+                 N, formulation, VX, VY, length(VX), EToV, size(EToV, 1), periodic, e_begin, e_end, h))
+    Setup(h[])
+end
+"init_reference_hex + init_mesh (3D) + periodic patch + the operators of dg3D_euler_hex.jl:34-98"
+function setup_hex(N, VX, VY, VZ, EToV; periodic = true, e_begin = 0, e_end = 0)
+    h = Ref{Ptr{Cvoid}}()
+    scheck(ccall((:esdg_setup_hex, LIB), Cint,
+                 (Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int64}, Int64, Cint, Int64, Int64, Ref{Ptr{Cvoid}}),
+                 N, VX, VY, VZ, length(VX), EToV, size(EToV, 1), periodic, e_begin, e_end, h))
+    Setup(h[])
+end
+"array by its SetupDG field name (\"Vq\", \"x\", \"rxJ\", \"Qrhskew\", ...): a Matrix{Float64} VIEW of library memory"
+function setup_array(s::Setup, name)
+    r, c = Ref{Int64}(), Ref{Int64}()
+    p = ccall((:esdg_setup_array, LIB), Ptr{Float64}, (Ptr{Cvoid}, Cstring, Ref{Int64}, Ref{Int64}), s.h, name, r, c)
+    p == C_NULL && error("no array $name: " * setup_error())
+    unsafe_wrap(Array, p, (Int(r[]), Int(c[])))
+end
+"index map by name (\"mapM\", \"mapP\", \"mapB\", \"FToF\"), 1-based Int64"
+function setup_map(s::Setup, name)
+    n = Ref{Int64}()
+    p = ccall((:esdg_setup_map, LIB), Ptr{Int64}, (Ptr{Cvoid}, Cstring, Ref{Int64}), s.h, name, n)
+    p == C_NULL && error("no map $name: " * setup_error())
+    unsafe_wrap(Array, p, Int(n[]))
+end
+"esdg_ops_t / esdg_mesh_t pointing into the set-up object, then esdg_create: an Engine without a Julia-side SetupDG"
+function Engine(s::Setup, phys::PhysT; shard = NoShard)
+    o, m = Ref{OpsT}(), Ref{MeshT}()
+    scheck(ccall((:esdg_setup_fill, LIB), Cint, (Ptr{Cvoid}, Ref{OpsT}, Ref{MeshT}), s.h, o, m))
+    keep = Any[s]
+    mm = m[]
+    if shard.nranks > 1                                        # esdg_setup_fill leaves one rank; patch the shard in
+        f = shard_fields(shard, mm.K, keep)
+        mm = MeshT(mm.K, mm.geo_ld, mm.rxJ, mm.sxJ, mm.ryJ, mm.syJ, mm.J, mm.wJq, mm.nxJ, mm.nyJ, mm.sJ, mm.mapP, mm.mapB, mm.NmapB,
+                   mm.bkind, f[1], f[2], f[3], f[4], f[5], mm.vlid)
+    end
+    ctx = Ref{Ptr{Cvoid}}()
+    GC.@preserve keep check(ccall((:esdg_create, LIB), Cint, (Ref{OpsT}, Ref{MeshT}, Ref{PhysT}, Ref{Ptr{Cvoid}}), o, mm, phys, ctx))
+    finish_engine(ctx[], Int(mm.K), Int(o[].Np), keep)
+end
+function HexEngine(s::Setup; lf_scale = 0.0, shard = NoShard)
+    o, m = Ref{HexOpsT}(), Ref{HexMeshT}()
+    scheck(ccall((:esdg_setup_fill_hex, LIB), Cint, (Ptr{Cvoid}, Ref{HexOpsT}, Ref{HexMeshT}), s.h, o, m))
+    keep = Any[s]
+    mm = m[]
+    if shard.nranks > 1
+        f = shard_fields(shard, mm.K, keep)
+        mm = HexMeshT(mm.K, mm.geo_ld, mm.rxJ, mm.sxJ, mm.txJ, mm.ryJ, mm.syJ, mm.tyJ, mm.rzJ, mm.szJ, mm.tzJ, mm.J, mm.wJq,
+                      mm.nxJ, mm.nyJ, mm.nzJ, mm.sJ, mm.mapP, f[1], f[2], f[3], f[4], f[5])
+    end
+    p = PhysT(EULER_HEX_COLLOCATED, lf_scale, 1, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+    ctx = Ref{Ptr{Cvoid}}()
+    GC.@preserve keep check(ccall((:esdg_create_hex, LIB), Cint, (Ref{HexOpsT}, Ref{HexMeshT}, Ref{PhysT}, Ref{Ptr{Cvoid}}), o, mm, p, ctx))
+    finish_engine(ctx[], Int(mm.K), Int(o[].Nq), keep)
+end
+function setup_destroy!(s::Setup)
+    ccall((:esdg_setup_destroy, LIB), Cint, (Ptr{Cvoid},), s.h)
+    s.h = C_NULL
+end
+
+# ---- one process per GPU: device selection and the library's RCCL transport (INTEGRATION.md section 4) -----------
+device_count() = Int(ccall((:esdg_device_count, LIB), Cint, ()))
+set_device(d) = check(ccall((:esdg_set_device, LIB), Cint, (Cint,), d))
+"128 bytes of ncclUniqueId: create on ONE rank, hand to the others (MPI.Bcast!, a file, a socket), then comm_init! everywhere"
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:esdg_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id))
+    id
+end
+"attach the communicator (collective); afterwards rhs! / rhs_lsrk! / lsrk45_step! / dopri45_attempt! run the sharded schedule"
+comm_init!(e::Engine, id::Vector{UInt8}, rank, nranks) =
+    check(ccall((:esdg_comm_init, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), e.ctx, id, rank, nranks))
+comm_size(e::Engine) = Int(ccall((:esdg_comm_size, LIB), Cint, (Ptr{Cvoid},), e.ctx))
+comm_destroy!(e::Engine) = check(ccall((:esdg_comm_destroy, LIB), Cint, (Ptr{Cvoid},), e.ctx))
+"sum (op = 0) / max (1) / min (2) of a few host doubles over the ranks: rhstest, the DOPRI error norm, dt"
+function comm_allreduce(e::Engine, vals::Vector{Float64}; op = 0)
+    v = copy(vals)
+    check(ccall((:esdg_comm_allreduce, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint, Cint, Ptr{Cvoid}), e.ctx, v, length(v), op, C_NULL))
+    v
+end
+"the two transport steps for hosts that drive the phases themselves (esdg_rhs_phase / esdg_halo_pack)"
+halo_exchange!(e::Engine, phase) = check(ccall((:esdg_halo_exchange, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}), e.ctx, phase, C_NULL))
+halo_wait!(e::Engine, phase) = check(ccall((:esdg_halo_wait, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}), e.ctx, phase, C_NULL))
 
 # ---- literal drop-in with host arrays (PCIe-bound; validation only) -------------------------------------------
 "`rhs(Q, md, ops, flux_fun, compute_rhstest)` of the Euler drivers with an engine in place of (md, ops): returns (rhsQ, rhstest)"

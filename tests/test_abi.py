@@ -99,4 +99,22 @@ def test_julia_shim_mirrors_the_header():
             size = 8 if t.startswith("Ptr{") else width[t]
             assert size == C.sizeof(cf[1]), (name, f, t)
     called = set(re.findall(r"\(:(esdg_[a-z0-9_]+), LIB\)", jl))
-    assert len(called) > 20 and called <= set(_declared_functions()), called - set(_declared_functions())
+    declared = set(_declared_functions())
+    assert len(called) > 20 and called <= declared, called - declared
+    # every symbol of the header is either bound by the shim or listed here with the reason a Julia driver does not need it
+    not_needed = {
+        # per-phase / per-range drivers and the plan inspection: the library runs the sharded schedule itself once a
+        # communicator is attached (esdg_comm_init); hosts that want their own transport bind these
+        "esdg_rhs_phase", "esdg_rhs_phase_lsrk", "esdg_rhs_phase_range", "esdg_rhs_phase_range_lsrk", "esdg_halo_pack",
+        "esdg_num_phases", "esdg_interior_range", "esdg_halo_num_neighbors", "esdg_num_exchanges", "esdg_exchange_info",
+        "esdg_halo_segment", "esdg_halo_plan_create", "esdg_halo_plan_destroy", "esdg_halo_plan_num_neighbors",
+        "esdg_halo_plan_num_ghosts", "esdg_halo_plan_num_sends", "esdg_halo_plan_neighbor", "esdg_halo_plan_mapP",
+        "esdg_halo_plan_sendlist", "esdg_comm_set_loopback",
+        # diagnostics / introspection
+        "esdg_version", "esdg_uses_tensor_kernels", "esdg_check_state", "esdg_debug_log", "esdg_device_synchronize",
+        # building blocks of entry points the shim binds whole (esdg_dopri45_attempt)
+        "esdg_axpy_stages", "esdg_dopri_error",
+    }
+    unbound = declared - called
+    assert unbound <= not_needed, sorted(unbound - not_needed)
+    assert not (not_needed & called), sorted(not_needed & called)

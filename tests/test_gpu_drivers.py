@@ -108,9 +108,17 @@ def test_lsrk45_hip_graph_replay_is_bitwise_equal_and_faster_on_cfg1():
     t1 = time.perf_counter()
     g = timestep.lsrk45_run_graph(eng, Q2, dt, 0)        # capture only
     torch.cuda.synchronize()
+    # allocations and writes between capture and replay must not be able to alias the graph's residual buffer: the graph
+    # object keeps it (and Q2) alive (g.esdg_buffers)
+    assert g.esdg_buffers[0] is Q2
+    junk = [torch.full_like(Q2, float("nan")) for _ in range(4)]
+    junk.append(eng.rhs(Q1))
+    torch.cuda.synchronize()
     t1b = time.perf_counter()
-    for _ in range(nsteps):
+    for i in range(nsteps):
         g.replay()
+        if i % 7 == 0:
+            junk[i % 4] = torch.full_like(Q2, float(i))
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f"cfg1 LSRK45: {1e6 * (t1 - t0) / nsteps:.1f} us/step stage-by-stage, {1e6 * (t2 - t1b) / nsteps:.1f} us/step graph replay "

@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 key = sys.argv[2] if len(sys.argv) > 2 else "cns_N4_512x512"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
@@ -27,6 +27,18 @@ def per_kernel(path, counter):
 
 f = per_kernel(os.path.join(src, "fetch_counters.csv"), "FETCH_SIZE")
 w = per_kernel(os.path.join(src, "write_counters.csv"), "WRITE_SIZE")
+# fp64 VALU work: wave-instructions by kind (one pass); flops = 64 lanes x (ADD + MUL + TRANS + 2 FMA).  Lanes switched
+# off by EXEC still occupy their issue slot, so this is the issued fp64 work the 78.6 TFLOP/s vector peak is quoted for.
+valu = {}
+vpath = os.path.join(src, "valu_counters.csv")
+if os.path.exists(vpath):
+    parts = {c: per_kernel(vpath, c) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64",
+                                               "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU", "SQ_WAVES")}
+    for k in parts["SQ_INSTS_VALU"]:
+        a, m, fm, t = (parts[c].get(k, 0.0) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64",
+                                                       "SQ_INSTS_VALU_TRANS_F64"))
+        valu[k] = {"insts_valu": parts["SQ_INSTS_VALU"][k], "insts_f64": a + m + fm + t, "waves": parts["SQ_WAVES"].get(k, 0.0),
+                   "fp64_flops": 64.0 * (a + m + t + 2 * fm)}
 out = {}
 for k in sorted(set(f) | set(w)):
     if "esdg::" not in k:
@@ -34,6 +46,7 @@ for k in sorted(set(f) | set(w)):
     rd_raw, wr = f.get(k, 0.0) * 1024, w.get(k, 0.0) * 1024
     out[k] = {"fetch_bytes_raw": rd_raw, "fetch_bytes_x2": 2 * rd_raw, "write_bytes": wr,
               "hbm_bytes_per_launch": 2 * rd_raw + wr}
+    out[k].update(valu.get(k, {}))
 dst = os.path.join(root, "profiles", "pmc_traffic.json")
 allj = json.load(open(dst)) if os.path.exists(dst) else {}
 rhs = [v for k, v in out.items() if "_rhs<" in k]
@@ -49,10 +62,18 @@ for k in out:
     if k in avg_us:
         out[k]["rocprofv3_avg_us"] = avg_us[k]
 rhs_name = [k for k in out if "_rhs<" in k]
+sys.path.insert(0, root)
+import bench  # noqa: E402
+main = {k: v for k, v in out.items() if any(t in k for t in ("kt_project", "kt_sigma", "kt_rhs", "kh_project", "kh_rhs"))}
+extra = {"kernel_src_sha": bench.kernel_source_hash(),
+         "whole_rhs_hbm_bytes": sum(v["hbm_bytes_per_launch"] for v in main.values()),
+         "whole_rhs_fp64_flops": sum(v.get("fp64_flops", 0.0) for v in main.values()) or None,
+         "k_rhs_fp64_flops_per_launch": (rhs[0].get("fp64_flops") if rhs else None)}
 allj[key] = {"source": f"gpurun_out/prof_{tag} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; durations from the "
                        "--kernel-trace --stats pass)",
              "kernels": out, "k_rhs_hbm_bytes_per_launch": rhs[0]["hbm_bytes_per_launch"] if rhs else None,
              "k_rhs_rocprofv3_avg_us": avg_us.get(rhs_name[0]) if rhs_name else None}
+allj[key].update(extra)
 json.dump(allj, open(dst, "w"), indent=1)
 for k, v in out.items():
     print(f"{k:45s} fetch(raw) {v['fetch_bytes_raw']/1e6:9.1f} MB  x2 {v['fetch_bytes_x2']/1e6:9.1f} MB  write {v['write_bytes']/1e6:9.1f} MB")
