@@ -291,6 +291,71 @@ bool build_tensor_host(int N1, const Mat& Qr, const Mat& Qs, const Mat& PhC, con
   return true;
 }
 
+// per-node rows of the v2 tensor kernels (NodeLayout / FaceLayout in esdg_tensor_tables.hpp) from the verified 1D tables
+struct NodeHost {
+  std::vector<double> nd, fd;
+  std::vector<int32_t> ni, fi;
+  int gface[4] = {0, 0, 0, 0};
+};
+
+void build_node_host(int N1, const TensorHost& H, NodeHost& T) {
+  const TensorLayout L(N1);
+  const NodeLayout NL(N1);
+  const FaceLayout FL(N1);
+  const int Nq = N1 * N1, Nfq = 4 * N1;
+  const double* D = H.dbl.data();
+  const int32_t* I = H.ints.data();
+  T.nd.assign((size_t)Nq * NL.LD, 0.0);
+  T.ni.assign((size_t)Nq * NL.LI, 0);
+  T.fd.assign((size_t)Nfq * FL.LD, 0.0);
+  T.fi.assign((size_t)Nfq * FL.LI, 0);
+  for (int q = 0; q < Nq; ++q) {
+    const int a = q % N1, b = q / N1;
+    double* r = &T.nd[(size_t)q * NL.LD];
+    int32_t* ri = &T.ni[(size_t)q * NL.LI];
+    for (int i = 0; i < N1; ++i) {
+      r[NL.IQ + i] = D[L.IQ + a * N1 + i];
+      r[NL.IPL + i] = D[L.IP + a * N1 + i];
+      r[NL.IPH + i] = D[L.IP + b * N1 + i];
+      r[NL.DG0 + i] = D[L.DG + (0 * N1 + a) * N1 + i];
+      r[NL.DG1 + i] = D[L.DG + (1 * N1 + b) * N1 + i];
+    }
+    for (int d = 0; d < 2; ++d) {
+      const int pos = d == 0 ? a : b, oth = d == 0 ? b : a, stride = d == 0 ? 1 : N1;
+      for (int t = 0; t < 2; ++t) {
+        const int k = 2 * d + t, f = I[L.FN + k * N1 + oth];
+        const double pw = D[L.PF + k * N1 + pos] * D[L.PTF + k * N1 + oth];
+        r[NL.PW + k] = pw;
+        r[NL.LW + k] = pw * D[L.WFAC + f];
+        r[NL.SVF + k] = D[L.SF + k * N1 + pos] * D[L.WTF + k * N1 + oth];
+        ri[NL.FQ + k] = f;
+      }
+      for (int i = 0; i < NL.NFULL; ++i) {
+        const int pp = (pos + i + 1) % N1;
+        r[NL.SVV + d * NL.NFULL + i] = D[L.S + (d * N1 + pos) * N1 + pp] * D[L.WT + d * N1 + oth];
+        ri[NL.PID + d * NL.NFULL + i] = q + (pp - pos) * stride;
+      }
+    }
+    if (N1 % 2 == 0) {   // antipodal round: nodes with (a >= H) != (b >= H) serve their d = 0 pair, the others d = 1
+      const int Hh = N1 / 2, d = ((a >= Hh) != (b >= Hh)) ? 0 : 1;
+      const int pos = d == 0 ? a : b, oth = d == 0 ? b : a, stride = d == 0 ? 1 : N1, pp = (pos + Hh) % N1;
+      r[NL.SVV + 2 * NL.NFULL] = D[L.S + (d * N1 + pos) * N1 + pp] * D[L.WT + d * N1 + oth];
+      ri[NL.PID + 2 * NL.NFULL] = q + (pp - pos) * stride;
+      ri[NL.AD] = d;
+    }
+    r[NL.PD] = D[L.PD + q];
+  }
+  for (int f = 0; f < Nfq; ++f) {
+    const int w = I[L.FINV + f], d = w & 1, t = (w >> 1) & 1, o = w >> 2, k = 2 * d + t;
+    for (int j = 0; j < N1; ++j) T.fd[(size_t)f * FL.LD + FL.EE + j] = D[L.EE + k * N1 + j];
+    T.fd[(size_t)f * FL.LD + FL.WFAC] = D[L.WFAC + f];
+    T.fi[(size_t)f * FL.LI + FL.NODE0] = d == 0 ? N1 * o : o;
+    T.fi[(size_t)f * FL.LI + FL.STRIDE] = d == 0 ? 1 : N1;
+    T.fi[(size_t)f * FL.LI + FL.K] = k;
+    T.gface[k] = f / N1;
+  }
+}
+
 // Host image of the hexahedral 1D tables (esdg_hex_tables.hpp), derived from the dense matrices of the driver
 // (Qrhskew/Qshskew/Qthskew, Ph, Lf, Ef of dg3D_euler_hex.jl:34-98) and verified entry by entry (1e-11).
 struct HexHost {
@@ -486,6 +551,7 @@ struct esdg_ctx {
   Tables T{};
   TensorTables TT{};
   bool use_fast = false;
+  bool v1 = false;         // ESDG_V1=1 in the environment: round-1 tensor kernels only (A/B against esdg_kernels_tensor2.hip)
   int dim = 2, nfld = 4;   // 3 / 5 on the hexahedral path
   HexTables HT{};
   int au_nc = AU_NC;
@@ -498,6 +564,7 @@ struct esdg_ctx {
   DevBuf d_pair_ij, d_pair_c, d_inc_ptr, d_inc, d_Ef_i, d_Ef_v, d_Ph_i, d_Ph_v, d_Lf_i, d_Lf_v, d_Dr_i, d_Dr_v, d_Ds_i,
       d_Ds_v, d_Vq, d_Pq, d_geo, d_mapP, d_bc, d_vlid, d_wJq, d_sendlist, d_partial;
   DevBuf t_dbl, t_int, d_G9, d_Jq, d_nrm;
+  DevBuf t_nd, t_ni, t_fd, t_fi;   // per-node rows of the v2 tensor kernels
   DevBuf e_Vq2, e_wq2, e_x, e_y, e_J, e_Vf, e_wf;   // error functionals (esdg_error_setup)
   ErrDev E{};
   bool have_err = false;
@@ -637,6 +704,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   c->ph.parts = 3;
   c->ph.dbg = 0;
   if (const char* env = getenv("ESDG_DBG")) c->ph.dbg = atoi(env);
+  if (const char* env = getenv("ESDG_V1")) c->v1 = env[0] == '1';
 
   // ---- collocated sparse operators -------------------------------------------------------
   Mat EfD, PhC, LfC, DrC, DsC, Vq, Pq;
@@ -817,6 +885,12 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
     c->TT.ints = c->t_int.as<int>();
     c->TT.op0 = th.op[0];
     c->TT.op1 = th.op[1];
+    NodeHost nh;
+    build_node_host(N1, th, nh);
+    UP(t_nd, nh.nd); UP(t_ni, nh.ni); UP(t_fd, nh.fd); UP(t_fi, nh.fi);
+    c->TT.node_d = c->t_nd.as<double>(); c->TT.node_i = c->t_ni.as<int>();
+    c->TT.face_d = c->t_fd.as<double>(); c->TT.face_i = c->t_fi.as<int>();
+    for (int k4 = 0; k4 < 4; ++k4) c->TT.gface[k4] = nh.gface[k4];
   }
   if (mesh->wJq) {
     std::vector<double> w(mesh->wJq, mesh->wJq + (size_t)K * Nq);
@@ -1083,8 +1157,12 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
     rc = ctx->use_fast ? launch_project_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, A_v, s)
                        : launch_project(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, s);
   } else if (visc && phase == 1) {
-    rc = ctx->use_fast ? launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, SG, nullptr, s)
-                       : launch_sigma(ctx->T, ctx->M, ctx->ph, Q, A_v, B, s);
+    // v2 kernel: meshes without walls (the wall closures and the visc_test reduction stay with kt_sigma); ESDG_V1=1: A/B
+    if (ctx->use_fast && !ctx->M.bc && !ctx->v1)
+      rc = launch_sigma_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, SG, s);
+    else
+      rc = ctx->use_fast ? launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, SG, nullptr, s)
+                         : launch_sigma(ctx->T, ctx->M, ctx->ph, Q, A_v, B, s);
   } else {
     if (!rhs && !lf.Qw) return fail(ESDG_ERR_ARG, "rhs output is null");
     if (lf.Qw && !ctx->use_fast) return fail(ESDG_ERR_STATE, "the fused RK update needs the tensor kernels");

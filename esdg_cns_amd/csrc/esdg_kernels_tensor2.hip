@@ -1,0 +1,462 @@
+// esdg_kernels_tensor2.hip -- second generation of the tensor-product kernels for gfx950 (MI355X / CDNA4).
+//
+// Same algorithm, face-trace protocol and lane mapping as esdg_kernels_tensor.hip (reference citations there): a group of
+// GW waves owns E elements, lane t of the group is Gauss node t % Nq of element t / Nq and face node t % Nfq of element
+// t / Nfq.  What changed is everything around the arithmetic.  The round-1 kernels were bound by instruction issue with
+// only half of their VALU instructions doing fp64 math (SQ_INSTS_VALU_*_F64: 795 of 1543 per wave in kt_rhs, 384 of 776
+// in kt_sigma); the rest was index arithmetic on the 1D tables, 64-bit address formation, runtime-direction selects and
+// the EXEC bookkeeping of many small divergent regions.  Here
+//   * every per-node quantity (operator rows, lift / projection / SBP weights, partner and face ids) comes from ONE row of
+//     host-built per-node tables (NodeLayout / FaceLayout, esdg_tensor_tables.hpp), loaded straight into registers;
+//   * both tensor directions are compile-time: LDS addresses are a per-lane base plus an immediate offset;
+//   * all LDS arrays are structure-of-arrays planes [component][E * nodes], so that consecutive lanes touch consecutive
+//     8-byte slots (conflict-free ds_read_b64 / ds_write_b64);
+//   * the per-element geometry records of a group are staged in LDS once;
+//   * lanes without a node compute on duplicated data instead of branching; only stores are masked.
+#include "esdg_dev.hpp"
+#include "esdg_tensor_tables.hpp"
+#include "esdg_devmath.hpp"
+
+namespace esdg {
+namespace t2 {
+
+using namespace devmath;
+
+constexpr int TW = 64;
+
+// waves per group by degree (same choices as TCfg in esdg_kernels_tensor.hip, measured there)
+template <int N1> struct Cfg { static constexpr int GW = 1; };
+template <> struct Cfg<5> { static constexpr int GW = 2; };
+template <> struct Cfg<6> { static constexpr int GW = 4; };
+template <> struct Cfg<7> { static constexpr int GW = 4; };
+
+template <int N1> struct Geo {
+  static constexpr int GW = Cfg<N1>::GW, GT = TW * GW, Nq = N1 * N1, Nfq = 4 * N1;
+  static constexpr int E = (GT / Nq) < (GT / Nfq) ? (GT / Nq) : (GT / Nfq);
+  static constexpr int NV = E * Nq, NF = E * Nfq;   // volume / face lanes of a group
+  static_assert(E >= 1, "group does not hold an element");
+};
+
+constexpr double GM1 = 0.4;   // the CNS drivers' literal (cavity_optimized.jl:463)
+
+// viscous_matrices! + sigma rows 2..4 (cavity :613-645, 786-801); lam already sign-flipped (quirk Q4); gk = gamma*mu/Pr
+__device__ __forceinline__ void viscous_stress(const double* v, const double* tx, const double* ty, double lam, double mu,
+                                               double gk, double* sx, double* sy) {
+  const double v2 = v[0], v3 = v[1], v4 = v[2];
+  const double i1 = rcp_refined(v4);
+  const double i2 = i1 * i1, i3 = i2 * i1;
+  const double l2m = lam + 2.0 * mu;
+  const double a24 = v2 * i2, a34 = v3 * i2;
+  const double Kxx22 = -l2m * i1, Kxx24 = l2m * a24, Kxx33 = -mu * i1, Kxx34 = mu * a34,
+               Kxx44 = -i3 * (l2m * (v2 * v2) + mu * (v3 * v3) - gk * v4);
+  const double Kxy23 = -lam * i1, Kxy24 = lam * a34, Kxy32 = Kxx33, Kxy34 = mu * a24, Kxy42 = Kxx34, Kxy43 = lam * a24,
+               Kxy44 = i3 * (lam + mu) * (-v2 * v3);
+  const double Kyy22 = Kxx33, Kyy24 = Kxy34, Kyy33 = Kxx22, Kyy34 = l2m * a34,
+               Kyy44 = -i3 * (l2m * (v3 * v3) + mu * (v2 * v2) - gk * v4);
+  sx[0] = Kxx22 * tx[0] + Kxx24 * tx[2] + Kxy23 * ty[1] + Kxy24 * ty[2];
+  sx[1] = Kxx33 * tx[1] + Kxx34 * tx[2] + Kxy32 * ty[0] + Kxy34 * ty[2];
+  sx[2] = Kxx24 * tx[0] + Kxx34 * tx[1] + Kxx44 * tx[2] + Kxy42 * ty[0] + Kxy43 * ty[1] + Kxy44 * ty[2];
+  sy[0] = Kxy32 * tx[1] + Kxy42 * tx[2] + Kyy22 * ty[0] + Kyy24 * ty[2];
+  sy[1] = Kxy23 * tx[0] + Kxy43 * tx[2] + Kyy33 * ty[1] + Kyy34 * ty[2];
+  sy[2] = Kxy24 * tx[0] + Kxy34 * tx[1] + Kxy44 * tx[2] + Kyy24 * ty[0] + Kyy34 * ty[1] + Kyy44 * ty[2];
+}
+
+// LDS layout.  Measured on MI355X (tools/ubench/lds_read.hip, 2 waves per SIMD): a ds_read_b64 and a ds_read_b128
+// wave-instruction cost the same LDS time (~4.5 cycles; 119 vs 223 B/clk/CU), ds_read2_b64 costs two.  All arrays are
+// therefore planes of double2 ("pair planes": two components of one node side by side, [pairs][E * nodes], lane stride
+// 16 B = conflict-free ds_read_b128 / ds_write_b128) plus a plane of doubles for an odd component.
+typedef double2 d2;
+
+// Uq = Vq Qn by sum factorisation through the pair planes sA, sB ([2][NV] each).  Nodal values are r-fastest, Gauss
+// nodes s-fastest (SetupDG.jl:244): Vq[(a + N1 b), (i + N1 j)] = IQ[b,i] IQ[a,j].  c = IQ[a][:]; rowb = first slot of
+// row b, colq = slot b of row 0 (both of this lane's element).
+template <int N1>
+__device__ __forceinline__ void vq_apply(const double* c, d2* sA, d2* sB, unsigned tv, unsigned rowb, unsigned colq,
+                                         const double* x, double* U) {
+  constexpr int NV = Geo<N1>::NV;
+  if (x) {
+    sA[tv] = make_double2(x[0], x[1]);
+    sA[NV + tv] = make_double2(x[2], x[3]);
+  }
+  __syncthreads();
+  // stage 1: W[a + N1 b] = sum_i IQ[a,i] Qn[i + N1 b]   (this lane: row b of the nodal values)
+  {
+    const d2* r = sA + rowb;
+    d2 p = r[0], t = r[NV];
+    double w0 = c[0] * p.x, w1 = c[0] * p.y, w2 = c[0] * t.x, w3 = c[0] * t.y;
+#pragma unroll
+    for (int i = 1; i < N1; ++i) {
+      p = r[i]; t = r[NV + i];
+      w0 = __builtin_fma(c[i], p.x, w0); w1 = __builtin_fma(c[i], p.y, w1);
+      w2 = __builtin_fma(c[i], t.x, w2); w3 = __builtin_fma(c[i], t.y, w3);
+    }
+    sB[tv] = make_double2(w0, w1);
+    sB[NV + tv] = make_double2(w2, w3);
+  }
+  __syncthreads();
+  // stage 2: Uq[a + N1 b] = sum_j IQ[a,j] W[b + N1 j]   (this lane: column b of W)
+  {
+    const d2* r = sB + colq;
+    d2 p = r[0], t = r[NV];
+    U[0] = c[0] * p.x; U[1] = c[0] * p.y; U[2] = c[0] * t.x; U[3] = c[0] * t.y;
+#pragma unroll
+    for (int j = 1; j < N1; ++j) {
+      p = r[N1 * j]; t = r[NV + N1 * j];
+      U[0] = __builtin_fma(c[j], p.x, U[0]); U[1] = __builtin_fma(c[j], p.y, U[1]);
+      U[2] = __builtin_fma(c[j], t.x, U[2]); U[3] = __builtin_fma(c[j], t.y, U[3]);
+    }
+  }
+}
+
+// The kernels are PERSISTENT: a workgroup (= one group of GW waves) walks the element groups blockIdx.x, blockIdx.x +
+// gridDim.x, ... and issues the global loads of its next group before it computes on the current one.  One-shot
+// workgroups had only the loads of the groups that happened to be in their first phase in flight (measured: kt2_sigma
+// at 3.4 TB/s of its own traffic with 12-16 waves per CU, no faster with more waves); with the prefetch every resident
+// workgroup keeps ~8 KB in flight all the time, and the per-lane table rows and index arithmetic are paid once.
+// The loads of the NEXT group go into the registers of the current one right after their last use (no second register
+// set, no copies that would have to wait).  What is left on the table: hipcc drains all outstanding vector-memory
+// operations (s_waitcnt vmcnt(0)) at the loop head, i.e. also this iteration's stores (~19 % of an iteration in
+// kt2_sigma by s_memtime stamps); inline-asm loads with counted waits remove that wait, but hipcc then copies the asm
+// destinations between registers before the data has landed (audited in the .s), so the loads stay compiler-managed.
+// grid = what the device holds at once (occupancy query; ESDG_T2_WG_PER_CU overrides for experiments)
+template <class K>
+__host__ inline int persistent_grid(K kernel, int threads, int64_t ngroups) {
+  static int per_cu = 0, cus = 0;     // one kernel per instantiation of this template
+  if (!per_cu) {
+    int dev = 0;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) != hipSuccess || n < 1) n = 2;
+    if (const char* env = getenv("ESDG_T2_WG_PER_CU")) n = atoi(env) > 0 ? atoi(env) : n;
+    per_cu = n;
+  }
+  const int64_t g = (int64_t)cus * per_cu;
+  return (int)(ngroups < g ? ngroups : g);
+}
+
+// Diagnostic build only (-DESDG_T2_STAMP): per-phase wave cycles (s_memtime) summed into a buffer nothing else reads.
+#ifdef ESDG_T2_STAMP
+__device__ unsigned long long g_stamp[16];
+#define T2_STAMP(i)                                                                          \
+  do {                                                                                       \
+    unsigned long long t_;                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    t_acc[i] += t_ - t_prev;                                                                 \
+    t_prev = t_;                                                                             \
+  } while (0)
+#define T2_STAMP_INIT                                                                        \
+  unsigned long long t_prev, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};               \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory")
+#define T2_STAMP_FLUSH                                                                       \
+  if (threadIdx.x == 0)                                                                      \
+    for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_stamp[i_], t_acc[i_])
+#else
+#define T2_STAMP(i)
+#define T2_STAMP_INIT
+#define T2_STAMP_FLUSH
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------------
+// phase 1 (CNS, meshes without walls): sigma = K(v) grad v -> normal-stress traces B and the volume part of div sigma
+// (rhs_viscous! :749-815 in collocated form, dg_grad! :548-569; see kt_sigma in esdg_kernels_tensor.hip)
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef ESDG_T2_SIGMA_WPE
+#define ESDG_T2_SIGMA_WPE 1   // minimum waves per SIMD asked of the register allocator (A/B hook)
+#endif
+// FULL = true: persistent over the complete groups of the launch's element range; every lane holds valid data (lanes
+// beyond a group's slots duplicate slot tid - NV / tid % NF), so nothing is masked -- duplicate lanes store the same
+// value to the same address -- and no branch hides the outstanding-store count from the compiler's s_waitcnt placement.
+// FULL = false: the one partial group at the end of the range (one workgroup, masked stores); same arithmetic.
+template <int N1, bool FULL>
+__global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
+                                                        const double* __restrict__ A_U, double* __restrict__ B,
+                                                        double* __restrict__ SG) {
+  using G = Geo<N1>;
+  constexpr int Nq = G::Nq, Nfq = G::Nfq, E = G::E, NV = G::NV, NF = G::NF;
+  constexpr NodeLayout NL(N1);
+  constexpr FaceLayout FL(N1);
+  // LDS arena in doubles.  R0: Vq scratch A|B (4 pair planes), later sigma (3 pair planes: (sx0,sx1) (sx2,sy0) (sy1,sy2))
+  // and the pair plane of S^0; R1: pair plane of S^1, single planes S^0_2, S^1_2; then V (pair (v2,v3) + single v4),
+  // the half jumps (pair + single, face nodes) and the geometry records of the group's elements.
+  constexpr int NVP = NV + (NV & 1), NFP = NF + (NF & 1);   // single planes padded to an even length: pair planes stay 16-B aligned
+  constexpr int NGEO = E * GEO_STRIDE, GPT = (NGEO + G::GT - 1) / G::GT;   // geometry doubles of a group / per thread
+  constexpr int R0 = 0, R1 = 8 * NV, RV = R1 + 2 * NV + 2 * NVP, RD = RV + 2 * NV + NVP, RG = RD + 2 * NF + NFP,
+                NLDS = RG + GPT * G::GT;
+  __shared__ __align__(16) double lds[NLDS];
+  d2* sSg = reinterpret_cast<d2*>(lds + R0);          // [3][NV] sigma pairs
+  d2* sS0 = reinterpret_cast<d2*>(lds + R0 + 6 * NV); // [NV] (S^0_0, S^0_1)
+  d2* sS1 = reinterpret_cast<d2*>(lds + R1);          // [NV] (S^1_0, S^1_1)
+  double* sS02 = lds + R1 + 2 * NV;                   // [NV] S^0_2
+  double* sS12 = lds + R1 + 2 * NV + NVP;             // [NV] S^1_2
+  d2* sVp = reinterpret_cast<d2*>(lds + RV);          // [NV] (v2, v3)
+  double* sV4 = lds + RV + 2 * NV;                    // [NV] v4
+  d2* sDp = reinterpret_cast<d2*>(lds + RD);          // [NF] half jumps of (v2, v3)
+  double* sD4 = lds + RD + 2 * NF;                    // [NF] half jump of v4
+  double* sGeo = lds + RG;
+  static_assert((R1 % 2) == 0 && (RV % 2) == 0 && (RD % 2) == 0, "pair planes must be 16-byte aligned");
+
+  const unsigned tid = threadIdx.x;
+  // Lanes beyond the group's NV volume / NF face slots redo the work of slot tid - NV / tid % NF (same loads, same
+  // values: their LDS writes are duplicates), slots of elements beyond the mesh compute on the data of slot 0: no
+  // divergent regions, only the global stores are masked.
+  const unsigned tv = tid < (unsigned)NV ? tid : tid - NV;              // volume slot
+  const unsigned tf = tid < (unsigned)NF ? tid : tid % NF;              // face slot
+  const unsigned ev = tv / Nq, q = tv - ev * Nq, a = q % N1, b = q / N1;
+  const unsigned ef = tf / Nfq, fn = tf - ef * Nfq;
+  const unsigned rowb = ev * Nq + N1 * b, colb = ev * Nq + a;           // first node of this lane's d = 0 / d = 1 line
+  const int64_t KN = M.K * Nq;
+
+  // per-lane table rows, once per workgroup
+  const double* nd = TT.node_d + q * NL.LD;
+  const int* ni = TT.node_i + q * NL.LI;
+  const double* fd = TT.face_d + fn * FL.LD;
+  const int* fi = TT.face_i + fn * FL.LI;
+  double cq[N1], dg0[N1], dg1[N1], ee[N1], lw[4];
+#pragma unroll
+  for (int i = 0; i < N1; ++i) { cq[i] = nd[NL.IQ + i]; dg0[i] = nd[NL.DG0 + i]; dg1[i] = nd[NL.DG1 + i]; ee[i] = fd[FL.EE + i]; }
+  unsigned fq[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { lw[k] = nd[NL.LW + k]; fq[k] = ev * Nfq + ni[NL.FQ + k]; }
+  const unsigned fnode0 = ef * Nq + fi[FL.NODE0], fstride = fi[FL.STRIDE];
+  const unsigned gfo = 5 + 3 * (fn / N1);
+
+  const int64_t e_end = M.e_begin + M.e_count;
+  const int64_t nfull = M.e_count / E;
+  const int64_t ngrp = FULL ? nfull : nfull + 1;
+  // ---- prologue: loads of the first group ---------------------------------------------------------------------------
+  // Prefetch without a second register set: the loads of the NEXT group go into the registers of the current one right
+  // after their last use (x and the geometry are written to LDS first thing; the neighbour traces are consumed by the
+  // face-jump stage), so that every load has most of an iteration to land and no copy ever waits for one.
+  int64_t grp = FULL ? (int64_t)blockIdx.x : nfull;
+  double x[4], geo[GPT];
+  d2 up0, up1;
+  {
+    const int64_t e0 = M.e_begin + grp * E;
+    const int nE = FULL ? E : (int)(e_end - e0);
+    const unsigned tvl = tv < (unsigned)(nE * Nq) ? tv : 0u, tfl = tf < (unsigned)(nE * Nfq) ? tf : 0u;
+    const unsigned mp = (unsigned)M.mapP[e0 * Nfq + tfl];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) x[f] = Q[f * KN + e0 * Nq + tvl];
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) { const unsigned n = tid + i * G::GT; geo[i] = M.geo[e0 * GEO_STRIDE + (n < (unsigned)(nE * GEO_STRIDE) ? n : 0u)]; }
+    const d2* up = reinterpret_cast<const d2*>(A_U + (size_t)mp * FAU_NC);
+    up0 = up[0]; up1 = up[1];
+  }
+
+  T2_STAMP_INIT;
+#pragma unroll 1
+  for (; grp < ngrp; grp += gridDim.x) {
+    T2_STAMP(0);
+    const int64_t e0 = M.e_begin + grp * E;
+    const int nE = FULL ? E : (int)(e_end - e0);
+    const bool vact = FULL || tid < (unsigned)(nE * Nq), fact = FULL || tid < (unsigned)(nE * Nfq);
+    // next group, clamped to the last one (harmless re-loads at the end)
+    const int64_t gnx = min(grp + (int64_t)gridDim.x, ngrp - 1);
+    const int64_t e0n = M.e_begin + gnx * E;
+    const int nEn = FULL ? E : (int)(e_end - e0n);
+    const unsigned tvn = tv < (unsigned)(nEn * Nq) ? tv : 0u, tfn = tf < (unsigned)(nEn * Nfq) ? tf : 0u;
+
+    // ---- this group's state and geometry to LDS; their registers take the next group's loads ---------------------------
+    d2* sA = reinterpret_cast<d2*>(lds + R0);
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) sGeo[tid + i * G::GT] = geo[i];
+    sA[tv] = make_double2(x[0], x[1]);
+    sA[NV + tv] = make_double2(x[2], x[3]);
+    __builtin_amdgcn_sched_barrier(0);
+    // mapP first: it is waited for first (vmcnt counts in issue order), the others may then still be in flight.
+    // unsigned: a sign-extending load would put its shift, and with it the wait for the load, right here
+    const unsigned mpn = (unsigned)M.mapP[e0n * Nfq + tfn];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) x[f] = Q[f * KN + e0n * Nq + tvn];
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) { const unsigned n = tid + i * G::GT; geo[i] = M.geo[e0n * GEO_STRIDE + (n < (unsigned)(nEn * GEO_STRIDE) ? n : 0u)]; }
+    __builtin_amdgcn_sched_barrier(0);
+    T2_STAMP(1);
+
+    // ---- state at the Gauss node, entropy variables 2..4 --------------------------------------------------------------
+    double U[4];
+    vq_apply<N1>(cq, sA, reinterpret_cast<d2*>(lds + R0 + 4 * NV), tv, rowb, ev * Nq + b, nullptr, U);
+    T2_STAMP(2);
+    double V[3];
+    {
+      const double m2 = U[1] * U[1] + U[2] * U[2];
+      const double rre = __builtin_fma(U[0], U[3], -.5 * m2);      // rho * rhoe
+      const double t = U[0] * rcp_refined(rre);                    // rho / (rho rhoe) = 1 / rhoe
+      V[0] = U[1] * t; V[1] = U[2] * t; V[2] = -(U[0] * t);       // (rho u, rho v, -rho) / rhoe  (cavity :464-467)
+    }
+    sVp[tv] = make_double2(V[0], V[1]);
+    sV4[tv] = V[2];
+    __syncthreads();
+    T2_STAMP(3);
+
+    // ---- face lanes: projected entropy variables at the face node, half jump to the neighbour's ---------------------
+    {
+      const double b2 = 2 * GM1 * up1.y;                           // neighbour: (v2,v3,v4) = (b u, b v, -b), b = 2 (gamma-1) beta
+      double vP[3] = {b2 * up0.y, b2 * up1.x, -b2};
+      {   // the neighbour traces of the next group (its mapP entries were requested two barriers ago) into the registers
+          // of this group's, whose last use is forced to lie above this point
+        asm volatile("" : "+v"(vP[0]), "+v"(vP[1]), "+v"(vP[2]));
+        __builtin_amdgcn_sched_barrier(0);
+        const d2* upn = reinterpret_cast<const d2*>(A_U + (size_t)mpn * FAU_NC);
+        up0 = upn[0]; up1 = upn[1];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      d2 p = sVp[fnode0];
+      double vf0 = ee[0] * p.x, vf1 = ee[0] * p.y, vf2 = ee[0] * sV4[fnode0];
+#pragma unroll
+      for (int j = 1; j < N1; ++j) {
+        p = sVp[fnode0 + j * fstride];
+        vf0 = __builtin_fma(ee[j], p.x, vf0); vf1 = __builtin_fma(ee[j], p.y, vf1);
+        vf2 = __builtin_fma(ee[j], sV4[fnode0 + j * fstride], vf2);
+      }
+      sDp[tf] = make_double2(.5 * (vP[0] - vf0), .5 * (vP[1] - vf1));     // (duplicate lanes: duplicate writes)
+      sD4[tf] = .5 * (vP[2] - vf2);
+    }
+    __syncthreads();
+    T2_STAMP(4);
+
+    // ---- volume lanes: BR1 gradient, sigma = K(v) grad v --------------------------------------------------------------
+    const double* g = sGeo + ev * GEO_STRIDE;     // elements beyond the mesh read the (clamped) staged values: finite, unused
+    const double gx0 = g[TT.op0], gy0 = g[2 + TT.op0], gx1 = g[TT.op1], gy1 = g[2 + TT.op1];
+    double sgx[3], sgy[3];
+    {
+      double d0[3], d1[3], tx[3], ty[3];
+      {
+        d2 p = sVp[rowb], t = sVp[colb];
+        d0[0] = dg0[0] * p.x; d0[1] = dg0[0] * p.y; d0[2] = dg0[0] * sV4[rowb];
+        d1[0] = dg1[0] * t.x; d1[1] = dg1[0] * t.y; d1[2] = dg1[0] * sV4[colb];
+#pragma unroll
+        for (int j = 1; j < N1; ++j) {
+          p = sVp[rowb + j]; t = sVp[colb + N1 * j];
+          d0[0] = __builtin_fma(dg0[j], p.x, d0[0]); d0[1] = __builtin_fma(dg0[j], p.y, d0[1]);
+          d0[2] = __builtin_fma(dg0[j], sV4[rowb + j], d0[2]);
+          d1[0] = __builtin_fma(dg1[j], t.x, d1[0]); d1[1] = __builtin_fma(dg1[j], t.y, d1[1]);
+          d1[2] = __builtin_fma(dg1[j], sV4[colb + N1 * j], d1[2]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        tx[c] = __builtin_fma(gx1, d1[c], gx0 * d0[c]);
+        ty[c] = __builtin_fma(gy1, d1[c], gy0 * d0[c]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {   // lift of the half jumps on the four faces at the ends of this node's lines
+        const double* gn = g + 5 + 3 * TT.gface[k];
+        const double lx = lw[k] * gn[0], ly = lw[k] * gn[1];
+        const d2 dj = sDp[fq[k]];
+        const double dj2 = sD4[fq[k]];
+        tx[0] = __builtin_fma(lx, dj.x, tx[0]); ty[0] = __builtin_fma(ly, dj.x, ty[0]);
+        tx[1] = __builtin_fma(lx, dj.y, tx[1]); ty[1] = __builtin_fma(ly, dj.y, ty[1]);
+        tx[2] = __builtin_fma(lx, dj2, tx[2]); ty[2] = __builtin_fma(ly, dj2, ty[2]);
+      }
+      const double iJ = rcp_refined(g[4]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { tx[c] *= iJ; ty[c] *= iJ; }
+      viscous_stress(V, tx, ty, -ph.lambda, ph.mu, ph.kappa, sgx, sgy);
+    }
+    {
+      sSg[tv] = make_double2(sgx[0], sgx[1]);
+      sSg[NV + tv] = make_double2(sgx[2], sgy[0]);
+      sSg[2 * NV + tv] = make_double2(sgy[1], sgy[2]);
+      // contravariant components: the divergence below differentiates these along the tensor lines
+      sS0[tv] = make_double2(__builtin_fma(gy0, sgy[0], gx0 * sgx[0]), __builtin_fma(gy0, sgy[1], gx0 * sgx[1]));
+      sS02[tv] = __builtin_fma(gy0, sgy[2], gx0 * sgx[2]);
+      sS1[tv] = make_double2(__builtin_fma(gy1, sgy[0], gx1 * sgx[0]), __builtin_fma(gy1, sgy[1], gx1 * sgx[1]));
+      sS12[tv] = __builtin_fma(gy1, sgy[2], gx1 * sgx[2]);
+    }
+    __syncthreads();
+    T2_STAMP(5);
+
+    // ---- volume part of div sigma (dg_div! :590-611 without the lift) -> SG[3][K][Nq] --------------------------------
+    {
+      d2 p = sS0[rowb];
+      double dv0 = dg0[0] * p.x, dv1 = dg0[0] * p.y, dv2 = dg0[0] * sS02[rowb];
+#pragma unroll
+      for (int j = 1; j < N1; ++j) {
+        p = sS0[rowb + j];
+        dv0 = __builtin_fma(dg0[j], p.x, dv0); dv1 = __builtin_fma(dg0[j], p.y, dv1);
+        dv2 = __builtin_fma(dg0[j], sS02[rowb + j], dv2);
+      }
+#pragma unroll
+      for (int j = 0; j < N1; ++j) {
+        p = sS1[colb + N1 * j];
+        dv0 = __builtin_fma(dg1[j], p.x, dv0); dv1 = __builtin_fma(dg1[j], p.y, dv1);
+        dv2 = __builtin_fma(dg1[j], sS12[colb + N1 * j], dv2);
+      }
+      if (vact) {
+        double* o = SG + e0 * Nq + tv;
+        o[0] = dv0; o[KN] = dv1; o[2 * KN] = dv2;
+      }
+    }
+    T2_STAMP(6);
+    // ---- face lanes: own normal stress (Ef*sigma_x)*nxJ + (Ef*sigma_y)*nyJ -> B ----------------------------------------
+    {
+      const double* gn = sGeo + ef * GEO_STRIDE + gfo;
+      const double nx = gn[0], ny = gn[1];
+      d2 p0 = sSg[fnode0], p1 = sSg[NV + fnode0], p2 = sSg[2 * NV + fnode0];
+      double fx0 = ee[0] * p0.x, fx1 = ee[0] * p0.y, fx2 = ee[0] * p1.x, fy0 = ee[0] * p1.y, fy1 = ee[0] * p2.x, fy2 = ee[0] * p2.y;
+#pragma unroll
+      for (int j = 1; j < N1; ++j) {
+        const unsigned n = fnode0 + j * fstride;
+        p0 = sSg[n]; p1 = sSg[NV + n]; p2 = sSg[2 * NV + n];
+        fx0 = __builtin_fma(ee[j], p0.x, fx0); fx1 = __builtin_fma(ee[j], p0.y, fx1); fx2 = __builtin_fma(ee[j], p1.x, fx2);
+        fy0 = __builtin_fma(ee[j], p1.y, fy0); fy1 = __builtin_fma(ee[j], p2.x, fy1); fy2 = __builtin_fma(ee[j], p2.y, fy2);
+      }
+      if (fact) {
+        double* bb = B + (e0 * Nfq + tf) * B_NC;
+        bb[0] = __builtin_fma(fy0, ny, fx0 * nx);
+        bb[1] = __builtin_fma(fy1, ny, fx1 * nx);
+        bb[2] = __builtin_fma(fy2, ny, fx2 * nx);
+      }
+    }
+    T2_STAMP(7);
+    __syncthreads();   // the LDS planes are rewritten by the next iteration
+    T2_STAMP(8);
+  }
+  T2_STAMP_FLUSH;
+}
+
+}  // namespace t2
+
+#define ESDG_T2_DISPATCH(N1v, BODY)                  \
+  switch (N1v) {                                     \
+    case 2: { constexpr int N1 = 2; BODY; } break;   \
+    case 3: { constexpr int N1 = 3; BODY; } break;   \
+    case 4: { constexpr int N1 = 4; BODY; } break;   \
+    case 5: { constexpr int N1 = 5; BODY; } break;   \
+    case 6: { constexpr int N1 = 6; BODY; } break;   \
+    case 7: { constexpr int N1 = 7; BODY; } break;   \
+    case 8: { constexpr int N1 = 8; BODY; } break;   \
+    default: return (int)hipErrorInvalidValue;       \
+  }
+
+#ifdef ESDG_T2_STAMP
+extern "C" int esdg_debug_stamps(unsigned long long* out16, int reset) {
+  unsigned long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(t2::g_stamp), sizeof z) != hipSuccess) return -1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(t2::g_stamp), z, sizeof z) != hipSuccess) return -1;
+  return 0;
+}
+#endif
+
+// phase 1 on meshes without walls and without the visc_test reduction (the other variants stay with kt_sigma)
+int launch_sigma_tensor2(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
+                         double* B, double* SG, hipStream_t s) {
+  if (M.e_count <= 0) return 0;
+  ESDG_T2_DISPATCH(N1v, {
+    using G = t2::Geo<N1>;
+    const int64_t nfull = M.e_count / G::E;
+    if (nfull > 0) {
+      const int nb = t2::persistent_grid(t2::kt2_sigma<N1, true>, G::GT, nfull);
+      hipLaunchKernelGGL((t2::kt2_sigma<N1, true>), dim3(nb), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);
+    }
+    if (M.e_count % G::E) hipLaunchKernelGGL((t2::kt2_sigma<N1, false>), dim3(1), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);
+  });
+  return (int)hipGetLastError();
+}
+
+}  // namespace esdg

@@ -40,11 +40,48 @@ struct TensorLayout {
         NINT(8 * n1) {}
 };
 
+// Per-node tables of the v2 tensor kernels (esdg_kernels_tensor2.hip): everything a lane needs about ITS node as one
+// row, derived on the host from the 1D tables above, so the kernels do no index arithmetic or table chasing.
+// Faces are numbered k = 2 d + t (the face at end t of the d-lines); circulant round r = d * NFULL + i pairs the node
+// at position pos of its d-line with position (pos + i + 1) mod N1; even N1 has one more, antipodal round (pos + N1/2)
+// in which a node serves ONE of its two directions (see kt_rhs).
+//   volume node q = a + N1 b, NodeLayout::LD doubles:
+//     IQ[N1] = IQ[a][:]          IPL[N1] = IP[a][:]      IPH[N1] = IP[b][:]
+//     DG0[N1] = DG[0][a][:]      DG1[N1] = DG[1][b][:]
+//     LW[4]  = PF*PTF*WFAC of face k (collocated lift)      PW[4] = PF*PTF (collocated projection)
+//     SVF[4] = SF*WTF (volume-face SBP weight)              SVV[NRND] = S*WT of round r (volume-volume SBP weight)
+//     PD     = (Vq*Ph)[q,q]
+//   and NodeLayout::LI ints: FQ[4] = face node of face k, PID[NRND] = partner node of round r,
+//     AD = direction served in the antipodal round (even N1)
+//   face node fn, FaceLayout::LD doubles: EE[N1] (interpolation weights along its line), WFAC
+//   and FaceLayout::LI ints: NODE0 = first node of its line, STRIDE = node stride along the line, K = face number k
+struct NodeLayout {
+  int N1, NFULL, NRND, IQ, IPL, IPH, DG0, DG1, LW, PW, SVF, SVV, PD, LD;
+  int FQ, PID, AD, LI;
+  __host__ __device__ constexpr explicit NodeLayout(int n1)
+      : N1(n1), NFULL((n1 - 1) / 2), NRND(2 * ((n1 - 1) / 2) + (n1 % 2 == 0 ? 1 : 0)),
+        IQ(0), IPL(n1), IPH(2 * n1), DG0(3 * n1), DG1(4 * n1), LW(5 * n1), PW(5 * n1 + 4), SVF(5 * n1 + 8), SVV(5 * n1 + 12),
+        PD(5 * n1 + 12 + 2 * ((n1 - 1) / 2) + (n1 % 2 == 0 ? 1 : 0)),
+        LD(5 * n1 + 13 + 2 * ((n1 - 1) / 2) + (n1 % 2 == 0 ? 1 : 0)),
+        FQ(0), PID(4), AD(4 + 2 * ((n1 - 1) / 2) + (n1 % 2 == 0 ? 1 : 0)), LI(5 + 2 * ((n1 - 1) / 2) + (n1 % 2 == 0 ? 1 : 0)) {}
+};
+struct FaceLayout {
+  int N1, EE, WFAC, LD, NODE0, STRIDE, K, LI;
+  __host__ __device__ constexpr explicit FaceLayout(int n1) : N1(n1), EE(0), WFAC(n1), LD(n1 + 1), NODE0(0), STRIDE(1), K(2), LI(3) {}
+};
+
 // device-side handle: one buffer of NDBL doubles followed by NINT int32
 struct TensorTables {
   const double* dbl;
   const int* ints;
   int op0, op1;  // operator family of direction 0 / 1
+  // v2 kernels: per-node rows (NodeLayout / FaceLayout) and the mesh face (0..3, position in the normals of the geometry
+  // record) of face k = 2 d + t
+  const double* node_d;
+  const int* node_i;
+  const double* face_d;
+  const int* face_i;
+  int gface[4];
 };
 
 }  // namespace esdg
