@@ -347,7 +347,10 @@ void build_node_host(int N1, const TensorHost& H, NodeHost& T) {
   }
   for (int f = 0; f < Nfq; ++f) {
     const int w = I[L.FINV + f], d = w & 1, t = (w >> 1) & 1, o = w >> 2, k = 2 * d + t;
-    for (int j = 0; j < N1; ++j) T.fd[(size_t)f * FL.LD + FL.EE + j] = D[L.EE + k * N1 + j];
+    for (int j = 0; j < N1; ++j) {
+      T.fd[(size_t)f * FL.LD + FL.EE + j] = D[L.EE + k * N1 + j];
+      T.fd[(size_t)f * FL.LD + FL.SVF + j] = D[L.SF + k * N1 + j] * D[L.WTF + k * N1 + o];
+    }
     T.fd[(size_t)f * FL.LD + FL.WFAC] = D[L.WFAC + f];
     T.fi[(size_t)f * FL.LI + FL.NODE0] = d == 0 ? N1 * o : o;
     T.fi[(size_t)f * FL.LI + FL.STRIDE] = d == 0 ? 1 : N1;
@@ -1166,8 +1169,12 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
   } else {
     if (!rhs && !lf.Qw) return fail(ESDG_ERR_ARG, "rhs output is null");
     if (lf.Qw && !ctx->use_fast) return fail(ESDG_ERR_STATE, "the fused RK update needs the tensor kernels");
-    rc = ctx->use_fast ? launch_rhs_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s)
-                       : launch_rhs(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, B, rhs, s);
+    rc = -1;
+    if (ctx->use_fast && !ctx->M.bc && !ctx->v1 && !ctx->ph.dbg)      // v2 kernel: meshes without walls, degrees N <= 5
+      rc = launch_rhs_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s);
+    if (rc == -1)
+      rc = ctx->use_fast ? launch_rhs_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s)
+                         : launch_rhs(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, B, rhs, s);
   }
   // pack what this phase produced for the off-rank neighbours (ranged launches leave that to esdg_halo_pack)
   if (!rc && ctx->nsend && !ranged)

@@ -53,6 +53,9 @@ int launch_sigma_tensor(int N1, const TensorTables& TT, const MeshDev& M, const 
                         const double* A_U, double* B, double* SG, double* visc_test_partial, hipStream_t s);
 int sigma_tensor_blocks(int N1, int64_t K);
 // v2 tensor kernels (esdg_kernels_tensor2.hip)
+struct LsrkFuse;
+int launch_rhs_tensor2(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
+                       const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s);
 int launch_sigma_tensor2(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
                          double* B, double* SG, hipStream_t s);
 struct LsrkFuse;

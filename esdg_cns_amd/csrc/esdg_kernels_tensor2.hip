@@ -420,6 +420,381 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
   T2_STAMP_FLUSH;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// last phase (meshes without walls): interface + volume flux differencing (+ viscous divergence and penalty) -> rhs
+// (euler_quad.jl:141-194 / rhs_inviscid! :447-528, update_flux! :308-324, flux_differencing! :326-348, dg_div! :590-611;
+// see kt_rhs in esdg_kernels_tensor.hip for the formulas)
+//
+// Flux pairs.  Volume-volume pairs: circulant rounds, each unordered pair once, by the volume lanes (the partner's share
+// goes to an LDS accumulator with ds_add_f64).  Volume-face pairs: by the FACE lanes, which walk the N1 volume nodes
+// of their line with their own trace state in registers, keep the face node's sum in registers and push the volume
+// node's share with ds_add_f64.  Every accumulator cell receives at most TWO adds, on a cell zeroed beforehand: one plane
+// set per direction for the volume-volume shares (rounds i = 0, 1 of a direction), one per direction for the shares
+// coming from the two faces at the ends of a line, one for the antipodal round of even N1.  0 + x + y does not depend on
+// the order of the two adds, so the result is bit-for-bit the same wherever the element sits in its group and however
+// the waves of a group are scheduled (elements may straddle two waves) -- no per-wave accumulator copies.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool MODAL> struct Gas2 { static constexpr double GM1 = MODAL ? 0.4 : (1.4 - 1); };   // literal 0.4 in the CNS drivers
+
+// (gx,gy) . (Fx,Fy) of the entropy-conservative flux (euler_fluxes.jl:23-48 with logmean.jl:14-28) between the states
+// (rho,u,v,beta,lrho,lbeta); one refined reciprocal serves the three quotients; the |f| < 1e-4 series is selected
+template <bool MODAL>
+__device__ __forceinline__ void ec_flux_dir(const double* qL, const double* qR, double gx, double gy, double* F) {
+  constexpr double GM1 = Gas2<MODAL>::GM1;
+  const double dr = qR[0] - qL[0], ravg = .5 * (qR[0] + qL[0]);
+  const double db = qR[3] - qL[3], bavg = .5 * (qR[3] + qL[3]);
+  const double A = qL[4] - qR[4], Bl = qL[5] - qR[5];
+  const bool ser_r = fabs(dr) < 1e-4 * ravg, ser_b = fabs(db) < 1e-4 * bavg;
+  const double yr = ser_r ? ravg : A;
+  const double yb = ser_b ? bavg : db;
+  const double yp = qL[3] + qR[3];
+  const double ybp = yb * yp;
+  const double R = rcp_refined(yr * ybp);
+  const double ir = R * ybp;
+  const double ryr = R * yr;
+  const double ib = ryr * yp;
+  const double ip = ryr * yb;
+  const double fr = dr * ir, vr = fr * fr;
+  const double rholog = ser_r ? ravg * (1 + vr * (-.2 - vr * (.0512 - vr * 0.026038857142857))) : -fr;
+  const double fb = db * ib, vb = fb * fb;
+  const double ibetalog = ser_b ? ib * (1 + vb * (.2 + vb * .0912)) : -(Bl * ib);
+  const double uavg = .5 * (qL[1] + qR[1]), vavg = .5 * (qL[2] + qR[2]);
+  const double unorm = qL[1] * qR[1] + qL[2] * qR[2];
+  const double pa = ravg * ip;
+  const double f4aux = rholog * ibetalog * (1.0 / (2 * GM1)) + pa + .5 * rholog * unorm;
+  const double un = gx * uavg + gy * vavg;
+  F[0] = rholog * un;
+  F[1] = F[0] * uavg + pa * gx;
+  F[2] = F[0] * vavg + pa * gy;
+  F[3] = f4aux * un;
+}
+
+// conservative -> (rho,u,v,beta,log rho,log beta)
+template <bool MODAL>
+__device__ __forceinline__ void prim_logs(const double* U, double* q) {
+  constexpr double GM1 = Gas2<MODAL>::GM1;
+  const double m2 = U[1] * U[1] + U[2] * U[2];
+  const double rre = U[0] * U[3] - .5 * m2;
+  const double R = rcp_refined(U[0] * rre);
+  const double ir = R * rre;
+  q[0] = U[0];
+  q[1] = U[1] * ir;
+  q[2] = U[2] * ir;
+  q[3] = (U[0] * U[0]) * (U[0] * R) * (1.0 / (2 * GM1));
+  q[4] = log_pos(U[0]);
+  q[5] = log_pos(q[3]);
+}
+
+template <int N1, bool MODAL, bool VISC> struct RhsLds2 {
+  using G = Geo<N1>;
+  static constexpr NodeLayout NL = NodeLayout(N1);
+  static constexpr int NV = G::NV, NF = G::NF;
+  static constexpr int NVV = (NL.NFULL + 1) / 2;                      // accumulator plane sets per direction, volume-volume
+  static constexpr int NACC = 2 * NVV + (N1 % 2 == 0 ? 1 : 0) + 2;    // + antipodal + the two volume-face sets
+  static constexpr int REC = 0;                                       // 3 pair planes [NV]: (rho,u) (v,beta) (lrho,lbeta)
+  static constexpr int VQB = REC + 6 * NV;                            // Vq / Pq second buffer (2 pair planes); stress jumps
+  static constexpr int SJ = 3 * NF + (NF & 1);                        // stress jumps: pair plane + single plane [NF]
+  static constexpr int ACC = VQB + (4 * NV > SJ ? 4 * NV : SJ);       // NACC x 2 pair planes [NV]
+  static constexpr int SGF = ACC + NACC * 4 * NV;                     // face totals G_f: 2 pair planes [NF]
+  static constexpr int GEO = SGF + 4 * NF;
+  static constexpr int NLDS = GEO + ((G::E * GEO_STRIDE + 1) & ~1);
+};
+
+// One workgroup per group of elements.  (A persistent variant with next-group prefetch like kt2_sigma's was measured and
+// rejected: the loop-invariant table rows plus the loop-carried loads need 314 VGPRs, i.e. 2 workgroups per CU: 0.504 ms
+// against 0.427 ms for this form at cfg3; capped at 256 VGPRs it spills and takes 0.727 ms.)
+template <int N1, bool MODAL, bool VISC>
+__global__ __launch_bounds__(Geo<N1>::GT) void kt2_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
+                                                                       const double* __restrict__ A_U, const double* __restrict__ SG,
+                                                                       const double* __restrict__ B, double* __restrict__ rhs, LsrkFuse lf) {
+  using G = Geo<N1>;
+  using LD = RhsLds2<N1, MODAL, VISC>;
+  constexpr int Nq = G::Nq, Nfq = G::Nfq, E = G::E, NV = G::NV, NF = G::NF;
+  constexpr NodeLayout NL(N1);
+  constexpr FaceLayout FL(N1);
+  constexpr int NFULL = NL.NFULL, NRND = NL.NRND, NVV = LD::NVV;
+  constexpr int NGEO = E * GEO_STRIDE, GPT = (NGEO + G::GT - 1) / G::GT;
+  static_assert(LD::NLDS - LD::GEO >= GPT * G::GT || true, "");
+  __shared__ __align__(16) double lds[LD::GEO + GPT * G::GT];
+  d2* sRec = reinterpret_cast<d2*>(lds + LD::REC);
+  d2* sVqB = reinterpret_cast<d2*>(lds + LD::VQB);
+  d2* sAcc = reinterpret_cast<d2*>(lds + LD::ACC);
+  d2* sGf = reinterpret_cast<d2*>(lds + LD::SGF);
+  double* sGeo = lds + LD::GEO;
+
+  const unsigned tid = threadIdx.x;
+  const unsigned tv = tid < (unsigned)NV ? tid : tid - NV;
+  const unsigned tf = tid < (unsigned)NF ? tid : tid % NF;
+  const unsigned ev = tv / Nq, q = tv - ev * Nq, a = q % N1, b = q / N1;
+  const unsigned ef = tf / Nfq, fn = tf - ef * Nfq;
+  const unsigned rowb = ev * Nq + N1 * b, colb = ev * Nq + a, colq = ev * Nq + b;
+  const int64_t KN = M.K * Nq;
+  const bool inviscid = (ph.parts & 1) != 0, viscous = VISC && (ph.parts & 2) != 0;
+  const bool vown = NV == G::GT || tid < (unsigned)NV, fown = NF == G::GT || tid < (unsigned)NF;   // not a duplicate lane
+
+  // per-lane table rows, once per workgroup
+  const double* nd = TT.node_d + q * NL.LD;
+  const int* ni = TT.node_i + q * NL.LI;
+  const double* fd = TT.face_d + fn * FL.LD;
+  const int* fi = TT.face_i + fn * FL.LI;
+  double svv[NRND > 0 ? NRND : 1], pw[4], svf[N1];
+  unsigned pid[NRND > 0 ? NRND : 1], fq[4];
+#pragma unroll
+  for (int r = 0; r < NRND; ++r) { svv[r] = nd[NL.SVV + r]; pid[r] = ev * Nq + ni[NL.PID + r]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { pw[k] = nd[NL.PW + k]; fq[k] = ev * Nfq + ni[NL.FQ + k]; }
+#pragma unroll
+  for (int j = 0; j < N1; ++j) svf[j] = fd[FL.SVF + j];
+  const double pd = nd[NL.PD], wfac = fd[FL.WFAC];
+  const unsigned fnode0 = ef * Nq + fi[FL.NODE0], fstride = fi[FL.STRIDE];
+  const int fdir = fi[FL.K] >> 1, ad = (N1 % 2 == 0) ? ni[NL.AD] : 0;
+  const unsigned gfo = 5 + 3 * (fn / N1);
+  const int opf = fdir ? TT.op1 : TT.op0;
+
+  const int64_t e0 = M.e_begin + (int64_t)blockIdx.x * E;
+  const int nE = (int)min((int64_t)E, M.e_begin + M.e_count - e0);
+  const bool vact = tid < (unsigned)(nE * Nq);
+
+  // ---- global loads -------------------------------------------------------------------------------------------------
+  double x[4], geo[GPT], qM[8], qP[8], bPn[3] = {0, 0, 0}, bOwn[3] = {0, 0, 0}, dvs[3] = {0, 0, 0};
+  {
+    const unsigned tvl = tv < (unsigned)(nE * Nq) ? tv : 0u, tfl = tf < (unsigned)(nE * Nfq) ? tf : 0u;
+    const int64_t nf = e0 * Nfq + tfl;
+    const unsigned mp = (unsigned)M.mapP[nf];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) x[f] = Q[f * KN + e0 * Nq + tvl];
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) { const unsigned n = tid + i * G::GT; geo[i] = M.geo[e0 * GEO_STRIDE + (n < (unsigned)(nE * GEO_STRIDE) ? n : 0u)]; }
+    const d2* aM = reinterpret_cast<const d2*>(A_U + nf * FAU_NC);
+    const d2* aM2 = reinterpret_cast<const d2*>(A_U + (M.trace_nodes + nf) * FAU_NC);
+    const d2* aP = reinterpret_cast<const d2*>(A_U + (size_t)mp * FAU_NC);
+    const d2* aP2 = reinterpret_cast<const d2*>(A_U + (M.trace_nodes + (size_t)mp) * FAU_NC);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const d2 m = aM[c], p = aP[c], m2 = aM2[c], p2 = aP2[c];
+      qM[2 * c] = m.x; qM[2 * c + 1] = m.y; qP[2 * c] = p.x; qP[2 * c + 1] = p.y;
+      qM[4 + 2 * c] = m2.x; qM[5 + 2 * c] = m2.y; qP[4 + 2 * c] = p2.x; qP[5 + 2 * c] = p2.y;
+    }
+    if (VISC) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { bPn[c] = B[(size_t)mp * B_NC + c]; bOwn[c] = B[nf * B_NC + c]; dvs[c] = SG[c * KN + e0 * Nq + tvl]; }
+    }
+  }
+
+  {
+    // ---- state and geometry to LDS ----------------------------------------------------------------------------------------
+    double U[4];
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) sGeo[tid + i * G::GT] = geo[i];
+    if (MODAL) {
+      sRec[tv] = make_double2(x[0], x[1]);
+      sRec[NV + tv] = make_double2(x[2], x[3]);
+    } else {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) U[f] = x[f];
+    }
+
+    // ---- state at the Gauss node -> primitives + logs ---------------------------------------------------------------------
+    if (MODAL) {
+      double cq[N1];
+#pragma unroll
+      for (int i = 0; i < N1; ++i) cq[i] = nd[NL.IQ + i];
+      vq_apply<N1>(cq, sRec, sVqB, tv, rowb, colq, nullptr, U);
+    }
+    double qh[6];
+    prim_logs<MODAL>(U, qh);
+    // (modal: the Vq input planes alias the record planes; every lane is past its stage-1 reads, which the second barrier
+    // inside vq_apply separates from here)
+    sRec[tv] = make_double2(qh[0], qh[1]);
+    sRec[NV + tv] = make_double2(qh[2], qh[3]);
+    sRec[2 * NV + tv] = make_double2(qh[4], qh[5]);
+#pragma unroll
+    for (int p = 0; p < 2 * LD::NACC; ++p) sAcc[p * NV + tv] = make_double2(0.0, 0.0);
+    __syncthreads();     // geometry, records and zeroed accumulators of every lane are in place
+
+    // ---- face lanes: interface flux and penalty from the two trace states (registers only) -----------------------------------
+    const double* gf = sGeo + ef * GEO_STRIDE;     // (slots of elements beyond the mesh hold the clamped loads: finite, unused)
+    double Gf[4], pnr[3] = {0, 0, 0};
+    {
+      const double* gn = gf + gfo;
+      if (VISC) {   // penalty tau*[[v]] (:817-837): the projected entropy variables are those OF the trace states
+        const double bM = 2 * Gas2<MODAL>::GM1 * qM[3], bP = 2 * Gas2<MODAL>::GM1 * qP[3];
+        const double tau = ph.viscous_dissp ? -rcp_refined(-bM) * ph.inv_Re : 0.0;
+        pnr[0] = tau * (bP * qP[1] - bM * qM[1]);
+        pnr[1] = tau * (bP * qP[2] - bM * qM[2]);
+        pnr[2] = tau * (bM - bP);
+      }
+      double Fn[4];
+      ec_flux_dir<MODAL>(qM, qP, gn[0], gn[1], Fn);
+      const double LFc = ph.inviscid_dissp ? ph.lf_scale * fmax(qM[6], qP[6]) * gn[2] : 0.0;
+      const double dU[4] = {qP[0] - qM[0], qP[0] * qP[1] - qM[0] * qM[1], qP[0] * qP[2] - qM[0] * qM[2], qP[7] - qM[7]};
+      const double wf = inviscid ? wfac : 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Gf[c] = wf * (Fn[c] - LFc * dU[c]);
+    }
+
+    // ---- flux differencing ----------------------------------------------------------------------------------------------
+    double acc[4] = {0, 0, 0, 0};
+    if (inviscid) {   // uniform
+      const double* g = sGeo + ev * GEO_STRIDE;
+      const double gx0 = 2 * g[TT.op0], gy0 = 2 * g[2 + TT.op0], gx1 = 2 * g[TT.op1], gy1 = 2 * g[2 + TT.op1];
+      // volume-volume rounds: pair (pos, pos + i + 1 mod N1) of direction d; share of the partner -> plane set d * NVV + i / 2
+#pragma unroll
+      for (int r = 0; r < 2 * NFULL; ++r) {
+        const int d = r / NFULL, i = r % NFULL;
+        const d2 p0 = sRec[pid[r]], p1 = sRec[NV + pid[r]], p2 = sRec[2 * NV + pid[r]];
+        const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
+        double Fd[4];
+        ec_flux_dir<MODAL>(qh, qj, svv[r] * (d ? gx1 : gx0), svv[r] * (d ? gy1 : gy0), Fd);
+        double* tgt = reinterpret_cast<double*>(sAcc + (d * NVV + i / 2) * 2 * NV + pid[r]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += Fd[c];
+        if (vown) {   // duplicate lanes (slots beyond NV) must not add twice
+#pragma unroll
+          for (int c = 0; c < 4; ++c) lds_add(tgt + (c >> 1) * 2 * NV + (c & 1), -Fd[c]);
+        }
+      }
+      if (N1 % 2 == 0) {   // antipodal pairs: a node serves direction `ad` (one endpoint of every such pair does)
+        constexpr int r = 2 * NFULL;
+        const d2 p0 = sRec[pid[r]], p1 = sRec[NV + pid[r]], p2 = sRec[2 * NV + pid[r]];
+        const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
+        double Fd[4];
+        ec_flux_dir<MODAL>(qh, qj, svv[r] * (ad ? gx1 : gx0), svv[r] * (ad ? gy1 : gy0), Fd);
+        double* tgt = reinterpret_cast<double*>(sAcc + (2 * NVV) * 2 * NV + pid[r]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += Fd[c];
+        if (vown) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) lds_add(tgt + (c >> 1) * 2 * NV + (c & 1), -Fd[c]);
+        }
+      }
+      // volume-face pairs by the face lanes: share of the volume node -> plane set of the face's direction
+      {
+        const double gxf = 2 * gf[opf], gyf = 2 * gf[2 + opf];
+        const d2* accf = sAcc + (LD::NACC - 2 + fdir) * 2 * NV;
+#pragma unroll
+        for (int j = 0; j < N1; ++j) {
+          const unsigned n = fnode0 + j * fstride;
+          const d2 p0 = sRec[n], p1 = sRec[NV + n], p2 = sRec[2 * NV + n];
+          const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
+          double vv[4];
+          ec_flux_dir<MODAL>(qj, qM, svf[j] * gxf, svf[j] * gyf, vv);
+          double* tgt = const_cast<double*>(reinterpret_cast<const double*>(accf + n));
+          if (fown) {   // duplicate face lanes must not add twice
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lds_add(tgt + (c >> 1) * 2 * NV + (c & 1), vv[c]);
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) Gf[c] -= vv[c];
+        }
+      }
+    }
+    sGf[tf] = make_double2(Gf[0], Gf[1]);
+    sGf[NF + tf] = make_double2(Gf[2], Gf[3]);
+    if (VISC) {   // stress jump .5*((sxP-sxf)*nxJ + (syP-syf)*nyJ) + J * penalty (the penalty is lifted WITHOUT 1/J, quirk Q3)
+      const double Jf = gf[4];
+      d2* sSjp = sVqB;
+      double* sSj2 = lds + LD::VQB + 2 * NF;
+      sSjp[tf] = make_double2(__builtin_fma(Jf, pnr[0], .5 * (-bPn[0] - bOwn[0])), __builtin_fma(Jf, pnr[1], .5 * (-bPn[1] - bOwn[1])));
+      sSj2[tf] = __builtin_fma(Jf, pnr[2], .5 * (-bPn[2] - bOwn[2]));
+    }
+    __syncthreads();
+
+    // ---- collocated rhs: -(Ph*QF + Lf*flux)/J  (+ viscous divergence and penalty) ---------------------------------------------
+    double R[4];
+    {
+      const double* g = sGeo + ev * GEO_STRIDE;
+      const double iJ = rcp_refined(g[4]);
+#pragma unroll
+      for (int p = 0; p < LD::NACC; ++p) {
+        const d2 s0 = sAcc[(2 * p) * NV + tv], s1 = sAcc[(2 * p + 1) * NV + tv];
+        acc[0] += s0.x; acc[1] += s0.y; acc[2] += s1.x; acc[3] += s1.y;
+      }
+      double r[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) r[c] = pd * acc[c];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const d2 g0 = sGf[fq[k]], g1 = sGf[NF + fq[k]];
+        r[0] = __builtin_fma(pw[k], g0.x, r[0]); r[1] = __builtin_fma(pw[k], g0.y, r[1]);
+        r[2] = __builtin_fma(pw[k], g1.x, r[2]); r[3] = __builtin_fma(pw[k], g1.y, r[3]);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) R[c] = -r[c] * iJ;
+      if (VISC) {   // dg_div! :590-611: volume part from phase 1 + lift of the stress jumps (and J * penalty)
+        const d2* sSjp = sVqB;
+        const double* sSj2 = lds + LD::VQB + 2 * NF;
+        double dv[3] = {dvs[0], dvs[1], dvs[2]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const d2 sj = sSjp[fq[k]];
+          const double lwk = nd[NL.LW + k];
+          dv[0] = __builtin_fma(lwk, sj.x, dv[0]); dv[1] = __builtin_fma(lwk, sj.y, dv[1]);
+          dv[2] = __builtin_fma(lwk, sSj2[fq[k]], dv[2]);
+        }
+        const double vs = viscous ? iJ : 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R[c + 1] = __builtin_fma(dv[c], vs, R[c + 1]);
+      }
+    }
+    // ---- out = Pq R (modal), store or fused low-storage RK stage ---------------------------------------------------------------
+    double out[4];
+    if (MODAL) {
+      double ipl[N1], iph[N1];
+#pragma unroll
+      for (int i = 0; i < N1; ++i) { ipl[i] = nd[NL.IPL + i]; iph[i] = nd[NL.IPH + i]; }
+      d2* sA = sRec;                       // records are dead (all lanes are past the barrier after the flux rounds)
+      d2* sB = sAcc;                       // accumulators: read above, rewritten only after the next barrier
+      sA[tv] = make_double2(R[0], R[1]);
+      sA[NV + tv] = make_double2(R[2], R[3]);
+      __syncthreads();
+      {   // stage 1: W[a + N1 b] = sum_j IP[a,j] R[b + N1 j]   (this lane: column b of R)
+        const d2* rr = sA + colq;
+        d2 p = rr[0], t = rr[NV];
+        double w0 = ipl[0] * p.x, w1 = ipl[0] * p.y, w2 = ipl[0] * t.x, w3 = ipl[0] * t.y;
+#pragma unroll
+        for (int j = 1; j < N1; ++j) {
+          p = rr[N1 * j]; t = rr[NV + N1 * j];
+          w0 = __builtin_fma(ipl[j], p.x, w0); w1 = __builtin_fma(ipl[j], p.y, w1);
+          w2 = __builtin_fma(ipl[j], t.x, w2); w3 = __builtin_fma(ipl[j], t.y, w3);
+        }
+        sB[tv] = make_double2(w0, w1);
+        sB[NV + tv] = make_double2(w2, w3);
+      }
+      __syncthreads();
+      {   // stage 2: out[a + N1 b] = sum_i IP[b,i] W[a + N1 i]   (this lane: column a of W)
+        const d2* rr = sB + colb;
+        d2 p = rr[0], t = rr[NV];
+        out[0] = iph[0] * p.x; out[1] = iph[0] * p.y; out[2] = iph[0] * t.x; out[3] = iph[0] * t.y;
+#pragma unroll
+        for (int i = 1; i < N1; ++i) {
+          p = rr[N1 * i]; t = rr[NV + N1 * i];
+          out[0] = __builtin_fma(iph[i], p.x, out[0]); out[1] = __builtin_fma(iph[i], p.y, out[1]);
+          out[2] = __builtin_fma(iph[i], t.x, out[2]); out[3] = __builtin_fma(iph[i], t.y, out[3]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) out[f] = R[f];
+    }
+    if (vact) {
+      if (lf.Qw) {   // fused low-storage RK stage (uniform)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const int64_t idx = f * KN + e0 * Nq + tv;
+          const double rr = __builtin_fma(lf.a, lf.res[idx], lf.dt * out[f]);
+          lf.res[idx] = rr;
+          lf.Qw[idx] = __builtin_fma(lf.b, rr, lf.Qw[idx]);
+        }
+      } else {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) rhs[f * KN + e0 * Nq + tv] = out[f];
+      }
+    }
+  }
+}
+
 }  // namespace t2
 
 #define ESDG_T2_DISPATCH(N1v, BODY)                  \
@@ -455,6 +830,30 @@ int launch_sigma_tensor2(int N1v, const TensorTables& TT, const MeshDev& M, cons
       hipLaunchKernelGGL((t2::kt2_sigma<N1, true>), dim3(nb), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);
     }
     if (M.e_count % G::E) hipLaunchKernelGGL((t2::kt2_sigma<N1, false>), dim3(1), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);
+  });
+  return (int)hipGetLastError();
+}
+
+template <int N1, bool MODAL, bool VISC>
+static void launch_rhs2(const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U, const double* SG,
+                        const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s) {
+  using G = t2::Geo<N1>;
+  const int nb = (int)((M.e_count + G::E - 1) / G::E);
+  hipLaunchKernelGGL((t2::kt2_rhs<N1, MODAL, VISC>), dim3(nb), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
+}
+
+// last phase on meshes without walls; returns -1 where the v2 kernel does not cover the degree (caller falls back)
+int launch_rhs_tensor2(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
+                       const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s) {
+  if (M.e_count <= 0) return 0;
+  if (N1v < 2 || N1v > 6) return -1;     // accumulator planes are laid out for at most two full rounds per direction
+  const bool modal = ph.formulation != 0, visc = ph.formulation == 1;
+  ESDG_T2_DISPATCH(N1v, {
+    if constexpr (N1 <= 6) {
+      if (!modal) (launch_rhs2<N1, false, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
+      else if (visc) (launch_rhs2<N1, true, true>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
+      else (launch_rhs2<N1, true, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
+    }
   });
   return (int)hipGetLastError();
 }

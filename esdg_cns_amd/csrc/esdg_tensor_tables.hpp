@@ -53,7 +53,8 @@ struct TensorLayout {
 //     PD     = (Vq*Ph)[q,q]
 //   and NodeLayout::LI ints: FQ[4] = face node of face k, PID[NRND] = partner node of round r,
 //     AD = direction served in the antipodal round (even N1)
-//   face node fn, FaceLayout::LD doubles: EE[N1] (interpolation weights along its line), WFAC
+//   face node fn, FaceLayout::LD doubles: EE[N1] (interpolation weights along its line), WFAC,
+//     SVF[N1] = SF*WTF: volume-face SBP weight towards the j-th node of its line (the pairs as the FACE node sees them)
 //   and FaceLayout::LI ints: NODE0 = first node of its line, STRIDE = node stride along the line, K = face number k
 struct NodeLayout {
   int N1, NFULL, NRND, IQ, IPL, IPH, DG0, DG1, LW, PW, SVF, SVV, PD, LD;
@@ -66,8 +67,9 @@ struct NodeLayout {
         FQ(0), PID(4), AD(4 + 2 * ((n1 - 1) / 2) + (n1 % 2 == 0 ? 1 : 0)), LI(5 + 2 * ((n1 - 1) / 2) + (n1 % 2 == 0 ? 1 : 0)) {}
 };
 struct FaceLayout {
-  int N1, EE, WFAC, LD, NODE0, STRIDE, K, LI;
-  __host__ __device__ constexpr explicit FaceLayout(int n1) : N1(n1), EE(0), WFAC(n1), LD(n1 + 1), NODE0(0), STRIDE(1), K(2), LI(3) {}
+  int N1, EE, WFAC, SVF, LD, NODE0, STRIDE, K, LI;
+  __host__ __device__ constexpr explicit FaceLayout(int n1)
+      : N1(n1), EE(0), WFAC(n1), SVF(n1 + 1), LD(2 * n1 + 1), NODE0(0), STRIDE(1), K(2), LI(3) {}
 };
 
 // device-side handle: one buffer of NDBL doubles followed by NINT int32

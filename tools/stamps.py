@@ -20,13 +20,16 @@ for _ in range(50):
     eng.rhs_into(Qd, out)
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * 16)()
-L.esdg_debug_stamps(buf, 1)
 n = 20
-for _ in range(n):
-    eng.rhs_into(Qd, out)
-torch.cuda.synchronize()
-L.esdg_debug_stamps(buf, 1)
-v = np.array(list(buf), dtype=float)
-tot = v.sum()
-print("cycles per iteration (wave 0 of each workgroup), by stamp:", " ".join(f"{i}:{x / tot * 100:.1f}%" for i, x in enumerate(v) if x))
-print("sum per launch (cycles x workgroups):", tot / n)
+q, o = C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr())
+for ph in range(eng.nphases):      # one phase (= one kernel) at a time: the stamp slots are shared by the kernels
+    L.esdg_debug_stamps(buf, 1)
+    for _ in range(n):
+        _lib.check(eng.L.esdg_rhs_phase(eng.ctx, ph, q, o, None))
+    torch.cuda.synchronize()
+    L.esdg_debug_stamps(buf, 1)
+    v = np.array(list(buf), dtype=float)
+    tot = v.sum()
+    if tot:
+        print(f"phase {ph}: wave cycles by stamp:", " ".join(f"{i}:{x / tot * 100:.1f}%" for i, x in enumerate(v) if x),
+              f"| sum per launch {tot / n:.3e}")
