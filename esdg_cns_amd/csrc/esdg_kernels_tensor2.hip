@@ -28,7 +28,8 @@ constexpr int TW = 64;
 template <int N1> struct Cfg { static constexpr int GW = 1; };
 template <> struct Cfg<5> { static constexpr int GW = 2; };
 template <> struct Cfg<6> { static constexpr int GW = 4; };
-template <> struct Cfg<7> { static constexpr int GW = 4; };
+template <> struct Cfg<7> { static constexpr int GW = 2; };   // 2 elements per group: the accumulator planes stay under 64 KB
+template <> struct Cfg<8> { static constexpr int GW = 2; };
 
 template <int N1> struct Geo {
   static constexpr int GW = Cfg<N1>::GW, GT = TW * GW, Nq = N1 * N1, Nfq = 4 * N1;
@@ -846,10 +847,10 @@ static void launch_rhs2(const TensorTables& TT, const MeshDev& M, const Phys& ph
 int launch_rhs_tensor2(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
                        const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s) {
   if (M.e_count <= 0) return 0;
-  if (N1v < 2 || N1v > 6) return -1;     // accumulator planes are laid out for at most two full rounds per direction
+  if (N1v < 2 || N1v > 8) return -1;
   const bool modal = ph.formulation != 0, visc = ph.formulation == 1;
   ESDG_T2_DISPATCH(N1v, {
-    if constexpr (N1 <= 6) {
+    {
       if (!modal) (launch_rhs2<N1, false, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
       else if (visc) (launch_rhs2<N1, true, true>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
       else (launch_rhs2<N1, true, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
