@@ -554,7 +554,8 @@ struct esdg_ctx {
   Tables T{};
   TensorTables TT{};
   bool use_fast = false;
-  bool v1 = false;         // ESDG_V1=1 in the environment: round-1 tensor kernels only (A/B against esdg_kernels_tensor2.hip)
+  int v1 = 0;              // ESDG_V1=1 in the environment: round-1 tensor kernels only (A/B against esdg_kernels_tensor2.hip);
+                           // ESDG_V1=sigma / ESDG_V1=rhs: for that phase only (bit 0: phase 1, bit 1: last phase)
   int dim = 2, nfld = 4;   // 3 / 5 on the hexahedral path
   HexTables HT{};
   int au_nc = AU_NC;
@@ -568,6 +569,7 @@ struct esdg_ctx {
       d_Ds_v, d_Vq, d_Pq, d_geo, d_mapP, d_bc, d_vlid, d_wJq, d_sendlist, d_partial;
   DevBuf t_dbl, t_int, d_G9, d_Jq, d_nrm;
   DevBuf t_nd, t_ni, t_fd, t_fi;   // per-node rows of the v2 tensor kernels
+  DevBuf t_rvd, t_rvi, t_rfd, t_rfi;   // packed rows of kt2_rhs (RhsRows)
   DevBuf e_Vq2, e_wq2, e_x, e_y, e_J, e_Vf, e_wf;   // error functionals (esdg_error_setup)
   ErrDev E{};
   bool have_err = false;
@@ -707,7 +709,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   c->ph.parts = 3;
   c->ph.dbg = 0;
   if (const char* env = getenv("ESDG_DBG")) c->ph.dbg = atoi(env);
-  if (const char* env = getenv("ESDG_V1")) c->v1 = env[0] == '1';
+  if (const char* env = getenv("ESDG_V1")) c->v1 = env[0] == '1' ? 3 : env[0] == 's' ? 1 : env[0] == 'r' ? 2 : 0;
 
   // ---- collocated sparse operators -------------------------------------------------------
   Mat EfD, PhC, LfC, DrC, DsC, Vq, Pq;
@@ -890,6 +892,49 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
     c->TT.op1 = th.op[1];
     NodeHost nh;
     build_node_host(N1, th, nh);
+    {   // packed rows of the one-shot last-phase kernel (RhsRows), from the row-major host rows
+      const NodeLayout NLh(N1); const FaceLayout FLh(N1); const RhsRows RR(N1);
+      const int Nqh = N1 * N1, Nfqh = 4 * N1;
+      std::vector<double> vd((size_t)RR.NPV * Nqh * 2, 0.0), fd((size_t)RR.NPF * Nfqh * 2, 0.0);
+      std::vector<int32_t> vi((size_t)Nqh * 4, 0), fi((size_t)Nfqh, 0);
+      for (int q = 0; q < Nqh; ++q) {
+        const double* r = &nh.nd[(size_t)q * NLh.LD];
+        const int32_t* ri = &nh.ni[(size_t)q * NLh.LI];
+        std::vector<double> row;
+        for (int i = 0; i < RR.NRND; ++i) row.push_back(r[NLh.SVV + i]);
+        for (int k4 = 0; k4 < 4; ++k4) row.push_back(r[NLh.PW + k4]);
+        row.push_back(r[NLh.PD]);
+        for (size_t i = 0; i < row.size(); ++i) vd[((i / 2) * Nqh + q) * 2 + i % 2] = row[i];
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int i = 0; i < RR.NRND; ++i) w[i / 4] |= (uint32_t)ri[NLh.PID + i] << (8 * (i % 4));
+        for (int k4 = 0; k4 < 4; ++k4) w[2] |= (uint32_t)ri[NLh.FQ + k4] << (8 * k4);
+        w[3] = (N1 % 2 == 0) ? (uint32_t)ri[NLh.AD] : 0u;
+        for (int i = 0; i < 4; ++i) vi[(size_t)q * 4 + i] = (int32_t)w[i];
+      }
+      for (int f = 0; f < Nfqh; ++f) {
+        const double* r = &nh.fd[(size_t)f * FLh.LD];
+        const int32_t* ri = &nh.fi[(size_t)f * FLh.LI];
+        std::vector<double> row;
+        for (int j = 0; j < N1; ++j) row.push_back(r[FLh.SVF + j]);
+        row.push_back(r[FLh.WFAC]);
+        for (size_t i = 0; i < row.size(); ++i) fd[((i / 2) * Nfqh + f) * 2 + i % 2] = row[i];
+        fi[f] = ri[FLh.NODE0] | (ri[FLh.STRIDE] << 8) | (ri[FLh.K] << 16);
+      }
+      UP(t_rvd, vd); UP(t_rvi, vi); UP(t_rfd, fd); UP(t_rfi, fi);
+      c->TT.rhs_vd = c->t_rvd.as<double>(); c->TT.rhs_vi = c->t_rvi.as<int>();
+      c->TT.rhs_fd = c->t_rfd.as<double>(); c->TT.rhs_fi = c->t_rfi.as<int>();
+    }
+    {   // device layout: entry-major ([entry][node]), so that the lanes of an element read consecutive addresses
+      auto entry_major = [](auto& v, int rows, int ld) {
+        auto t = v;
+        for (int r = 0; r < rows; ++r)
+          for (int e = 0; e < ld; ++e) t[(size_t)e * rows + r] = v[(size_t)r * ld + e];
+        v.swap(t);
+      };
+      const NodeLayout NLh(N1); const FaceLayout FLh(N1);
+      entry_major(nh.nd, N1 * N1, NLh.LD); entry_major(nh.ni, N1 * N1, NLh.LI);
+      entry_major(nh.fd, 4 * N1, FLh.LD); entry_major(nh.fi, 4 * N1, FLh.LI);
+    }
     UP(t_nd, nh.nd); UP(t_ni, nh.ni); UP(t_fd, nh.fd); UP(t_fi, nh.fi);
     c->TT.node_d = c->t_nd.as<double>(); c->TT.node_i = c->t_ni.as<int>();
     c->TT.face_d = c->t_fd.as<double>(); c->TT.face_i = c->t_fi.as<int>();
@@ -1161,7 +1206,7 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
                        : launch_project(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, s);
   } else if (visc && phase == 1) {
     // v2 kernel: meshes without walls (the wall closures and the visc_test reduction stay with kt_sigma); ESDG_V1=1: A/B
-    if (ctx->use_fast && !ctx->M.bc && !ctx->v1)
+    if (ctx->use_fast && !ctx->M.bc && !(ctx->v1 & 1))
       rc = launch_sigma_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, SG, s);
     else
       rc = ctx->use_fast ? launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, SG, nullptr, s)
@@ -1170,7 +1215,7 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
     if (!rhs && !lf.Qw) return fail(ESDG_ERR_ARG, "rhs output is null");
     if (lf.Qw && !ctx->use_fast) return fail(ESDG_ERR_STATE, "the fused RK update needs the tensor kernels");
     rc = -1;
-    if (ctx->use_fast && !ctx->M.bc && !ctx->v1 && !ctx->ph.dbg)      // v2 kernel: meshes without walls, degrees N <= 5
+    if (ctx->use_fast && !ctx->M.bc && !(ctx->v1 & 2) && !ctx->ph.dbg)      // v2 kernel: meshes without walls, degrees N <= 5
       rc = launch_rhs_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s);
     if (rc == -1)
       rc = ctx->use_fast ? launch_rhs_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s)

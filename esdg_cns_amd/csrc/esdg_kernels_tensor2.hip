@@ -72,7 +72,7 @@ typedef double2 d2;
 // nodes s-fastest (SetupDG.jl:244): Vq[(a + N1 b), (i + N1 j)] = IQ[b,i] IQ[a,j].  c = IQ[a][:]; rowb = first slot of
 // row b, colq = slot b of row 0 (both of this lane's element).
 template <int N1>
-__device__ __forceinline__ void vq_apply(const double* c, d2* sA, d2* sB, unsigned tv, unsigned rowb, unsigned colq,
+__device__ __forceinline__ void vq_apply(const double* c, d2* sA, d2* sB0, d2* sB1, unsigned tv, unsigned rowb, unsigned colq,
                                          const double* x, double* U) {
   constexpr int NV = Geo<N1>::NV;
   if (x) {
@@ -91,18 +91,19 @@ __device__ __forceinline__ void vq_apply(const double* c, d2* sA, d2* sB, unsign
       w0 = __builtin_fma(c[i], p.x, w0); w1 = __builtin_fma(c[i], p.y, w1);
       w2 = __builtin_fma(c[i], t.x, w2); w3 = __builtin_fma(c[i], t.y, w3);
     }
-    sB[tv] = make_double2(w0, w1);
-    sB[NV + tv] = make_double2(w2, w3);
+    sB0[tv] = make_double2(w0, w1);
+    sB1[tv] = make_double2(w2, w3);
   }
   __syncthreads();
   // stage 2: Uq[a + N1 b] = sum_j IQ[a,j] W[b + N1 j]   (this lane: column b of W)
   {
-    const d2* r = sB + colq;
-    d2 p = r[0], t = r[NV];
+    const d2* r = sB0 + colq;
+    const d2* r1 = sB1 + colq;
+    d2 p = r[0], t = r1[0];
     U[0] = c[0] * p.x; U[1] = c[0] * p.y; U[2] = c[0] * t.x; U[3] = c[0] * t.y;
 #pragma unroll
     for (int j = 1; j < N1; ++j) {
-      p = r[N1 * j]; t = r[NV + N1 * j];
+      p = r[N1 * j]; t = r1[N1 * j];
       U[0] = __builtin_fma(c[j], p.x, U[0]); U[1] = __builtin_fma(c[j], p.y, U[1]);
       U[2] = __builtin_fma(c[j], t.x, U[2]); U[3] = __builtin_fma(c[j], t.y, U[3]);
     }
@@ -120,9 +121,9 @@ __device__ __forceinline__ void vq_apply(const double* c, d2* sA, d2* sB, unsign
 // kt2_sigma by s_memtime stamps); inline-asm loads with counted waits remove that wait, but hipcc then copies the asm
 // destinations between registers before the data has landed (audited in the .s), so the loads stay compiler-managed.
 // grid = what the device holds at once (occupancy query; ESDG_T2_WG_PER_CU overrides for experiments)
-template <class K>
-__host__ inline int persistent_grid(K kernel, int threads, int64_t ngroups) {
-  static int per_cu = 0, cus = 0;     // one kernel per instantiation of this template
+template <auto kernel>
+__host__ inline int persistent_grid(int threads, int64_t ngroups) {
+  static int per_cu = 0, cus = 0;     // one pair per kernel (the kernel is the template argument)
   if (!per_cu) {
     int dev = 0;
     cus = 256;
@@ -151,8 +152,10 @@ __device__ unsigned long long g_stamp[16];
 #define T2_STAMP_INIT                                                                        \
   unsigned long long t_prev, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};               \
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory")
+// (a sample of the workgroups: 12 same-address atomics from each of the 52429 workgroups of a one-shot launch at cfg3
+// would take ~7 ms and distort every wait)
 #define T2_STAMP_FLUSH                                                                       \
-  if (threadIdx.x == 0)                                                                      \
+  if (threadIdx.x == 0 && (blockIdx.x & 31) == 0)                                            \
     for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_stamp[i_], t_acc[i_])
 #else
 #define T2_STAMP(i)
@@ -199,6 +202,10 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
   double* sGeo = lds + RG;
   static_assert((R1 % 2) == 0 && (RV % 2) == 0 && (RD % 2) == 0, "pair planes must be 16-byte aligned");
 
+#ifdef ESDG_T2_POISON   // diagnostic build: LDS starts as NaN, so a read of a slot nobody wrote shows in the result
+  for (int i = threadIdx.x; i < NLDS; i += G::GT) lds[i] = __builtin_nan("");
+  __syncthreads();
+#endif
   const unsigned tid = threadIdx.x;
   // Lanes beyond the group's NV volume / NF face slots redo the work of slot tid - NV / tid % NF (same loads, same
   // values: their LDS writes are duplicates), slots of elements beyond the mesh compute on the data of slot 0: no
@@ -211,17 +218,17 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
   const int64_t KN = M.K * Nq;
 
   // per-lane table rows, once per workgroup
-  const double* nd = TT.node_d + q * NL.LD;
-  const int* ni = TT.node_i + q * NL.LI;
-  const double* fd = TT.face_d + fn * FL.LD;
-  const int* fi = TT.face_i + fn * FL.LI;
+  const double* nd_ = TT.node_d + q;      // entry-major tables: entry i of node q at [i * Nq + q]
+  const int* ni_ = TT.node_i + q;
+  const double* fd_ = TT.face_d + fn;
+  const int* fi_ = TT.face_i + fn;
   double cq[N1], dg0[N1], dg1[N1], ee[N1], lw[4];
 #pragma unroll
-  for (int i = 0; i < N1; ++i) { cq[i] = nd[NL.IQ + i]; dg0[i] = nd[NL.DG0 + i]; dg1[i] = nd[NL.DG1 + i]; ee[i] = fd[FL.EE + i]; }
+  for (int i = 0; i < N1; ++i) { cq[i] = nd_[(NL.IQ + i) * Nq]; dg0[i] = nd_[(NL.DG0 + i) * Nq]; dg1[i] = nd_[(NL.DG1 + i) * Nq]; ee[i] = fd_[(FL.EE + i) * Nfq]; }
   unsigned fq[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { lw[k] = nd[NL.LW + k]; fq[k] = ev * Nfq + ni[NL.FQ + k]; }
-  const unsigned fnode0 = ef * Nq + fi[FL.NODE0], fstride = fi[FL.STRIDE];
+  for (int k = 0; k < 4; ++k) { lw[k] = nd_[(NL.LW + k) * Nq]; fq[k] = ev * Nfq + ni_[(NL.FQ + k) * Nq]; }
+  const unsigned fnode0 = ef * Nq + fi_[(FL.NODE0) * Nfq], fstride = fi_[(FL.STRIDE) * Nfq];
   const unsigned gfo = 5 + 3 * (fn / N1);
 
   const int64_t e_end = M.e_begin + M.e_count;
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
 
     // ---- state at the Gauss node, entropy variables 2..4 --------------------------------------------------------------
     double U[4];
-    vq_apply<N1>(cq, sA, reinterpret_cast<d2*>(lds + R0 + 4 * NV), tv, rowb, ev * Nq + b, nullptr, U);
+    vq_apply<N1>(cq, sA, reinterpret_cast<d2*>(lds + R0 + 4 * NV), reinterpret_cast<d2*>(lds + R0 + 6 * NV), tv, rowb, ev * Nq + b, nullptr, U);
     T2_STAMP(2);
     double V[3];
     {
@@ -494,19 +501,24 @@ template <int N1, bool MODAL, bool VISC> struct RhsLds2 {
   static constexpr int NVV = (NL.NFULL + 1) / 2;                      // accumulator plane sets per direction, volume-volume
   static constexpr int NACC = 2 * NVV + (N1 % 2 == 0 ? 1 : 0) + 2;    // + antipodal + the two volume-face sets
   static constexpr int REC = 0;                                       // 3 pair planes [NV]: (rho,u) (v,beta) (lrho,lbeta)
-  static constexpr int VQB = REC + 6 * NV;                            // Vq / Pq second buffer (2 pair planes); stress jumps
-  static constexpr int SJ = 3 * NF + (NF & 1);                        // stress jumps: pair plane + single plane [NF]
-  static constexpr int ACC = VQB + (4 * NV > SJ ? 4 * NV : SJ);       // NACC x 2 pair planes [NV]
-  static constexpr int SGF = ACC + NACC * 4 * NV;                     // face totals G_f: 2 pair planes [NF]
-  static constexpr int GEO = SGF + 4 * NF;
+  // Before they are zeroed the accumulator planes hold Vq's second buffer (2 pair planes) and the 1D operator IQ (rows
+  // padded to even length); after the flux rounds the (dead) third record plane holds IP.
+  static constexpr int SGF = REC + 6 * NV;                            // face totals G_f: 2 pair planes [NF]
+  static constexpr int ACC = SGF + 4 * NF;                            // NACC x 2 pair planes [NV]
+  static constexpr int TABQ = ACC + 4 * NV, TABP = REC + 4 * NV;
+  static constexpr int GEO = ACC + NACC * 4 * NV;
   static constexpr int NLDS = GEO + ((G::E * GEO_STRIDE + 1) & ~1);
+  static_assert(N1 * (N1 + (N1 & 1)) <= 2 * NV, "operator fits the third record plane");
 };
 
-// One workgroup per group of elements.  (A persistent variant with next-group prefetch like kt2_sigma's was measured and
-// rejected: the loop-invariant table rows plus the loop-carried loads need 314 VGPRs, i.e. 2 workgroups per CU: 0.504 ms
-// against 0.427 ms for this form at cfg3; capped at 256 VGPRs it spills and takes 0.727 ms.)
+// One workgroup per group of E elements (one-shot).  Measured and rejected at cfg3 (profiles/experiments/README.md):
+//   * persistent over the groups with next-group prefetch: rows + loop-carried loads = 314 VGPRs, 2 workgroups per CU, 0.504 ms
+//     (capped at 256 VGPRs: spills, 0.727 ms);
+//   * persistent without prefetch (rows fetched once per workgroup, in registers or in LDS): 0.46 ms -- hoisted addresses
+//     spill, and resident workgroups that start together stay in step, so their load and compute phases do not overlap
+//     the way consecutive one-shot workgroups' do.
 template <int N1, bool MODAL, bool VISC>
-__global__ __launch_bounds__(Geo<N1>::GT) void kt2_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
+__global__ __launch_bounds__(Geo<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                                        const double* __restrict__ A_U, const double* __restrict__ SG,
                                                                        const double* __restrict__ B, double* __restrict__ rhs, LsrkFuse lf) {
   using G = Geo<N1>;
@@ -516,10 +528,15 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_rhs(TensorTables TT, MeshDev 
   constexpr FaceLayout FL(N1);
   constexpr int NFULL = NL.NFULL, NRND = NL.NRND, NVV = LD::NVV;
   constexpr int NGEO = E * GEO_STRIDE, GPT = (NGEO + G::GT - 1) / G::GT;
-  static_assert(LD::NLDS - LD::GEO >= GPT * G::GT || true, "");
-  __shared__ __align__(16) double lds[LD::GEO + GPT * G::GT];
+  // 1D operators IQ (Gauss nodes from nodal values) and IP (back), rows padded to an even length: a lane reads row a / b
+  // as N1P / 2 ds_read_b128 at the point of use instead of holding per-lane copies in registers across the flux rounds.
+  // Each is staged (from one register per lane, loaded with the group's data) into the third record plane while that
+  // plane holds no records.
+  constexpr int N1P = N1 + (N1 & 1);
+  constexpr TensorLayout TL(N1);
+  static_assert(TL.IP == TL.IQ + N1 * N1, "IQ and IP are adjacent in the 1D tables");
+  __shared__ __align__(16) double lds[LD::NLDS];
   d2* sRec = reinterpret_cast<d2*>(lds + LD::REC);
-  d2* sVqB = reinterpret_cast<d2*>(lds + LD::VQB);
   d2* sAcc = reinterpret_cast<d2*>(lds + LD::ACC);
   d2* sGf = reinterpret_cast<d2*>(lds + LD::SGF);
   double* sGeo = lds + LD::GEO;
@@ -534,61 +551,92 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_rhs(TensorTables TT, MeshDev 
   const bool inviscid = (ph.parts & 1) != 0, viscous = VISC && (ph.parts & 2) != 0;
   const bool vown = NV == G::GT || tid < (unsigned)NV, fown = NF == G::GT || tid < (unsigned)NF;   // not a duplicate lane
 
-  // per-lane table rows, once per workgroup
-  const double* nd = TT.node_d + q * NL.LD;
-  const int* ni = TT.node_i + q * NL.LI;
-  const double* fd = TT.face_d + fn * FL.LD;
-  const int* fi = TT.face_i + fn * FL.LI;
-  double svv[NRND > 0 ? NRND : 1], pw[4], svf[N1];
-  unsigned pid[NRND > 0 ? NRND : 1], fq[4];
-#pragma unroll
-  for (int r = 0; r < NRND; ++r) { svv[r] = nd[NL.SVV + r]; pid[r] = ev * Nq + ni[NL.PID + r]; }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { pw[k] = nd[NL.PW + k]; fq[k] = ev * Nfq + ni[NL.FQ + k]; }
-#pragma unroll
-  for (int j = 0; j < N1; ++j) svf[j] = fd[FL.SVF + j];
-  const double pd = nd[NL.PD], wfac = fd[FL.WFAC];
-  const unsigned fnode0 = ef * Nq + fi[FL.NODE0], fstride = fi[FL.STRIDE];
-  const int fdir = fi[FL.K] >> 1, ad = (N1 % 2 == 0) ? ni[NL.AD] : 0;
-  const unsigned gfo = 5 + 3 * (fn / N1);
-  const int opf = fdir ? TT.op1 : TT.op0;
-
   const int64_t e0 = M.e_begin + (int64_t)blockIdx.x * E;
   const int nE = (int)min((int64_t)E, M.e_begin + M.e_count - e0);
   const bool vact = tid < (unsigned)(nE * Nq);
+  constexpr RhsRows RR(N1);
+  T2_STAMP_INIT;
+#ifdef ESDG_T2_POISON   // diagnostic build: LDS starts as NaN, so a read of a slot nobody wrote shows in the result
+  for (int i = tid; i < LD::NLDS; i += G::GT) lds[i] = __builtin_nan("");
+  __syncthreads();
+#endif
 
   // ---- global loads -------------------------------------------------------------------------------------------------
+  // (the neighbour index first: the trace loads depend on it)
   double x[4], geo[GPT], qM[8], qP[8], bPn[3] = {0, 0, 0}, bOwn[3] = {0, 0, 0}, dvs[3] = {0, 0, 0};
+  const unsigned tvl = tv < (unsigned)(nE * Nq) ? tv : 0u, tfl = tf < (unsigned)(nE * Nfq) ? tf : 0u, tvg = tv;
+  const int64_t nf = e0 * Nfq + tfl;
+  const unsigned mp = (unsigned)M.mapP[nf];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) x[f] = Q[f * KN + e0 * Nq + tvl];
+#pragma unroll
+  for (int i = 0; i < GPT; ++i) { const unsigned n = tid + i * G::GT; geo[i] = M.geo[e0 * GEO_STRIDE + (n < (unsigned)(nE * GEO_STRIDE) ? n : 0u)]; }
+  static_assert(N1 * N1 <= G::GT, "one operator entry per lane");
+  double tabq = 0.0, tabp = 0.0;
+  if (MODAL) { const unsigned n = tid < (unsigned)(N1 * N1) ? tid : 0u; tabq = TT.dbl[TL.IQ + n]; tabp = TT.dbl[TL.IP + n]; }
+  // packed rows (RhsRows): NPV + NPF coalesced 16-byte loads and one int4 + one int per lane
+  double svv[NRND > 0 ? NRND : 1], pw[4], svf[N1], pd, wfac;
+  unsigned pid[NRND > 0 ? NRND : 1], fq[4], fnode0, fstride;
+  int fdir, ad;
   {
-    const unsigned tvl = tv < (unsigned)(nE * Nq) ? tv : 0u, tfl = tf < (unsigned)(nE * Nfq) ? tf : 0u;
-    const int64_t nf = e0 * Nfq + tfl;
-    const unsigned mp = (unsigned)M.mapP[nf];
+    const d2* vd = reinterpret_cast<const d2*>(TT.rhs_vd) + q;
+    const d2* fd = reinterpret_cast<const d2*>(TT.rhs_fd) + fn;
+    double rv[2 * RR.NPV], rf[2 * RR.NPF];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) x[f] = Q[f * KN + e0 * Nq + tvl];
+    for (int i = 0; i < RR.NPV; ++i) { const d2 t = vd[i * Nq]; rv[2 * i] = t.x; rv[2 * i + 1] = t.y; }
 #pragma unroll
-    for (int i = 0; i < GPT; ++i) { const unsigned n = tid + i * G::GT; geo[i] = M.geo[e0 * GEO_STRIDE + (n < (unsigned)(nE * GEO_STRIDE) ? n : 0u)]; }
+    for (int i = 0; i < RR.NPF; ++i) { const d2 t = fd[i * Nfq]; rf[2 * i] = t.x; rf[2 * i + 1] = t.y; }
+    const int4 wi = reinterpret_cast<const int4*>(TT.rhs_vi)[q];
+    const unsigned wf = (unsigned)TT.rhs_fi[fn];
+#pragma unroll
+    for (int r = 0; r < NRND; ++r) {
+      svv[r] = rv[r];
+      pid[r] = ev * Nq + (((unsigned)(r < 4 ? wi.x : wi.y) >> (8 * (r % 4))) & 255u);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { pw[k] = rv[NRND + k]; fq[k] = ev * Nfq + (((unsigned)wi.z >> (8 * k)) & 255u); }
+    pd = rv[NRND + 4];
+#pragma unroll
+    for (int j = 0; j < N1; ++j) svf[j] = rf[j];
+    wfac = rf[N1];
+    fnode0 = ef * Nq + (wf & 255u); fstride = (wf >> 8) & 255u;
+    fdir = (int)(wf >> 17); ad = (N1 % 2 == 0) ? wi.w : 0;
+  }
+  const unsigned gfo = 5 + 3 * (fn / N1);
+  const int opf = fdir ? TT.op1 : TT.op0;
+
+    T2_STAMP(9);     // loads that need no neighbour index issued
+#ifdef ESDG_T2_STAMP
+    { unsigned mpw = mp; asm volatile("" : "+v"(mpw)); (void)mpw; }
+    T2_STAMP(10);    // neighbour index landed
+#endif
+#ifdef ESDG_EXP_SMALLTRACE   // experiment: all trace reads from a cache-resident window (wrong results, same instruction stream)
+    const int64_t nfx = nf & ESDG_EXP_SMALLTRACE; const size_t mpx = mp & ESDG_EXP_SMALLTRACE;
+    const d2* aM = reinterpret_cast<const d2*>(A_U + nfx * FAU_NC);
+    const d2* aM2 = reinterpret_cast<const d2*>(A_U + (M.trace_nodes + nfx) * FAU_NC);
+    const d2* aP = reinterpret_cast<const d2*>(A_U + mpx * FAU_NC);
+    const d2* aP2 = reinterpret_cast<const d2*>(A_U + (M.trace_nodes + mpx) * FAU_NC);
+#else
     const d2* aM = reinterpret_cast<const d2*>(A_U + nf * FAU_NC);
     const d2* aM2 = reinterpret_cast<const d2*>(A_U + (M.trace_nodes + nf) * FAU_NC);
     const d2* aP = reinterpret_cast<const d2*>(A_U + (size_t)mp * FAU_NC);
     const d2* aP2 = reinterpret_cast<const d2*>(A_U + (M.trace_nodes + (size_t)mp) * FAU_NC);
+#endif
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const d2 m = aM[c], p = aP[c], m2 = aM2[c], p2 = aP2[c];
       qM[2 * c] = m.x; qM[2 * c + 1] = m.y; qP[2 * c] = p.x; qP[2 * c + 1] = p.y;
       qM[4 + 2 * c] = m2.x; qM[5 + 2 * c] = m2.y; qP[4 + 2 * c] = p2.x; qP[5 + 2 * c] = p2.y;
     }
-    if (VISC) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { bPn[c] = B[(size_t)mp * B_NC + c]; bOwn[c] = B[nf * B_NC + c]; dvs[c] = SG[c * KN + e0 * Nq + tvl]; }
-    }
-  }
 
   {
     // ---- state and geometry to LDS ----------------------------------------------------------------------------------------
     double U[4];
+    T2_STAMP(0);     // table rows + load issue
 #pragma unroll
-    for (int i = 0; i < GPT; ++i) sGeo[tid + i * G::GT] = geo[i];
+    for (int i = 0; i < GPT; ++i) { const unsigned n = tid + i * G::GT; if (n < (unsigned)NGEO) sGeo[n] = geo[i]; }
     if (MODAL) {
+      if (tid < (unsigned)(N1 * N1)) lds[LD::TABQ + (tid / N1) * N1P + tid % N1] = tabq;
       sRec[tv] = make_double2(x[0], x[1]);
       sRec[NV + tv] = make_double2(x[2], x[3]);
     } else {
@@ -598,11 +646,15 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_rhs(TensorTables TT, MeshDev 
 
     // ---- state at the Gauss node -> primitives + logs ---------------------------------------------------------------------
     if (MODAL) {
-      double cq[N1];
+      __syncthreads();   // operator rows staged
+      double cq[N1P];
+      const d2* row = reinterpret_cast<const d2*>(lds + LD::TABQ + a * N1P);
 #pragma unroll
-      for (int i = 0; i < N1; ++i) cq[i] = nd[NL.IQ + i];
-      vq_apply<N1>(cq, sRec, sVqB, tv, rowb, colq, nullptr, U);
+      for (int i = 0; i < N1P / 2; ++i) { const d2 t = row[i]; cq[2 * i] = t.x; cq[2 * i + 1] = t.y; }
+      vq_apply<N1>(cq, sRec, sAcc, sAcc + NV, tv, rowb, colq, nullptr, U);
+      __syncthreads();   // every lane is past its reads of the buffer in the accumulator planes, which are zeroed below
     }
+    T2_STAMP(1);     // Q landed + Vq
     double qh[6];
     prim_logs<MODAL>(U, qh);
     // (modal: the Vq input planes alias the record planes; every lane is past its stage-1 reads, which the second barrier
@@ -613,29 +665,10 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_rhs(TensorTables TT, MeshDev 
 #pragma unroll
     for (int p = 0; p < 2 * LD::NACC; ++p) sAcc[p * NV + tv] = make_double2(0.0, 0.0);
     __syncthreads();     // geometry, records and zeroed accumulators of every lane are in place
-
-    // ---- face lanes: interface flux and penalty from the two trace states (registers only) -----------------------------------
-    const double* gf = sGeo + ef * GEO_STRIDE;     // (slots of elements beyond the mesh hold the clamped loads: finite, unused)
-    double Gf[4], pnr[3] = {0, 0, 0};
-    {
-      const double* gn = gf + gfo;
-      if (VISC) {   // penalty tau*[[v]] (:817-837): the projected entropy variables are those OF the trace states
-        const double bM = 2 * Gas2<MODAL>::GM1 * qM[3], bP = 2 * Gas2<MODAL>::GM1 * qP[3];
-        const double tau = ph.viscous_dissp ? -rcp_refined(-bM) * ph.inv_Re : 0.0;
-        pnr[0] = tau * (bP * qP[1] - bM * qM[1]);
-        pnr[1] = tau * (bP * qP[2] - bM * qM[2]);
-        pnr[2] = tau * (bM - bP);
-      }
-      double Fn[4];
-      ec_flux_dir<MODAL>(qM, qP, gn[0], gn[1], Fn);
-      const double LFc = ph.inviscid_dissp ? ph.lf_scale * fmax(qM[6], qP[6]) * gn[2] : 0.0;
-      const double dU[4] = {qP[0] - qM[0], qP[0] * qP[1] - qM[0] * qM[1], qP[0] * qP[2] - qM[0] * qM[2], qP[7] - qM[7]};
-      const double wf = inviscid ? wfac : 0.0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) Gf[c] = wf * (Fn[c] - LFc * dU[c]);
-    }
+    T2_STAMP(2);     // prim_logs + records
 
     // ---- flux differencing ----------------------------------------------------------------------------------------------
+    // (volume-volume rounds first: they need no trace data, whose loads were issued last)
     double acc[4] = {0, 0, 0, 0};
     if (inviscid) {   // uniform
       const double* g = sGeo + ev * GEO_STRIDE;
@@ -670,6 +703,35 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_rhs(TensorTables TT, MeshDev 
           for (int c = 0; c < 4; ++c) lds_add(tgt + (c >> 1) * 2 * NV + (c & 1), -Fd[c]);
         }
       }
+    }
+    T2_STAMP(4);   // volume-volume rounds
+    if (VISC) {   // needed after the volume-face pairs: issued here, their destinations are not live during the rounds above
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { bPn[c] = B[(size_t)mp * B_NC + c]; bOwn[c] = B[nf * B_NC + c]; dvs[c] = SG[c * KN + e0 * Nq + tvl]; }
+    }
+    // ---- face lanes: interface flux and penalty from the two trace states (registers only) -----------------------------------
+    const double* gf = sGeo + ef * GEO_STRIDE;     // (slots of elements beyond the mesh hold the clamped loads: finite, unused)
+    double Gf[4], pnr[3] = {0, 0, 0};
+    {
+      const double* gn = gf + gfo;
+      if (VISC) {   // penalty tau*[[v]] (:817-837): the projected entropy variables are those OF the trace states
+        const double bM = 2 * Gas2<MODAL>::GM1 * qM[3], bP = 2 * Gas2<MODAL>::GM1 * qP[3];
+        const double tau = ph.viscous_dissp ? -rcp_refined(-bM) * ph.inv_Re : 0.0;
+        pnr[0] = tau * (bP * qP[1] - bM * qM[1]);
+        pnr[1] = tau * (bP * qP[2] - bM * qM[2]);
+        pnr[2] = tau * (bM - bP);
+      }
+      double Fn[4];
+      ec_flux_dir<MODAL>(qM, qP, gn[0], gn[1], Fn);
+      const double LFc = ph.inviscid_dissp ? ph.lf_scale * fmax(qM[6], qP[6]) * gn[2] : 0.0;
+      const double dU[4] = {qP[0] - qM[0], qP[0] * qP[1] - qM[0] * qM[1], qP[0] * qP[2] - qM[0] * qM[2], qP[7] - qM[7]};
+      const double wf = inviscid ? wfac : 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Gf[c] = wf * (Fn[c] - LFc * dU[c]);
+    }
+
+    T2_STAMP(3);     // traces landed + interface flux
+    if (inviscid) {
       // volume-face pairs by the face lanes: share of the volume node -> plane set of the face's direction
       {
         const double gxf = 2 * gf[opf], gyf = 2 * gf[2 + opf];
@@ -691,15 +753,16 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_rhs(TensorTables TT, MeshDev 
         }
       }
     }
+    T2_STAMP(5);     // volume-face pairs
+    if (VISC) {   // stress jump .5*((sxP-sxf)*nxJ + (syP-syf)*nyJ) + J * penalty (the penalty is lifted WITHOUT 1/J, quirk Q3).
+      // Its lift uses the weights of the inviscid lift times the face weight (LW = PW * WFAC) and enters the rhs with the
+      // opposite sign, so it rides in the face totals: one lift serves both, no second set of face planes in LDS.
+      const double Jf = gf[4], ws = viscous ? wfac : 0.0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Gf[c + 1] = __builtin_fma(-ws, __builtin_fma(Jf, pnr[c], .5 * (-bPn[c] - bOwn[c])), Gf[c + 1]);
+    }
     sGf[tf] = make_double2(Gf[0], Gf[1]);
     sGf[NF + tf] = make_double2(Gf[2], Gf[3]);
-    if (VISC) {   // stress jump .5*((sxP-sxf)*nxJ + (syP-syf)*nyJ) + J * penalty (the penalty is lifted WITHOUT 1/J, quirk Q3)
-      const double Jf = gf[4];
-      d2* sSjp = sVqB;
-      double* sSj2 = lds + LD::VQB + 2 * NF;
-      sSjp[tf] = make_double2(__builtin_fma(Jf, pnr[0], .5 * (-bPn[0] - bOwn[0])), __builtin_fma(Jf, pnr[1], .5 * (-bPn[1] - bOwn[1])));
-      sSj2[tf] = __builtin_fma(Jf, pnr[2], .5 * (-bPn[2] - bOwn[2]));
-    }
     __syncthreads();
 
     // ---- collocated rhs: -(Ph*QF + Lf*flux)/J  (+ viscous divergence and penalty) ---------------------------------------------
@@ -723,33 +786,29 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_rhs(TensorTables TT, MeshDev 
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c) R[c] = -r[c] * iJ;
-      if (VISC) {   // dg_div! :590-611: volume part from phase 1 + lift of the stress jumps (and J * penalty)
-        const d2* sSjp = sVqB;
-        const double* sSj2 = lds + LD::VQB + 2 * NF;
-        double dv[3] = {dvs[0], dvs[1], dvs[2]};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const d2 sj = sSjp[fq[k]];
-          const double lwk = nd[NL.LW + k];
-          dv[0] = __builtin_fma(lwk, sj.x, dv[0]); dv[1] = __builtin_fma(lwk, sj.y, dv[1]);
-          dv[2] = __builtin_fma(lwk, sSj2[fq[k]], dv[2]);
-        }
+      if (VISC) {   // dg_div! :590-611: volume part from phase 1 (the lift of the stress jumps came with the face totals)
         const double vs = viscous ? iJ : 0.0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) R[c + 1] = __builtin_fma(dv[c], vs, R[c + 1]);
+        for (int c = 0; c < 3; ++c) R[c + 1] = __builtin_fma(dvs[c], vs, R[c + 1]);
       }
     }
+    T2_STAMP(6);     // barrier + gather + lift
     // ---- out = Pq R (modal), store or fused low-storage RK stage ---------------------------------------------------------------
     double out[4];
     if (MODAL) {
-      double ipl[N1], iph[N1];
-#pragma unroll
-      for (int i = 0; i < N1; ++i) { ipl[i] = nd[NL.IPL + i]; iph[i] = nd[NL.IPH + i]; }
       d2* sA = sRec;                       // records are dead (all lanes are past the barrier after the flux rounds)
       d2* sB = sAcc;                       // accumulators: read above, rewritten only after the next barrier
       sA[tv] = make_double2(R[0], R[1]);
       sA[NV + tv] = make_double2(R[2], R[3]);
+      if (tid < (unsigned)(N1 * N1)) lds[LD::TABP + (tid / N1) * N1P + tid % N1] = tabp;   // IP into the (dead) third record plane
       __syncthreads();
+      double ipl[N1P], iph[N1P];
+      {
+        const d2* rl = reinterpret_cast<const d2*>(lds + LD::TABP + a * N1P);
+        const d2* rh = reinterpret_cast<const d2*>(lds + LD::TABP + b * N1P);
+#pragma unroll
+        for (int i = 0; i < N1P / 2; ++i) { const d2 t = rl[i], u = rh[i]; ipl[2 * i] = t.x; ipl[2 * i + 1] = t.y; iph[2 * i] = u.x; iph[2 * i + 1] = u.y; }
+      }
       {   // stage 1: W[a + N1 b] = sum_j IP[a,j] R[b + N1 j]   (this lane: column b of R)
         const d2* rr = sA + colq;
         d2 p = rr[0], t = rr[NV];
@@ -779,20 +838,26 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_rhs(TensorTables TT, MeshDev 
 #pragma unroll
       for (int f = 0; f < 4; ++f) out[f] = R[f];
     }
+    T2_STAMP(7);     // Pq
     if (vact) {
       if (lf.Qw) {   // fused low-storage RK stage (uniform)
+        double ro[4], qo[4];   // (res and Qw are distinct arrays: all loads first, then the stores)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { const int64_t idx = f * KN + e0 * Nq + tvg; ro[f] = lf.res[idx]; qo[f] = lf.Qw[idx]; }
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-          const int64_t idx = f * KN + e0 * Nq + tv;
-          const double rr = __builtin_fma(lf.a, lf.res[idx], lf.dt * out[f]);
+          const int64_t idx = f * KN + e0 * Nq + tvg;
+          const double rr = __builtin_fma(lf.a, ro[f], lf.dt * out[f]);
           lf.res[idx] = rr;
-          lf.Qw[idx] = __builtin_fma(lf.b, rr, lf.Qw[idx]);
+          lf.Qw[idx] = __builtin_fma(lf.b, rr, qo[f]);
         }
       } else {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) rhs[f * KN + e0 * Nq + tv] = out[f];
+        for (int f = 0; f < 4; ++f) rhs[f * KN + e0 * Nq + tvg] = out[f];
       }
     }
+    T2_STAMP(8);
+    T2_STAMP_FLUSH;
   }
 }
 
@@ -819,19 +884,23 @@ extern "C" int esdg_debug_stamps(unsigned long long* out16, int reset) {
 }
 #endif
 
+template <int N1>
+static void launch_sigma2(const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U, double* B,
+                          double* SG, hipStream_t s) {
+  using G = t2::Geo<N1>;
+  const int64_t nfull = M.e_count / G::E;
+  if (nfull > 0) {
+    const int nb = t2::persistent_grid<t2::kt2_sigma<N1, true>>(G::GT, nfull);
+    hipLaunchKernelGGL((t2::kt2_sigma<N1, true>), dim3(nb), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);
+  }
+  if (M.e_count % G::E) hipLaunchKernelGGL((t2::kt2_sigma<N1, false>), dim3(1), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);
+}
+
 // phase 1 on meshes without walls and without the visc_test reduction (the other variants stay with kt_sigma)
 int launch_sigma_tensor2(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
                          double* B, double* SG, hipStream_t s) {
   if (M.e_count <= 0) return 0;
-  ESDG_T2_DISPATCH(N1v, {
-    using G = t2::Geo<N1>;
-    const int64_t nfull = M.e_count / G::E;
-    if (nfull > 0) {
-      const int nb = t2::persistent_grid(t2::kt2_sigma<N1, true>, G::GT, nfull);
-      hipLaunchKernelGGL((t2::kt2_sigma<N1, true>), dim3(nb), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);
-    }
-    if (M.e_count % G::E) hipLaunchKernelGGL((t2::kt2_sigma<N1, false>), dim3(1), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);
-  });
+  ESDG_T2_DISPATCH(N1v, launch_sigma2<N1>(TT, M, ph, Q, A_U, B, SG, s));
   return (int)hipGetLastError();
 }
 

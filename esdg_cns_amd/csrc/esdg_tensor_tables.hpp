@@ -72,6 +72,17 @@ struct FaceLayout {
       : N1(n1), EE(0), WFAC(n1), SVF(n1 + 1), LD(2 * n1 + 1), NODE0(0), STRIDE(1), K(2), LI(3) {}
 };
 
+// Packed rows of the one-shot last-phase kernel kt2_rhs, which reloads its rows in every workgroup: a lane fetches its
+// doubles as NPV (volume node) / NPF (face node) coalesced 16-byte loads from pair planes [pair][node] and its indices as
+// one int4 / one int:
+//   volume doubles: SVV[NRND], PW[4], PD         face doubles: SVF[N1], WFAC
+//   volume int4: { PID[0..3] bytes, PID[4..7] bytes, FQ[0..3] bytes, AD }      face int: NODE0 | STRIDE << 8 | K << 16
+struct RhsRows {
+  int NRND, NDV, NPV, NDF, NPF;
+  __host__ __device__ constexpr explicit RhsRows(int n1)
+      : NRND(2 * ((n1 - 1) / 2) + (n1 % 2 == 0 ? 1 : 0)), NDV(NRND + 5), NPV((NRND + 6) / 2), NDF(n1 + 1), NPF((n1 + 2) / 2) {}
+};
+
 // device-side handle: one buffer of NDBL doubles followed by NINT int32
 struct TensorTables {
   const double* dbl;
@@ -84,6 +95,10 @@ struct TensorTables {
   const double* face_d;
   const int* face_i;
   int gface[4];
+  const double* rhs_vd;   // RhsRows: [NPV][Nq] double2
+  const int* rhs_vi;      // [Nq] int4
+  const double* rhs_fd;   // [NPF][Nfq] double2
+  const int* rhs_fi;      // [Nfq] int
 };
 
 }  // namespace esdg

@@ -1,14 +1,14 @@
 #!/bin/bash
-# Same-box comparison of the production build with every esdg_cns_amd/variants/*.so (ESDG_HIP_LIB): ms per RHS and the live
-# per-phase kernel times of bench.py, two passes.   bash tools/ab_variants.sh [bench.py args...]
+# Same-box A/B of library variants (esdg_cns_amd/variants/*.so, built with `python -m esdg_cns_amd.build -D... --out ...`)
+# against the main build: ms per RHS and per-phase kernel times.   bash tools/ab_variants.sh name1 name2 ...
 cd "$GRAFT_REPO_ROOT" || exit 1
-for pass in 1 2; do
-  for v in main esdg_cns_amd/variants/*.so; do
-    if [ "$v" = main ]; then unset ESDG_HIP_LIB; else export ESDG_HIP_LIB=$PWD/$v; fi
-    echo -n "$(basename $v .so): "
-    timeout -k 10 300 python bench.py --no-cpu-baseline "$@" 2>/dev/null | python3 -c "
+for rep in 1 2; do
+for v in main "$@"; do
+  if [ $v = main ]; then unset ESDG_HIP_LIB; else export ESDG_HIP_LIB=$PWD/esdg_cns_amd/variants/$v.so; fi
+  echo -n "$v: "
+  timeout -k 10 300 python bench.py --no-cpu-baseline 2>/dev/null | python3 -c "
 import sys, json
 r = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('ms_per_step %.4f  phases %s' % (r['ms_per_step'], ' '.join('%.4f' % p for p in r['roofline']['phase_ms'])))"
-  done
+done
 done
