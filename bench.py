@@ -346,7 +346,7 @@ def run(args):
         except Exception:
             pass
     kname = "kh_rhs (last phase: surface flux + flux differencing + lift)" if hexw else \
-        "kt_rhs (last phase: flux differencing + viscous divergence)"
+        "kt2_rhs (last phase: flux differencing + viscous divergence + projection)"
     roofline = {
         # the binding roof is fp64 VALU issue, not HBM (SQ counters, profiles/): `frac` stays the HBM figure the north star
         # names, `valu_frac` is the counted fp64 flops of the same kernel against the fp64 vector peak

@@ -64,7 +64,7 @@ for k in out:
 rhs_name = [k for k in out if "_rhs<" in k]
 sys.path.insert(0, root)
 import bench  # noqa: E402
-main = {k: v for k, v in out.items() if any(t in k for t in ("kt_project", "kt_sigma", "kt_rhs", "kh_project", "kh_rhs"))}
+main = {k: v for k, v in out.items() if any(t in k for t in ("kt_project", "kt_sigma", "kt_rhs", "kt2_sigma", "kt2_rhs", "kh_project", "kh_rhs"))}
 extra = {"kernel_src_sha": bench.kernel_source_hash(),
          "whole_rhs_hbm_bytes": sum(v["hbm_bytes_per_launch"] for v in main.values()),
          "whole_rhs_fp64_flops": sum(v.get("fp64_flops", 0.0) for v in main.values()) or None,
