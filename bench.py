@@ -268,10 +268,33 @@ def run(args):
         eng = engine.RhsEngine(rd, md, ops, form, rank=rank, nranks=world, rank_offsets=rank_offsets)
         K_total = Kx * Ky_total
     rccl_ranks = 0
-    if world > 1 and transport == "rccl":
-        rccl_ranks = eng.attach_rccl()
     Qd = eng.upload(Q)
     out = eng.new_state()
+    transport_note = None
+    if world > 1 and transport == "rccl":
+        # The library's communicator is attached and proven with two evaluations before anything is timed; if ANY rank
+        # fails (agreed through the bootstrap group), every rank falls back to the torch.distributed transport and the
+        # JSON line says so (config.transport / config.transport_note) -- a scaling number over the slower path is worth
+        # more than none.
+        err = ""
+        try:
+            rccl_ranks = eng.attach_rccl()
+            for _ in range(2):
+                eng.rhs_into(Qd, out)
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        flag = torch.tensor([1.0 if err else 0.0], device=torch.device("cuda", dev) if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if float(flag.item()) > 0:
+            try:
+                eng.L.esdg_comm_destroy(eng.ctx)
+            except Exception:  # noqa: BLE001
+                pass
+            eng.transport, transport, rccl_ranks = "torch", "torch", 0
+            transport_note = "library RCCL transport failed on a rank (" + (err or "another rank") + "); fell back to torch.distributed P2P"
+            if rank == 0:
+                print("bench.py: " + transport_note, file=sys.stderr)
     Np, K_local, nfld = eng.Np, eng.K, eng.nfld
 
     def sync_all():
@@ -374,7 +397,7 @@ def run(args):
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload, "elements": K_total, "elements_per_gpu": K_local, "Np": Np, "nfields": nfld,
                    "parallelism": f"element-{'slabs' if hexw else 'strips'} x{world}", "prewarm_evals": PREWARM_EVALS,
-                   "backend": args.backend if world > 1 else None, "transport": transport if world > 1 else None,
+                   "backend": args.backend if world > 1 else None, "transport": transport if world > 1 else None, "transport_note": transport_note,
                    "rccl_ranks": rccl_ranks, "visible_gpus": ndev, "oversubscribed": oversub},
         "rhs_evals_per_s": evals_per_s, "elements_per_s": K_total * evals_per_s,
         "ms_per_step_median": per[len(per) // 2], "ms_per_step_min": per[0], "ms_per_step_reps": [r / args.steps * 1e3 for r in reps],
