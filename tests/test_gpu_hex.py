@@ -209,3 +209,65 @@ def test_hex_curved_mesh_matches_oracle(eng_mod, oracle_lib, N, K3):
             scale = float(np.sum(np.abs(md.wJq)) * float(r.abs().max()))
             print(f"curved hex rhstest (LF off) {rt:.3e} scale {scale:.3e}")
             assert abs(rt) < 1e-12 * scale
+
+
+def _slab_periodic_state(x, y, z, LZ):
+    """Smooth 3D state with period 2 in x and y and LZ in z (one z-slab of the sharded box is then periodic on its own);
+    no exact zeros of a normal velocity at nodes (quirk Q1)."""
+    from esdg_cns_amd import physics as ph
+    cz = 2 * np.pi * (z - z.min()) / LZ
+    rho = 2 + .5 * np.sin(np.pi * x + .1) * np.cos(np.pi * y) * (1 + .2 * np.cos(cz + .3))
+    u = .3 * np.sin(cz + .2) + .05
+    v = 1 + .1 * np.cos(np.pi * x + .4)
+    w = .1 * np.sin(np.pi * (x + y) + .3) + .02 * np.cos(cz - .5)
+    p = 1 + .2 * np.cos(cz + .6) * np.sin(np.pi * y + .2)
+    return [np.asfortranarray(q) for q in ph.primitive_to_conservative_3d(rho, u, v, w, p)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Kx,Kzr,lf", [(8, 2, 0.25), (32, 4, 0.0)])
+def test_cfg5_rank0_slab_of_the_8_rank_box_over_the_library_rccl_transport(eng_mod, Kx, Kzr, lf):
+    """BASELINE config 5 in its 8-rank form (z-slabs of the periodic box): rank 0's slab with its ghost slots, send lists
+    and the library's RCCL transport in loopback (what goes to the slab below comes in from above: for a state that is
+    periodic over the slab exactly what ranks 1 and 7 would send).  Bit for bit the stand-alone periodic slab, also
+    through the fused LSRK stage."""
+    import copy
+    import torch
+    from esdg_cns_amd import setup_dg as sd
+    N, nr = 3, 8
+    Kzt = Kzr * nr
+
+    def build(Kz_total, e0, e1):
+        VX, VY, VZ, EToV = sd.uniform_hex_mesh(Kx, Kx, Kz_total)
+        VZ = VZ * (Kz_total / Kx)                       # same element size whatever the number of layers
+        rd = sd.init_reference_hex(N, sd.gauss_quad(0, 0, N))
+        md = sd.init_mesh_3d((VX, VY, VZ), EToV, rd, elem_range=(e0, e1))
+        sd.make_periodic_3d(md, rd)
+        ops = sd.hex_ops(rd)
+        sd.hex_driver_geometry(md, rd, hybrid=False)
+        return rd, md, ops
+
+    Ks = Kx * Kx * Kzr
+    rd, md, ops = build(Kzt, 0, Ks)
+    offsets = np.array([Ks * r for r in range(nr + 1)], dtype=np.int64)
+    sh = eng_mod.RhsEngine(rd, md, ops, eng_mod.EULER_HEX_COLLOCATED, lf_scale=lf, rank=0, nranks=nr, rank_offsets=offsets)
+    assert sh.attach_rccl(loopback=True) == 1 and sh.transport == "rccl"
+    LZ = 2.0 * Kzr / Kx
+    Q = _slab_periodic_state(md.xq, md.yq, md.zq, LZ)
+    _, md1s, _ = build(Kzr, 0, Ks)                      # the stand-alone periodic slab: the shard's own arrays, its mapP
+    md1 = copy.copy(md)
+    md1.mapP, md1.elem_offset, md1.Kglobal = md1s.mapP, 0, md.K
+    one = eng_mod.RhsEngine(rd, md1, ops, eng_mod.EULER_HEX_COLLOCATED, lf_scale=lf)
+    Qd = sh.upload(Q)
+    for _ in range(2):
+        got, ref = sh.rhs(Qd), one.rhs(Qd)
+        torch.cuda.synchronize()
+        assert torch.isfinite(got).all()
+        assert torch.equal(got, ref), float((got - ref).abs().max() / ref.abs().max())
+    q1, q2 = Qd.clone(), Qd.clone()
+    r1, r2 = torch.zeros_like(Qd), torch.zeros_like(Qd)
+    for k in range(3):
+        sh.rhs_lsrk_fused(q1, r1, -0.4 * k, 0.3, 1e-3)
+        one.rhs_lsrk_fused(q2, r2, -0.4 * k, 0.3, 1e-3)
+    torch.cuda.synchronize()
+    assert torch.equal(q1, q2)
