@@ -446,16 +446,29 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
 template <bool MODAL> struct Gas2 { static constexpr double GM1 = MODAL ? 0.4 : (1.4 - 1); };   // literal 0.4 in the CNS drivers
 
 // (gx,gy) . (Fx,Fy) of the entropy-conservative flux (euler_fluxes.jl:23-48 with logmean.jl:14-28) between the states
-// (rho,u,v,beta,lrho,lbeta); one refined reciprocal serves the three quotients; the |f| < 1e-4 series is selected
-template <bool MODAL>
-__device__ __forceinline__ void ec_flux_dir(const double* qL, const double* qR, double gx, double gy, double* F) {
+// (rho,u,v,beta,lrho,lbeta); one refined reciprocal serves the three quotients.  The reference's |f| < 1e-4 series branch
+// (logmean.jl:23-27) is taken per lane by selection (MODE 0); when EVERY lane of the wave takes the series for both means
+// (MODE 1: smooth regions, e.g. the far field of the vortex) or NO lane takes it for either (MODE 2) the unselected
+// half is not computed at all -- 13-15 of ~64 VALU instructions per flux.  The three variants evaluate the same
+// expressions with explicit FMAs, so a lane's result does not depend on which variant its wave ran (the ranged-launch
+// and shard tests compare bit for bit across different wave compositions).
+__device__ __forceinline__ double logmean_series_rho(double ravg, double vr) {
+  return ravg * __builtin_fma(vr, __builtin_fma(vr, __builtin_fma(vr, 0.026038857142857, -.0512), -.2), 1.0);
+}
+__device__ __forceinline__ double logmean_series_ibeta(double ib, double vb) {
+  return ib * __builtin_fma(vb, __builtin_fma(vb, .0912, .2), 1.0);
+}
+template <bool MODAL, int MODE>
+__device__ __forceinline__ void ec_flux_core(const double* qL, const double* qR, double gx, double gy, double* F, double dr, double ravg,
+                                             double db, double bavg, bool ser_r, bool ser_b) {
   constexpr double GM1 = Gas2<MODAL>::GM1;
-  const double dr = qR[0] - qL[0], ravg = .5 * (qR[0] + qL[0]);
-  const double db = qR[3] - qL[3], bavg = .5 * (qR[3] + qL[3]);
-  const double A = qL[4] - qR[4], Bl = qL[5] - qR[5];
-  const bool ser_r = fabs(dr) < 1e-4 * ravg, ser_b = fabs(db) < 1e-4 * bavg;
-  const double yr = ser_r ? ravg : A;
-  const double yb = ser_b ? bavg : db;
+  double yr, yb;
+  if (MODE == 1) { yr = ravg; yb = bavg; }
+  else {
+    const double A = qL[4] - qR[4];
+    yr = MODE == 2 ? A : (ser_r ? ravg : A);
+    yb = MODE == 2 ? db : (ser_b ? bavg : db);
+  }
   const double yp = qL[3] + qR[3];
   const double ybp = yb * yp;
   const double R = rcp_refined(yr * ybp);
@@ -463,19 +476,40 @@ __device__ __forceinline__ void ec_flux_dir(const double* qL, const double* qR, 
   const double ryr = R * yr;
   const double ib = ryr * yp;
   const double ip = ryr * yb;
-  const double fr = dr * ir, vr = fr * fr;
-  const double rholog = ser_r ? ravg * (1 + vr * (-.2 - vr * (.0512 - vr * 0.026038857142857))) : -fr;
-  const double fb = db * ib, vb = fb * fb;
-  const double ibetalog = ser_b ? ib * (1 + vb * (.2 + vb * .0912)) : -(Bl * ib);
+  const double fr = dr * ir;
+  const double fb = db * ib;
+  double rholog, ibetalog;
+  if (MODE == 2) {
+    rholog = -fr;
+    ibetalog = -((qL[5] - qR[5]) * ib);
+  } else {
+    const double sr = logmean_series_rho(ravg, fr * fr), sb = logmean_series_ibeta(ib, fb * fb);
+    if (MODE == 1) { rholog = sr; ibetalog = sb; }
+    else { rholog = ser_r ? sr : -fr; ibetalog = ser_b ? sb : -((qL[5] - qR[5]) * ib); }
+  }
   const double uavg = .5 * (qL[1] + qR[1]), vavg = .5 * (qL[2] + qR[2]);
-  const double unorm = qL[1] * qR[1] + qL[2] * qR[2];
+  const double unorm = __builtin_fma(qL[2], qR[2], qL[1] * qR[1]);
   const double pa = ravg * ip;
-  const double f4aux = rholog * ibetalog * (1.0 / (2 * GM1)) + pa + .5 * rholog * unorm;
-  const double un = gx * uavg + gy * vavg;
+  const double f4aux = __builtin_fma(.5 * rholog, unorm, __builtin_fma(rholog * ibetalog, 1.0 / (2 * GM1), pa));
+  const double un = __builtin_fma(gy, vavg, gx * uavg);
   F[0] = rholog * un;
-  F[1] = F[0] * uavg + pa * gx;
-  F[2] = F[0] * vavg + pa * gy;
+  F[1] = __builtin_fma(F[0], uavg, pa * gx);
+  F[2] = __builtin_fma(F[0], vavg, pa * gy);
   F[3] = f4aux * un;
+}
+template <bool MODAL>
+__device__ __forceinline__ void ec_flux_dir(const double* qL, const double* qR, double gx, double gy, double* F) {
+  const double dr = qR[0] - qL[0], ravg = .5 * (qR[0] + qL[0]);
+  const double db = qR[3] - qL[3], bavg = .5 * (qR[3] + qL[3]);
+  const bool ser_r = fabs(dr) < 1e-4 * ravg, ser_b = fabs(db) < 1e-4 * bavg;
+#ifdef ESDG_T2_NO_UNIFORM_LOGMEAN
+  ec_flux_core<MODAL, 0>(qL, qR, gx, gy, F, dr, ravg, db, bavg, ser_r, ser_b);
+#else
+  const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+  if (__builtin_amdgcn_ballot_w64(ser_r && ser_b) == active) ec_flux_core<MODAL, 1>(qL, qR, gx, gy, F, dr, ravg, db, bavg, ser_r, ser_b);
+  else if (__builtin_amdgcn_ballot_w64(ser_r || ser_b) == 0) ec_flux_core<MODAL, 2>(qL, qR, gx, gy, F, dr, ravg, db, bavg, ser_r, ser_b);
+  else ec_flux_core<MODAL, 0>(qL, qR, gx, gy, F, dr, ravg, db, bavg, ser_r, ser_b);
+#endif
 }
 
 // conservative -> (rho,u,v,beta,log rho,log beta)
