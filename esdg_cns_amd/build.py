@@ -56,6 +56,7 @@ def build(force=False, verbose=False, defines=(), out=OUT, tag=""):
 
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4) or 1) as ex:
         list(ex.map(run, jobs))
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
     objs = [os.path.join(odir, os.path.basename(s) + ".o") for s in _sources()]
     run([hipcc, "--offload-arch=gfx950", "-shared", "-o", out] + objs + LINK)
     return out
