@@ -273,3 +273,25 @@ def test_pure_c_sharded_driver_over_the_library_rccl_transport(tmp_path):
         out = subprocess.check_output([exe] + args, text=True, timeout=300)
         print(out.strip())
         assert "OK" in out and "RCCL comm size 1" in out
+
+
+@pytest.mark.parametrize("formulation", ["cns", "hex", "cavity"])
+def test_two_gloo_ranks_sharing_the_gpu_match_the_single_engine(formulation):
+    """The multi-rank product path end to end (RhsEngine + halo plan + overlapped schedule + HaloExchanger over
+    torch.distributed, traces staged through the host with gloo): two fresh rank processes share the GPU and must
+    reproduce the single engine -- tools/check_sharded.py exits 0 only for bitwise / round-off agreement of the RHS, the
+    fused LSRK stage and the reduced error functional."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tools", "check_sharded.py"), "--backend", "gloo", "--formulation", formulation]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    print(p.stdout[-1500:])
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "MISMATCH" not in p.stdout and "check_sharded" in p.stdout
