@@ -582,6 +582,9 @@ struct esdg_ctx {
   char* ws = nullptr;
   size_t off_AU = 0, off_Av = 0, off_B = 0, off_S = 0;
   int64_t int_lo = 0, int_hi = 0;   // longest run of elements [int_lo, int_hi) that touch no ghost slot
+  // nested interiors: nest_lo/hi[0] = [int_lo, int_hi); nest[p] = the longest run inside nest[p-1] all of whose face
+  // neighbours lie in nest[p-1] -- what phase p can compute from data the same stream produced in phase p-1
+  int64_t nest_lo[4] = {0, 0, 0, 0}, nest_hi[4] = {0, 0, 0, 0};
   static constexpr int NPARTIAL = 1024;
   // RCCL transport of the halo exchange (esdg_comm_init): communicator, its stream, and per producing phase one event
   // "packed buffers ready" (compute stream -> comm stream) and one "traces landed" (comm stream -> compute stream)
@@ -592,15 +595,24 @@ struct esdg_ctx {
   hipStream_t cstream = nullptr;
   static constexpr int MAXPH = 4;
   hipEvent_t ev_ready[MAXPH] = {nullptr, nullptr, nullptr, nullptr}, ev_landed[MAXPH] = {nullptr, nullptr, nullptr, nullptr};
+  // boundary stream of the sharded schedule: the two boundary strips of a phase, their packs and the posting of the exchange
+  // run beside the interior launch of the same phase (ev_int: interior of a phase done on the caller's stream; ev_bnd:
+  // boundary strips + packs of a phase done on bstream; ev_start: the caller's stream at entry)
+  hipStream_t bstream = nullptr;
+  hipEvent_t ev_int[MAXPH] = {nullptr, nullptr, nullptr, nullptr}, ev_bnd[MAXPH] = {nullptr, nullptr, nullptr, nullptr}, ev_start = nullptr;
   bool posted[MAXPH] = {false, false, false, false};
   DevBuf d_red;   // scratch of esdg_comm_allreduce
   ~esdg_ctx() {
     for (int i = 0; i < MAXPH; ++i) {
       if (ev_ready[i]) (void)hipEventDestroy(ev_ready[i]);
       if (ev_landed[i]) (void)hipEventDestroy(ev_landed[i]);
+      if (ev_int[i]) (void)hipEventDestroy(ev_int[i]);
+      if (ev_bnd[i]) (void)hipEventDestroy(ev_bnd[i]);
     }
+    if (ev_start) (void)hipEventDestroy(ev_start);
     if (comm) (void)ncclCommDestroy(comm);
     if (cstream) (void)hipStreamDestroy(cstream);
+    if (bstream) (void)hipStreamDestroy(bstream);
   }
 };
 
@@ -620,6 +632,24 @@ static void set_interior(esdg_ctx* c, const std::vector<int32_t>& mapP, int64_t 
   }
   c->int_lo = best_lo;
   c->int_hi = best_hi;
+  c->nest_lo[0] = best_lo; c->nest_hi[0] = best_hi;
+  for (int p = 1; p < 4; ++p) {
+    const int64_t plo = c->nest_lo[p - 1], phi = c->nest_hi[p - 1];
+    int64_t blo = plo, bhi = plo, rlo = plo;
+    for (int64_t e = plo; e <= phi; ++e) {
+      bool out = e == phi;
+      if (!out)
+        for (int i = 0; i < Nfq; ++i) {
+          const int64_t ne = mapP[(size_t)e * Nfq + i] / Nfq;     // (ghost slots lie beyond K: outside every range)
+          if (ne < plo || ne >= phi) { out = true; break; }
+        }
+      if (out) {
+        if (e - rlo > bhi - blo) { blo = rlo; bhi = e; }
+        rlo = e + 1;
+      }
+    }
+    c->nest_lo[p] = blo; c->nest_hi[p] = bhi;
+  }
 }
 
 extern "C" {
@@ -1344,10 +1374,17 @@ int esdg_comm_init(esdg_ctx* ctx, const void* id_bytes, int rank, int nranks) {
   std::memcpy(&id, id_bytes, sizeof id);
   NCCL_TRY(ncclCommInitRank(&ctx->comm, nranks, id, rank));
   NCCL_TRY(ncclCommCount(ctx->comm, &ctx->comm_size));
+  // (Normal priority on purpose: with high-priority side streams the RCCL copies and the boundary strips did start at
+  // once, but the interior launches on the caller's stream ran 35-70 % longer -- 2.21 vs 1.54 ms per evaluation of the
+  // cfg4 strip, tools/strip_overhead.py.)
   HIP_TRY(hipStreamCreateWithFlags(&ctx->cstream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&ctx->bstream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming));
   for (int i = 0; i < esdg_ctx::MAXPH; ++i) {
     HIP_TRY(hipEventCreateWithFlags(&ctx->ev_ready[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ctx->ev_landed[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_int[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_bnd[i], hipEventDisableTiming));
   }
   int rc = ctx->d_red.alloc(sizeof(double) * 64);
   if (rc) return rc;
@@ -1428,26 +1465,60 @@ static int rhs_sharded_impl(esdg_ctx* ctx, const double* Q, double* rhs, const L
   const int64_t lo = ctx->int_lo, hi = ctx->int_hi, K = ctx->K;
   const char* env = getenv("ESDG_NO_OVERLAP");
   const bool overlap = ctx->use_fast && hi > lo && (hi - lo) < K && !(env && env[0] == '1');
+  // ESDG_ONE_STREAM=1: the boundary strips on the caller's stream, after the interior (the schedule before the boundary
+  // stream existed; A/B hook).  ESDG_NO_NEST=1: boundary stream, but the same interior range in every phase.
+  const char* env1 = getenv("ESDG_ONE_STREAM");
+  const char* env2 = getenv("ESDG_NO_NEST");
+  hipStream_t b = (overlap && !(env1 && env1[0] == '1')) ? ctx->bstream : s;
+  // Nested interiors (see esdg_ctx::nest_lo): the caller's stream computes phase p on nest[p] and never waits for the
+  // boundary stream inside an evaluation; the boundary stream computes the complement (one row more per phase on a strip),
+  // waits for the interior of the previous phase and for the traces, packs and posts.  Used when the last nest is most of
+  // the shard; otherwise every phase uses nest[0] and the caller's stream waits for the previous phase's boundary strips.
+  const int np = ctx->nphases;
+  const bool nested = b != s && !(env2 && env2[0] == '1') && (ctx->nest_hi[np - 1] - ctx->nest_lo[np - 1]) * 4 >= K * 3;
   for (int i = 0; i < esdg_ctx::MAXPH; ++i) ctx->posted[i] = false;
   int rc = 0;
-  for (int ph = 0; ph < ctx->nphases; ++ph) {
-    const LsrkFuse& f = (ph == ctx->nphases - 1) ? lf : none;
+  if (b != s) {   // the boundary stream starts where the caller's stream stands
+    HIP_TRY(hipEventRecord(ctx->ev_start, s));
+    HIP_TRY(hipStreamWaitEvent(b, ctx->ev_start, 0));
+  }
+  for (int ph = 0; ph < np; ++ph) {
+    const LsrkFuse& f = (ph == np - 1) ? lf : none;
     bool outgoing = false;
     for (const Exchange& x : ctx->xch) outgoing = outgoing || x.after_phase == ph;
     if (!overlap) {
       if ((rc = wait_exchanges(ctx, ph, s)) != 0) return rc;
       if ((rc = rhs_phase_impl(ctx, ph, Q, rhs, f, stream)) != 0) return rc;   // packs what it produced
-    } else {
-      if (ph > 0 && (rc = rhs_phase_impl(ctx, ph, Q, rhs, f, stream, lo, hi - lo)) != 0) return rc;
-      if ((rc = wait_exchanges(ctx, ph, s)) != 0) return rc;
-      if ((rc = rhs_phase_impl(ctx, ph, Q, rhs, f, stream, 0, lo)) != 0) return rc;
-      if ((rc = rhs_phase_impl(ctx, ph, Q, rhs, f, stream, hi, K - hi)) != 0) return rc;
-      for (int x = 0; x < (int)ctx->xch.size(); ++x)
-        if (ctx->xch[x].after_phase == ph && (rc = esdg_halo_pack(ctx, x, stream)) != 0) return rc;
+      if (outgoing && (rc = post_exchanges(ctx, ph, s)) != 0) return rc;
+      continue;
     }
-    if (outgoing && (rc = post_exchanges(ctx, ph, s)) != 0) return rc;
-    if (overlap && ph == 0 && (rc = rhs_phase_impl(ctx, 0, Q, rhs, none, stream, lo, hi - lo)) != 0) return rc;
+    const int64_t ilo = nested ? ctx->nest_lo[ph] : lo, ihi = nested ? ctx->nest_hi[ph] : hi;
+    // (Measured on the cfg4 strip, rocprofv3 timelines via tools/strip_timeline.py / strip_modes.py: a saturating launch
+    // keeps the slots it frees -- kernels of another stream that arrive later run only when it has drained, unless they
+    // arrive while it is still ramping up.  High-priority side streams fix that but slow the interior launches by 35-70 %;
+    // delaying the strips of the persistent kt2_sigma phase until its interior is done moves them behind the last
+    // phase's interior.  Both were worse than letting the strips start beside the interior.)
+    // Interior of this phase on the caller's stream; beside it, on the boundary stream: wait for the traces of the previous
+    // phase, the boundary strips, the packs, the posting of this phase's exchange.  An interior element next to a boundary
+    // strip reads that strip's traces of the previous phase (not nested: hence the wait for ev_bnd) and vice versa (ev_int).
+    if (b != s && !nested && ph > 0) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_bnd[ph - 1], 0));
+    if (b == s && ph == 0) {
+      // one stream: boundary strips first so that the exchange is in flight during the interior
+    } else {
+      if ((rc = rhs_phase_impl(ctx, ph, Q, rhs, f, stream, ilo, ihi - ilo)) != 0) return rc;
+      if (b != s) HIP_TRY(hipEventRecord(ctx->ev_int[ph], s));
+    }
+    if (b != s && ph > 0) HIP_TRY(hipStreamWaitEvent(b, ctx->ev_int[ph - 1], 0));
+    if ((rc = wait_exchanges(ctx, ph, b)) != 0) return rc;
+    if ((rc = rhs_phase_impl(ctx, ph, Q, rhs, f, b, 0, ilo)) != 0) return rc;
+    if ((rc = rhs_phase_impl(ctx, ph, Q, rhs, f, b, ihi, K - ihi)) != 0) return rc;
+    for (int x = 0; x < (int)ctx->xch.size(); ++x)
+      if (ctx->xch[x].after_phase == ph && (rc = esdg_halo_pack(ctx, x, b)) != 0) return rc;
+    if (outgoing && (rc = post_exchanges(ctx, ph, b)) != 0) return rc;
+    if (b != s) HIP_TRY(hipEventRecord(ctx->ev_bnd[ph], b));
+    if (b == s && ph == 0 && (rc = rhs_phase_impl(ctx, 0, Q, rhs, none, stream, lo, hi - lo)) != 0) return rc;
   }
+  if (b != s && overlap) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_bnd[np - 1], 0));   // the caller's stream sees all of it
   return ESDG_OK;
 }
 
