@@ -177,7 +177,7 @@ def kernel_source_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "esdg_cns_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):
+        if f.endswith(".hpp") or (f.startswith("esdg_kernels") and f.endswith(".hip")):   # device code only (not the host API)
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
