@@ -403,4 +403,43 @@ function rhs(e::Engine, Q, flux_fun = nothing, compute_rhstest = false)
     Tuple(out), rhstest
 end
 
+# ---- the scripts' own signatures ---------------------------------------------------------------------------------
+# A driver that deletes its inline `rhs` / `rhsRK!` definitions and says `using ESDGHip.Scripts` keeps every call site
+# unchanged.  What the scripts read from globals (`Ef`, `mu`, `lambda`, `Pr`) is handed over once with `bind!`; engines are
+# created on first use and cached per (md, ops) pair.  Host arrays in and out per call (PCIe-bound: for validation and
+# for runs where the time loop is not worth porting; the device-resident loop is section 2 of INTEGRATION.md).
+module Scripts
+using ..ESDGHip
+export bind!, rhs, rhsRK!
+const CTX = Dict{Symbol,Any}()
+const ENGINES = IdDict{Any,Any}()
+"globals of the driver the reference functions read: `bind!(rd = rd, Ef = Ef)` (Euler quad / hex), `bind!(rd = rd, mu = mu, lambda = lambda, Pr = Pr)` (CNS)"
+bind!(; kw...) = (for (k, v) in kw; CTX[k] = v; end; nothing)
+function engine_for(key, make)
+    haskey(ENGINES, key) || (ENGINES[key] = make())
+    ENGINES[key]
+end
+"`rhsQ, rhstest = rhs(Q, md, ops, flux_fun, compute_rhstest)` -- dg2D_euler_quad.jl:141 (7-tuple `ops`, 4 fields) and dg3D_euler_hex.jl:167 (5 fields)"
+function rhs(Q, md, ops, flux_fun, compute_rhstest = false)
+    e = engine_for((md, ops), () -> length(Q) == 5 ?
+        ESDGHip.HexEngine(CTX[:rd], md, ops[1], ops[2], ops[3], ops[end-1], ops[end], CTX[:Ef]) :
+        ESDGHip.Engine(CTX[:rd], md, ops, CTX[:Ef]))
+    ESDGHip.rhs(e, Q, flux_fun, compute_rhstest)
+end
+"""
+`rhsQ, rhstest, rhstest_visc = rhsRK!(Q, rd, md, Re, BCTYPE, ops, euler_fluxes, inviscid_dissp, viscous_dissp, work...)`
+-- dg2D_CNS_cavity_optimized.jl:955; the work arrays are accepted and ignored.  Walls: `bind!(lid = ..., vlid = ...)`
+as for `CnsEngine`.
+"""
+function rhsRK!(Q, rd, md, Re, BCTYPE, ops, flux_fun, inviscid_dissp, viscous_dissp, work...)
+    e = engine_for((md, ops, BCTYPE), () -> ESDGHip.CnsEngine(rd, md, ops; Re = Re, mu = CTX[:mu], lambda = CTX[:lambda], Pr = CTX[:Pr],
+        BCTYPE = BCTYPE, inviscid_dissp = inviscid_dissp, viscous_dissp = viscous_dissp,
+        lid = get(CTX, :lid, nothing), vlid = get(CTX, :vlid, nothing)))
+    rhsQ, _ = ESDGHip.rhs(e, Q)                     # esdg_rhs_host: the sum of both parts
+    ESDGHip.upload!(e, Q)
+    rhstest, rhstest_visc = ESDGHip.rhsRK!(e; compute_rhstest = true)
+    rhsQ, rhstest, rhstest_visc
+end
+end # module Scripts
+
 end # module
