@@ -1892,7 +1892,9 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
                                  {35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0}};
   static const double E[7] = {71.0 / 57600.0, 0.0, -71.0 / 16695.0, 71.0 / 1920.0, -17253.0 / 339200.0, 22.0 / 525.0, -1.0 / 40.0};
   if (!ctx || !Q || !Qtmp || !k || !err_est) return fail(ESDG_ERR_ARG, "null argument");
-  if (ctx->nghost) return fail(ESDG_ERR_STATE, "esdg_dopri45_attempt needs an unsharded mesh");
+  if (ctx->nghost && !ctx->comm)
+    return fail(ESDG_ERR_STATE, "esdg_dopri45_attempt on a sharded mesh needs the library's communicator (esdg_comm_init): the "
+                                "error norm is a sum over all ranks");
   const int64_t n = (int64_t)ctx->nfld * ctx->K * ctx->Np;
   for (int s = 1; s < 7; ++s) {
     int rc = esdg_axpy_stages(Qtmp, Q, k, A[s], s, dt, n, stream);
@@ -1902,7 +1904,9 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
   double acc = 0.0;
   int rc = esdg_dopri_error(Q, k, E, 7, err_tol, n, &acc, stream);
   if (rc) return rc;
-  *err_est = std::sqrt(acc / (double)n);    // sqrt(sum/(length(Q[1])*4)), :1021
+  double tot[2] = {acc, (double)n};
+  if (ctx->nghost && (rc = esdg_comm_allreduce(ctx, tot, 2, 0, stream)) != 0) return rc;   // every rank gets the same estimate
+  *err_est = std::sqrt(tot[0] / tot[1]);    // sqrt(sum/(length(Q[1])*4)), :1021, over the whole mesh
   return ESDG_OK;
 }
 

@@ -417,3 +417,17 @@ def test_rccl_transport_inside_the_library_loopback(E, form, N, Kx, Kyr):
     if same_inputs:
         assert torch.equal(q1, q2)
     assert sh.allreduce([1.5, -2.0], "sum") == [1.5, -2.0] and sh.allreduce([3.0], "max") == [3.0]
+    # one DOPRI45 attempt (stages 2..7 + Hairer estimate, cavity_optimized.jl:1002-1021) through the sharded schedule: the
+    # error norm is reduced over the communicator (here: this rank alone, so it must equal the stand-alone strip's)
+    outs = []
+    for eng in (sh, one):
+        k = [torch.zeros_like(Qd) for _ in range(7)]
+        eng.rhs_into(Qd, k[0])
+        Qtmp = torch.empty_like(Qd)
+        ptrs = (C.c_void_p * 7)(*[t.data_ptr() for t in k])
+        err = C.c_double(0.0)
+        E.check(eng.L.esdg_dopri45_attempt(eng.ctx, C.c_void_p(Qd.data_ptr()), C.c_void_p(Qtmp.data_ptr()), ptrs, 2e-3, 1e-5, C.byref(err),
+                                           eng._stream()))
+        torch.cuda.synchronize()
+        outs.append((Qtmp, err.value))
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and outs[0][1] > 0
