@@ -60,6 +60,27 @@ def test_euler_collocated_matches_oracle(eng_mod, oracle_lib, N, Kx, Ky):
         assert e_gpu <= TOL, e_gpu         # strict north-star bound where the reference is well conditioned
 
 
+@pytest.mark.parametrize("form,N,Kx,Ky", [("euler", 4, 1, 1), ("euler", 3, 2, 1), ("euler", 2, 1, 3), ("cns", 4, 1, 1), ("cns", 4, 2, 1),
+                                          ("cns", 3, 1, 3), ("cns", 2, 1, 1)])
+def test_degenerate_periodic_meshes_match_oracle(eng_mod, oracle_lib, form, N, Kx, Ky):
+    """The smallest periodic meshes: one element that is its own neighbour on all four faces, two elements that meet on
+    two faces each, a single column -- every group is a partial group, every mapP entry wraps."""
+    if form == "euler":
+        rd, md, ops, Q = product_euler_problem(N, Kx, Ky)
+        p = as_oracle_problem(rd, md, ops, Q)
+        f64, truth = _euler(p)
+        eng = eng_mod.RhsEngine(rd, md, p.ops, eng_mod.EULER_COLLOCATED)
+        Qw = steep_state(md.xq, md.yq)
+        truth_gate(f"euler N={N} {Kx}x{Ky} tiny", _gpu_rhs(eng, Qw), f64(Qw), truth(Qw))
+    else:
+        rd, md, ops, Q = product_cns_problem(N, Kx, Ky)
+        p = as_oracle_problem(rd, md, ops, Q, **PHYS)
+        o, q = _cns(p)
+        eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, Re=p.Re, mu=p.mu, lam=p.lam, Pr=p.Pr)
+        Qw = steep_state(md.x, md.y)
+        truth_gate(f"cns N={N} {Kx}x{Ky} tiny", _gpu_rhs(eng, Qw), o.rhsRK(Qw, False)[0], q.rhsRK(Qw, False)[0])
+
+
 @pytest.mark.parametrize("N,Kx,Ky", [(4, 12, 8), (4, 64, 64), (3, 10, 10), (2, 7, 9), (1, 5, 5), (5, 4, 4), (4, 7, 3), (5, 5, 3), (6, 6, 5)])
 def test_cns_modal_matches_oracle(eng_mod, oracle_lib, N, Kx, Ky):
     """`rhsRK!` of dg2D_CNS_cavity_optimized.jl:955-972 on the periodic vortex box (BASELINE config 3's formulation)."""
