@@ -1579,12 +1579,18 @@ int esdg_set_parts(esdg_ctx* ctx, int parts) {
 int esdg_viscous_entropy_test(esdg_ctx* ctx, const double* Q, double* out, void* stream) {
   if (!ctx || !Q || !out) return fail(ESDG_ERR_ARG, "null argument");
   if (ctx->dim != 2 || ctx->nphases != 3 || !ctx->use_fast) return fail(ESDG_ERR_STATE, "needs a CNS context on the tensor kernels");
-  if (ctx->nghost) return fail(ESDG_ERR_STATE, "esdg_viscous_entropy_test needs an unsharded mesh");
+  if (ctx->nghost && !ctx->comm)
+    return fail(ESDG_ERR_STATE, "esdg_viscous_entropy_test on a sharded mesh needs the library's communicator (esdg_comm_init)");
   if (!ctx->M.wJq) return fail(ESDG_ERR_STATE, "wJq was not supplied at esdg_create");
   if (!ctx->ws) return fail(ESDG_ERR_STATE, "workspace not bound (esdg_bind_workspace)");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int rc = esdg_rhs_phase(ctx, 0, Q, nullptr, stream);
+  int rc = esdg_rhs_phase(ctx, 0, Q, nullptr, stream);   // (packs what the neighbours need)
   if (rc) return rc;
+  if (ctx->nghost) {   // sharded: the neighbours' traces of phase 0, then this rank's share of the sum (like esdg_rhstest)
+    for (int i = 0; i < esdg_ctx::MAXPH; ++i) ctx->posted[i] = false;
+    if ((rc = post_exchanges(ctx, 0, s)) != 0) return rc;
+    if ((rc = wait_exchanges(ctx, 1, s)) != 0) return rc;
+  }
   const int nb = sigma_tensor_blocks(ctx->T.N1, ctx->K);
   DevBuf part;
   if ((rc = part.alloc(sizeof(double) * (size_t)nb)) != 0) return rc;

@@ -211,7 +211,9 @@ int esdg_check_state(esdg_ctx* ctx, const double* Q_dev, double* min_rho_p, void
  * (default).  esdg_viscous_entropy_test returns the second value of rhs_viscous!,
  *   visc_test = sum(wJq .* (VUx .* sigma_x + VUy .* sigma_y))   (:802-806),
  * so that rhsRK!'s third return is  rhstest_visc = esdg_rhstest(Q, rhs_viscous) + visc_test  (:962-969).
- * (Runs phases 0 and 1 itself; unsharded meshes; synchronises `stream`.) */
+ * (Runs phases 0 and 1 itself; synchronises `stream`.  On a sharded context -- communicator attached -- it exchanges
+ * the traces of phase 0 and returns this rank's share of the sum, like esdg_rhstest: add the shares with
+ * esdg_comm_allreduce.) */
 int esdg_set_parts(esdg_ctx* ctx, int parts);
 int esdg_viscous_entropy_test(esdg_ctx* ctx, const double* Q_dev, double* visc_test, void* stream);
 

@@ -431,3 +431,10 @@ def test_rccl_transport_inside_the_library_loopback(E, form, N, Kx, Kyr):
         torch.cuda.synchronize()
         outs.append((Qtmp, err.value))
     assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and outs[0][1] > 0
+    if form == "cns":     # rhs_viscous!'s second return (visc_test, :802-806) through the sharded path: this rank's share
+        vt = []
+        for eng in (sh, one):
+            v = C.c_double(0.0)
+            E.check(eng.L.esdg_viscous_entropy_test(eng.ctx, C.c_void_p(Qd.data_ptr()), C.byref(v), eng._stream()))
+            vt.append(v.value)
+        assert vt[0] == vt[1] and vt[0] != 0.0
