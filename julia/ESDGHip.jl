@@ -200,7 +200,10 @@ function rhs!(e::Engine; compute_rhstest = false)
     diag[1]
 end
 
-"`rhsQ,rhstest,rhstest_visc = rhsRK!(...)` (dg2D_CNS_cavity_optimized.jl:955-972): rhs -> e.rhsd, returns the two scalars"
+"""
+`rhsQ,rhstest,rhstest_visc = rhsRK!(...)` (dg2D_CNS_cavity_optimized.jl:955-972): rhs -> e.rhsd, returns the two scalars.
+On a sharded engine (comm_init! done) both are this rank's shares: `comm_allreduce(e, [rhstest, rhstest_visc])` adds them.
+"""
 function rhsRK!(e::Engine; compute_rhstest = false)
     rhstest = rhs!(e; compute_rhstest = compute_rhstest)
     compute_rhstest || return 0.0, 0.0
