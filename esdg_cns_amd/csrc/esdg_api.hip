@@ -739,7 +739,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   c->ph.parts = 3;
   c->ph.dbg = 0;
   if (const char* env = getenv("ESDG_DBG")) c->ph.dbg = atoi(env);
-  if (const char* env = getenv("ESDG_V1")) c->v1 = env[0] == '1' ? 3 : env[0] == 's' ? 1 : env[0] == 'r' ? 2 : 0;
+  if (const char* env = getenv("ESDG_V1")) c->v1 = env[0] == '1' ? 3 : env[0] == 's' ? 1 : env[0] == 'r' ? 2 : env[0] == 'w' ? 8 : 0;
 
   // ---- collocated sparse operators -------------------------------------------------------
   Mat EfD, PhC, LfC, DrC, DsC, Vq, Pq;
@@ -1198,6 +1198,10 @@ int esdg_bind_workspace(esdg_ctx* ctx, void* dev_ptr, size_t bytes) {
 int esdg_num_phases(const esdg_ctx* ctx) { return ctx ? ctx->nphases : 0; }
 int esdg_uses_tensor_kernels(const esdg_ctx* ctx) { return ctx ? (int)ctx->use_fast : 0; }
 
+static bool v2_on_walls(const esdg_ctx* ctx) {
+  return ctx->v1 == 0 && !ctx->ph.dbg && ctx->T.N1 >= 2 && ctx->T.N1 <= 8;
+}
+
 static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs, const LsrkFuse& lf, void* stream,
                           int64_t e_begin = 0, int64_t e_count = -1) {
   if (!ctx || !Q) return fail(ESDG_ERR_ARG, "null argument");
@@ -1235,8 +1239,10 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
     rc = ctx->use_fast ? launch_project_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, A_v, s)
                        : launch_project(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, s);
   } else if (visc && phase == 1) {
-    // v2 kernel: meshes without walls (the wall closures and the visc_test reduction stay with kt_sigma); ESDG_V1=1: A/B
-    if (ctx->use_fast && !ctx->M.bc && !(ctx->v1 & 1))
+    // v2 kernel (the visc_test reduction stays with kt_sigma); ESDG_V1=1: A/B.  On meshes with walls the two viscous phases
+    // must come from the same set (kt_sigma stores sigma for kt_rhs, kt2_sigma the volume divergence and, at boundary
+    // nodes, minus the prescribed stress jump for kt2_rhs): v2 only if neither phase is forced to v1; ESDG_V1=walls: v1 there
+    if (ctx->use_fast && (ctx->M.bc ? v2_on_walls(ctx) : !(ctx->v1 & 1)))
       rc = launch_sigma_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, SG, s);
     else
       rc = ctx->use_fast ? launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, SG, nullptr, s)
@@ -1245,7 +1251,7 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
     if (!rhs && !lf.Qw) return fail(ESDG_ERR_ARG, "rhs output is null");
     if (lf.Qw && !ctx->use_fast) return fail(ESDG_ERR_STATE, "the fused RK update needs the tensor kernels");
     rc = -1;
-    if (ctx->use_fast && !ctx->M.bc && !(ctx->v1 & 2) && !ctx->ph.dbg)      // v2 kernel: meshes without walls, degrees N <= 5
+    if (ctx->use_fast && !ctx->ph.dbg && (ctx->M.bc ? v2_on_walls(ctx) : !(ctx->v1 & 2)))      // v2 kernel: degrees N <= 7
       rc = launch_rhs_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s);
     if (rc == -1)
       rc = ctx->use_fast ? launch_rhs_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s)

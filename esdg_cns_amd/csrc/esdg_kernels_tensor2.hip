@@ -167,6 +167,49 @@ __device__ unsigned long long g_stamp[16];
 // phase 1 (CNS, meshes without walls): sigma = K(v) grad v -> normal-stress traces B and the volume part of div sigma
 // (rhs_viscous! :749-815 in collocated form, dg_grad! :548-569; see kt_sigma in esdg_kernels_tensor.hip)
 // ---------------------------------------------------------------------------------------------------------------------
+// Wall closures (meshes with boundary nodes, M.bc != null; bc: 1 wall, 2 lid, 3 Dirichlet inflow, 4 copy).
+// wall_exterior_v: exterior projected entropy variables (v2,v3,v4) at a boundary face node from the own ones
+// (impose_BCs_entropyvars! cavity :178-216; dg2D_CNS_modalESDG.jl:187-203); gn = (nxJ, nyJ, sJ) of the face.
+__device__ __forceinline__ void wall_exterior_v(const double* vf, int bc, double vlid, const double* gn, const Phys& ph, double* vP) {
+  if (bc >= 3) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) vP[c] = bc == 3 ? ph.inflow_vv[c] : vf[c];
+  } else if (ph.BCTYPE == 1) {                            // adiabatic no-slip (vlid: lid velocity at this node)
+    vP[0] = bc == 2 ? -vf[0] - 2 * vlid * vf[2] : -vf[0];
+    vP[1] = -vf[1];
+    vP[2] = vf[2];
+  } else if (ph.BCTYPE == 2) {                            // isothermal
+    const double theta = 1.0 / (0.3 * 0.3) / 1.4 / 0.4;
+    vP[0] = bc == 2 ? 2.0 / theta - vf[0] : -vf[0];
+    vP[1] = -vf[1];
+    vP[2] = -2.0 / theta - vf[2];
+  } else {                                                // slip / reflective
+    const double is = rcp_refined(gn[2]);
+    const double nx = gn[0] * is, ny = gn[1] * is;
+    const double vn = vf[0] * nx + vf[1] * ny;
+    vP[0] = vf[0] - 2 * vn * nx;
+    vP[1] = vf[1] - 2 * vn * ny;
+    vP[2] = vf[2];
+  }
+}
+// wall_stress_jump: the stress jump impose_BCs_stress! (:218-262; modalESDG :205-216) prescribes at a boundary face node,
+// from the own face values of sigma_x (fx), sigma_y (fy) and their normal component sn
+__device__ __forceinline__ void wall_stress_jump(const double* sn, const double* fx, const double* fy, int bc, double vlid, const double* gn,
+                                                 const Phys& ph, double* sj) {
+  sj[0] = 0.0; sj[1] = 0.0; sj[2] = 0.0;
+  if (bc >= 3 || ph.BCTYPE == 2) return;
+  if (ph.BCTYPE == 1) {
+    sj[2] = bc == 2 ? -sn[2] + vlid * sn[0] : -sn[2];
+  } else {
+    const double is = rcp_refined(gn[2]);
+    const double n1 = gn[0] * is, n2 = gn[1] * is;
+    const double snx = fx[0] * n1 + fx[1] * n2, sny = fy[0] * n1 + fy[1] * n2;
+    sj[0] = .5 * ((-2 * fx[0] + 2 * n1 * snx) * gn[0] + (-2 * fy[0] + 2 * n1 * sny) * gn[1]);
+    sj[1] = .5 * ((-2 * fx[1] + 2 * n2 * snx) * gn[0] + (-2 * fy[1] + 2 * n2 * sny) * gn[1]);
+    sj[2] = -sn[2];
+  }
+}
+
 #ifndef ESDG_T2_SIGMA_WPE
 #define ESDG_T2_SIGMA_WPE 1   // minimum waves per SIMD asked of the register allocator (A/B hook)
 #endif
@@ -174,7 +217,9 @@ __device__ unsigned long long g_stamp[16];
 // beyond a group's slots duplicate slot tid - NV / tid % NF), so nothing is masked -- duplicate lanes store the same
 // value to the same address -- and no branch hides the outstanding-store count from the compiler's s_waitcnt placement.
 // FULL = false: the one partial group at the end of the range (one workgroup, masked stores); same arithmetic.
-template <int N1, bool FULL>
+// WALLS: boundary nodes (M.bc): exterior entropy variables by the wall closure; at a boundary node B holds MINUS the
+// prescribed stress jump, so that the last phase's .5*(-B[mapP] - B[own]) with mapP = own gives the jump unchanged.
+template <int N1, bool FULL, bool WALLS>
 __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                         const double* __restrict__ A_U, double* __restrict__ B,
                                                         double* __restrict__ SG) {
@@ -266,6 +311,13 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
     const int64_t e0n = M.e_begin + gnx * E;
     const int nEn = FULL ? E : (int)(e_end - e0n);
     const unsigned tvn = tv < (unsigned)(nEn * Nq) ? tv : 0u, tfn = tf < (unsigned)(nEn * Nfq) ? tf : 0u;
+    int bcf = 0;
+    double vlid = 1.0;
+    if (WALLS) {   // boundary flag (and lid velocity) of this lane's face node
+      const int64_t nfb = e0 * Nfq + (tf < (unsigned)(nE * Nfq) ? tf : 0u);
+      bcf = M.bc[nfb];
+      if (M.vlid) vlid = M.vlid[nfb];
+    }
 
     // ---- this group's state and geometry to LDS; their registers take the next group's loads ---------------------------
     d2* sA = reinterpret_cast<d2*>(lds + R0);
@@ -320,6 +372,10 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
         p = sVp[fnode0 + j * fstride];
         vf0 = __builtin_fma(ee[j], p.x, vf0); vf1 = __builtin_fma(ee[j], p.y, vf1);
         vf2 = __builtin_fma(ee[j], sV4[fnode0 + j * fstride], vf2);
+      }
+      if (WALLS && bcf) {
+        const double vfo[3] = {vf0, vf1, vf2};
+        wall_exterior_v(vfo, bcf, vlid, sGeo + ef * GEO_STRIDE + gfo, ph, vP);
       }
       sDp[tf] = make_double2(.5 * (vP[0] - vf0), .5 * (vP[1] - vf1));     // (duplicate lanes: duplicate writes)
       sD4[tf] = .5 * (vP[2] - vf2);
@@ -414,11 +470,16 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
         fx0 = __builtin_fma(ee[j], p0.x, fx0); fx1 = __builtin_fma(ee[j], p0.y, fx1); fx2 = __builtin_fma(ee[j], p1.x, fx2);
         fy0 = __builtin_fma(ee[j], p1.y, fy0); fy1 = __builtin_fma(ee[j], p2.x, fy1); fy2 = __builtin_fma(ee[j], p2.y, fy2);
       }
+      double sn[3] = {__builtin_fma(fy0, ny, fx0 * nx), __builtin_fma(fy1, ny, fx1 * nx), __builtin_fma(fy2, ny, fx2 * nx)};
+      if (WALLS && bcf) {   // minus the prescribed stress jump (see the kernel's header comment)
+        const double fx[3] = {fx0, fx1, fx2}, fy[3] = {fy0, fy1, fy2};
+        double sj[3];
+        wall_stress_jump(sn, fx, fy, bcf, vlid, gn, ph, sj);
+        sn[0] = -sj[0]; sn[1] = -sj[1]; sn[2] = -sj[2];
+      }
       if (fact) {
         double* bb = B + (e0 * Nfq + tf) * B_NC;
-        bb[0] = __builtin_fma(fy0, ny, fx0 * nx);
-        bb[1] = __builtin_fma(fy1, ny, fx1 * nx);
-        bb[2] = __builtin_fma(fy2, ny, fx2 * nx);
+        bb[0] = sn[0]; bb[1] = sn[1]; bb[2] = sn[2];
       }
     }
     T2_STAMP(7);
@@ -551,7 +612,7 @@ template <int N1, bool MODAL, bool VISC> struct RhsLds2 {
 //   * persistent without prefetch (rows fetched once per workgroup, in registers or in LDS): 0.46 ms -- hoisted addresses
 //     spill, and resident workgroups that start together stay in step, so their load and compute phases do not overlap
 //     the way consecutive one-shot workgroups' do.
-template <int N1, bool MODAL, bool VISC>
+template <int N1, bool MODAL, bool VISC, bool WALLS>
 __global__ __launch_bounds__(Geo<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                                        const double* __restrict__ A_U, const double* __restrict__ SG,
                                                                        const double* __restrict__ B, double* __restrict__ rhs, LsrkFuse lf) {
@@ -601,6 +662,12 @@ __global__ __launch_bounds__(Geo<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tensor
   const unsigned tvl = tv < (unsigned)(nE * Nq) ? tv : 0u, tfl = tf < (unsigned)(nE * Nfq) ? tf : 0u, tvg = tv;
   const int64_t nf = e0 * Nfq + tfl;
   const unsigned mp = (unsigned)M.mapP[nf];
+  int bcf = 0;
+  double vlid = 1.0;
+  if (WALLS) {   // boundary flag (1 wall, 2 lid, 3 inflow, 4 copy) and lid velocity of this lane's face node
+    bcf = M.bc[nf];
+    if (M.vlid) vlid = M.vlid[nf];
+  }
 #pragma unroll
   for (int f = 0; f < 4; ++f) x[f] = Q[f * KN + e0 * Nq + tvl];
 #pragma unroll
@@ -751,14 +818,42 @@ __global__ __launch_bounds__(Geo<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tensor
       if (VISC) {   // penalty tau*[[v]] (:817-837): the projected entropy variables are those OF the trace states
         const double bM = 2 * Gas2<MODAL>::GM1 * qM[3], bP = 2 * Gas2<MODAL>::GM1 * qP[3];
         const double tau = ph.viscous_dissp ? -rcp_refined(-bM) * ph.inv_Re : 0.0;
-        pnr[0] = tau * (bP * qP[1] - bM * qM[1]);
-        pnr[1] = tau * (bP * qP[2] - bM * qM[2]);
-        pnr[2] = tau * (bM - bP);
+        if (WALLS && bcf) {   // exterior values by the wall closure; third component overridden as in :827-837
+          const double vf[3] = {bM * qM[1], bM * qM[2], -bM};
+          double vP[3];
+          wall_exterior_v(vf, bcf, vlid, gn, ph, vP);
+          const double dV[3] = {vP[0] - vf[0], vP[1] - vf[1], vP[2] - vf[2]};
+          const double a2 = .5 * (vP[0] + vf[0]), a3 = .5 * (vP[1] + vf[1]);
+          double sq = a2 * dV[0] + a3 * dV[1];
+          if (ph.BCTYPE != 1) sq += dV[2] * dV[2] * .5;
+          pnr[0] = tau * dV[0];
+          pnr[1] = tau * dV[1];
+          pnr[2] = -tau * sq * rcp_refined(vf[2]);
+        } else {
+          pnr[0] = tau * (bP * qP[1] - bM * qM[1]);
+          pnr[1] = tau * (bP * qP[2] - bM * qM[2]);
+          pnr[2] = tau * (bM - bP);
+        }
+      }
+      if (WALLS && bcf >= 3) {   // shock-tube closures (dg2D_CNS_modalESDG.jl:168-185): Dirichlet state / copy, lam = lamP = 0
+#pragma unroll
+        for (int c = 0; c < 6; ++c) qP[c] = bcf == 3 ? ph.inflow_q[c] : qM[c];
+        qM[6] = 0.0; qP[6] = 0.0;
+      } else if (WALLS && bcf) {   // wall: mirror state rho+ = rho, beta+ = beta, u+ = u - 2 (u.n) n  (impose_BCs_inviscid! :157-176)
+        const double is = rcp_refined(gn[2]);
+        const double nx = gn[0] * is, ny = gn[1] * is;
+        const double un = qM[1] * nx + qM[2] * ny;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) qP[c] = qM[c];
+        qP[1] = qM[1] - 2 * un * nx;
+        qP[2] = qM[2] - 2 * un * ny;
       }
       double Fn[4];
       ec_flux_dir<MODAL>(qM, qP, gn[0], gn[1], Fn);
       const double LFc = ph.inviscid_dissp ? ph.lf_scale * fmax(qM[6], qP[6]) * gn[2] : 0.0;
-      const double dU[4] = {qP[0] - qM[0], qP[0] * qP[1] - qM[0] * qM[1], qP[0] * qP[2] - qM[0] * qM[2], qP[7] - qM[7]};
+      // (the LF jump uses Uf[mapP] - Uf, which vanishes at boundary nodes: mapP = self, cavity :511-513)
+      const double dz = (WALLS && bcf) ? 0.0 : 1.0;
+      const double dU[4] = {dz * (qP[0] - qM[0]), dz * (qP[0] * qP[1] - qM[0] * qM[1]), dz * (qP[0] * qP[2] - qM[0] * qM[2]), dz * (qP[7] - qM[7])};
       const double wf = inviscid ? wfac : 0.0;
 #pragma unroll
       for (int c = 0; c < 4; ++c) Gf[c] = wf * (Fn[c] - LFc * dU[c]);
@@ -918,16 +1013,22 @@ extern "C" int esdg_debug_stamps(unsigned long long* out16, int reset) {
 }
 #endif
 
-template <int N1>
-static void launch_sigma2(const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U, double* B,
-                          double* SG, hipStream_t s) {
+template <int N1, bool WALLS>
+static void launch_sigma2w(const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U, double* B,
+                           double* SG, hipStream_t s) {
   using G = t2::Geo<N1>;
   const int64_t nfull = M.e_count / G::E;
   if (nfull > 0) {
-    const int nb = t2::persistent_grid<t2::kt2_sigma<N1, true>>(G::GT, nfull);
-    hipLaunchKernelGGL((t2::kt2_sigma<N1, true>), dim3(nb), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);
+    const int nb = t2::persistent_grid<t2::kt2_sigma<N1, true, WALLS>>(G::GT, nfull);
+    hipLaunchKernelGGL((t2::kt2_sigma<N1, true, WALLS>), dim3(nb), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);
   }
-  if (M.e_count % G::E) hipLaunchKernelGGL((t2::kt2_sigma<N1, false>), dim3(1), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);
+  if (M.e_count % G::E) hipLaunchKernelGGL((t2::kt2_sigma<N1, false, WALLS>), dim3(1), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);
+}
+template <int N1>
+static void launch_sigma2(const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U, double* B,
+                          double* SG, hipStream_t s) {
+  if (M.bc) launch_sigma2w<N1, true>(TT, M, ph, Q, A_U, B, SG, s);
+  else launch_sigma2w<N1, false>(TT, M, ph, Q, A_U, B, SG, s);
 }
 
 // phase 1 on meshes without walls and without the visc_test reduction (the other variants stay with kt_sigma)
@@ -943,7 +1044,8 @@ static void launch_rhs2(const TensorTables& TT, const MeshDev& M, const Phys& ph
                         const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s) {
   using G = t2::Geo<N1>;
   const int nb = (int)((M.e_count + G::E - 1) / G::E);
-  hipLaunchKernelGGL((t2::kt2_rhs<N1, MODAL, VISC>), dim3(nb), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
+  if (M.bc) hipLaunchKernelGGL((t2::kt2_rhs<N1, MODAL, VISC, true>), dim3(nb), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
+  else hipLaunchKernelGGL((t2::kt2_rhs<N1, MODAL, VISC, false>), dim3(nb), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
 }
 
 // last phase on meshes without walls; returns -1 where the v2 kernel does not cover the degree (caller falls back)
