@@ -360,7 +360,8 @@ def test_cfg4_rank0_strip_of_the_8_rank_mesh(E):
     assert float(r.abs().max()) < 1e-11 / float(md.J.min())   # free stream through the ghost slots
 
 
-@pytest.mark.parametrize("form,N,Kx,Kyr", [("cns", 4, 24, 3), ("cns", 3, 16, 2), ("euler", 4, 20, 2)])
+@pytest.mark.parametrize("form,N,Kx,Kyr", [("cns", 4, 24, 3), ("cns", 3, 16, 2), ("euler", 4, 20, 2),
+                                           ("cns", 3, 10, 24), ("euler", 4, 10, 16)])   # many rows: nested two-stream schedule
 def test_rccl_transport_inside_the_library_loopback(E, form, N, Kx, Kyr):
     """The library's own RCCL transport and sharded schedule (esdg_comm_init / esdg_rhs on a sharded context: overlapped
     phases, packs, grouped ncclSend/ncclRecv on the comm stream) executed for real on one GPU: rank 0's strip of an 8-rank

@@ -225,7 +225,7 @@ def _slab_periodic_state(x, y, z, LZ):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("Kx,Kzr,lf", [(8, 2, 0.25), (32, 4, 0.0)])
+@pytest.mark.parametrize("Kx,Kzr,lf", [(8, 2, 0.25), (32, 4, 0.0), (8, 16, 0.25)])   # 16 layers: the nested two-stream schedule
 def test_cfg5_rank0_slab_of_the_8_rank_box_over_the_library_rccl_transport(eng_mod, Kx, Kzr, lf):
     """BASELINE config 5 in its 8-rank form (z-slabs of the periodic box): rank 0's slab with its ghost slots, send lists
     and the library's RCCL transport in loopback (what goes to the slab below comes in from above: for a state that is
