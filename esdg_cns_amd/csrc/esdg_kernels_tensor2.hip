@@ -1019,7 +1019,19 @@ static void launch_sigma2w(const TensorTables& TT, const MeshDev& M, const Phys&
   using G = t2::Geo<N1>;
   const int64_t nfull = M.e_count / G::E;
   if (nfull > 0) {
-    const int nb = t2::persistent_grid<t2::kt2_sigma<N1, true, WALLS>>(G::GT, nfull);
+    int nb = t2::persistent_grid<t2::kt2_sigma<N1, true, WALLS>>(G::GT, nfull);
+    // Ranged launches (sharded schedule): the interior leaves a few slots free and the boundary strips ask for no more
+    // than those, so that a strip never takes the slot of an interior workgroup, which would start late and still do its
+    // full static share (ESDG_T2_RESERVE: slots, default 64; 0 = off)
+    if (M.e_count != M.K) {
+      static int reserve = -1;
+      if (reserve < 0) { const char* env = getenv("ESDG_T2_RESERVE"); reserve = env ? atoi(env) : 64; }
+      if (reserve > 0) {
+        const int cap = t2::persistent_grid<t2::kt2_sigma<N1, true, WALLS>>(G::GT, (int64_t)1 << 40);
+        if (nfull >= cap) nb = cap - reserve > 0 ? cap - reserve : nb;   // interior
+        else if (nb > reserve) nb = reserve;                           // strip
+      }
+    }
     hipLaunchKernelGGL((t2::kt2_sigma<N1, true, WALLS>), dim3(nb), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);
   }
   if (M.e_count % G::E) hipLaunchKernelGGL((t2::kt2_sigma<N1, false, WALLS>), dim3(1), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);
