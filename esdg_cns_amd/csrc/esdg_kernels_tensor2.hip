@@ -277,8 +277,12 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
   const unsigned gfo = 5 + 3 * (fn / N1);
 
   const int64_t e_end = M.e_begin + M.e_count;
-  const int64_t nfull = M.e_count / E;
+  // FULL: ceil(e_count / E) groups, the last one shifted back so that it is complete too: it recomputes up to E - 1
+  // elements of the group before it and stores the same values to the same addresses (plain stores of slot-independent
+  // results) -- no masked partial group, no second launch.  FULL = false serves ranges of fewer than E elements only.
+  const int64_t nfull = FULL ? (M.e_count + E - 1) / E : 0;
   const int64_t ngrp = FULL ? nfull : nfull + 1;
+  const int64_t e_last = M.e_begin + M.e_count - E;   // base of the shifted last group (FULL)
   // ---- prologue: loads of the first group ---------------------------------------------------------------------------
   // Prefetch without a second register set: the loads of the NEXT group go into the registers of the current one right
   // after their last use (x and the geometry are written to LDS first thing; the neighbour traces are consumed by the
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
   double x[4], geo[GPT];
   d2 up0, up1;
   {
-    const int64_t e0 = M.e_begin + grp * E;
+    const int64_t e0 = FULL ? min(M.e_begin + grp * E, e_last) : M.e_begin;
     const int nE = FULL ? E : (int)(e_end - e0);
     const unsigned tvl = tv < (unsigned)(nE * Nq) ? tv : 0u, tfl = tf < (unsigned)(nE * Nfq) ? tf : 0u;
     const unsigned mp = (unsigned)M.mapP[e0 * Nfq + tfl];
@@ -303,12 +307,12 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
 #pragma unroll 1
   for (; grp < ngrp; grp += gridDim.x) {
     T2_STAMP(0);
-    const int64_t e0 = M.e_begin + grp * E;
+    const int64_t e0 = FULL ? min(M.e_begin + grp * E, e_last) : M.e_begin;
     const int nE = FULL ? E : (int)(e_end - e0);
     const bool vact = FULL || tid < (unsigned)(nE * Nq), fact = FULL || tid < (unsigned)(nE * Nfq);
     // next group, clamped to the last one (harmless re-loads at the end)
     const int64_t gnx = min(grp + (int64_t)gridDim.x, ngrp - 1);
-    const int64_t e0n = M.e_begin + gnx * E;
+    const int64_t e0n = FULL ? min(M.e_begin + gnx * E, e_last) : M.e_begin;
     const int nEn = FULL ? E : (int)(e_end - e0n);
     const unsigned tvn = tv < (unsigned)(nEn * Nq) ? tv : 0u, tfn = tf < (unsigned)(nEn * Nfq) ? tf : 0u;
     int bcf = 0;
@@ -1017,7 +1021,7 @@ template <int N1, bool WALLS>
 static void launch_sigma2w(const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U, double* B,
                            double* SG, hipStream_t s) {
   using G = t2::Geo<N1>;
-  const int64_t nfull = M.e_count / G::E;
+  const int64_t nfull = M.e_count >= G::E ? (M.e_count + G::E - 1) / G::E : 0;   // complete groups, the last one shifted back
   if (nfull > 0) {
     int nb = t2::persistent_grid<t2::kt2_sigma<N1, true, WALLS>>(G::GT, nfull);
     // Ranged launches (sharded schedule): the interior leaves a few slots free and the boundary strips ask for no more
@@ -1034,7 +1038,7 @@ static void launch_sigma2w(const TensorTables& TT, const MeshDev& M, const Phys&
     }
     hipLaunchKernelGGL((t2::kt2_sigma<N1, true, WALLS>), dim3(nb), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);
   }
-  if (M.e_count % G::E) hipLaunchKernelGGL((t2::kt2_sigma<N1, false, WALLS>), dim3(1), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);
+  else hipLaunchKernelGGL((t2::kt2_sigma<N1, false, WALLS>), dim3(1), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);   // fewer than E elements
 }
 template <int N1>
 static void launch_sigma2(const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U, double* B,
