@@ -31,12 +31,19 @@ template <> struct Cfg<6> { static constexpr int GW = 4; };
 template <> struct Cfg<7> { static constexpr int GW = 2; };   // 2 elements per group: the accumulator planes stay under 64 KB
 template <> struct Cfg<8> { static constexpr int GW = 2; };
 
-template <int N1> struct Geo {
-  static constexpr int GW = Cfg<N1>::GW, GT = TW * GW, Nq = N1 * N1, Nfq = 4 * N1;
+// ... and of the last-phase kernel where its measured optimum differs (N=5, 384x384, same box: kt2_rhs 0.400 ms with 4
+// waves per group -- 58 KB LDS, 2 workgroups per CU -- 0.358 ms with 2; kt2_sigma the other way round, 0.161 vs 0.179 ms)
+template <int N1> struct CfgRhs { static constexpr int GW = Cfg<N1>::GW; };
+template <> struct CfgRhs<6> { static constexpr int GW = 2; };
+
+template <int N1, int GWv = Cfg<N1>::GW> struct Geo {
+  static constexpr int GW = GWv, GT = TW * GW, Nq = N1 * N1, Nfq = 4 * N1;
   static constexpr int E = (GT / Nq) < (GT / Nfq) ? (GT / Nq) : (GT / Nfq);
   static constexpr int NV = E * Nq, NF = E * Nfq;   // volume / face lanes of a group
   static_assert(E >= 1, "group does not hold an element");
 };
+
+template <int N1> using GeoR = Geo<N1, CfgRhs<N1>::GW>;   // group geometry of kt2_rhs
 
 constexpr double GM1 = 0.4;   // the CNS drivers' literal (cavity_optimized.jl:463)
 
@@ -71,10 +78,9 @@ typedef double2 d2;
 // Uq = Vq Qn by sum factorisation through the pair planes sA, sB ([2][NV] each).  Nodal values are r-fastest, Gauss
 // nodes s-fastest (SetupDG.jl:244): Vq[(a + N1 b), (i + N1 j)] = IQ[b,i] IQ[a,j].  c = IQ[a][:]; rowb = first slot of
 // row b, colq = slot b of row 0 (both of this lane's element).
-template <int N1>
+template <int N1, int NV>
 __device__ __forceinline__ void vq_apply(const double* c, d2* sA, d2* sB0, d2* sB1, unsigned tv, unsigned rowb, unsigned colq,
                                          const double* x, double* U) {
-  constexpr int NV = Geo<N1>::NV;
   if (x) {
     sA[tv] = make_double2(x[0], x[1]);
     sA[NV + tv] = make_double2(x[2], x[3]);
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
 
     // ---- state at the Gauss node, entropy variables 2..4 --------------------------------------------------------------
     double U[4];
-    vq_apply<N1>(cq, sA, reinterpret_cast<d2*>(lds + R0 + 4 * NV), reinterpret_cast<d2*>(lds + R0 + 6 * NV), tv, rowb, ev * Nq + b, nullptr, U);
+    vq_apply<N1, NV>(cq, sA, reinterpret_cast<d2*>(lds + R0 + 4 * NV), reinterpret_cast<d2*>(lds + R0 + 6 * NV), tv, rowb, ev * Nq + b, nullptr, U);
     T2_STAMP(2);
     double V[3];
     {
@@ -594,7 +600,7 @@ __device__ __forceinline__ void prim_logs(const double* U, double* q) {
 }
 
 template <int N1, bool MODAL, bool VISC> struct RhsLds2 {
-  using G = Geo<N1>;
+  using G = GeoR<N1>;
   static constexpr NodeLayout NL = NodeLayout(N1);
   static constexpr int NV = G::NV, NF = G::NF;
   static constexpr int NVV = (NL.NFULL + 1) / 2;                      // accumulator plane sets per direction, volume-volume
@@ -617,10 +623,10 @@ template <int N1, bool MODAL, bool VISC> struct RhsLds2 {
 //     spill, and resident workgroups that start together stay in step, so their load and compute phases do not overlap
 //     the way consecutive one-shot workgroups' do.
 template <int N1, bool MODAL, bool VISC, bool WALLS>
-__global__ __launch_bounds__(Geo<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
+__global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                                        const double* __restrict__ A_U, const double* __restrict__ SG,
                                                                        const double* __restrict__ B, double* __restrict__ rhs, LsrkFuse lf) {
-  using G = Geo<N1>;
+  using G = GeoR<N1>;
   using LD = RhsLds2<N1, MODAL, VISC>;
   constexpr int Nq = G::Nq, Nfq = G::Nfq, E = G::E, NV = G::NV, NF = G::NF;
   constexpr NodeLayout NL(N1);
@@ -756,7 +762,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tensor
       const d2* row = reinterpret_cast<const d2*>(lds + LD::TABQ + a * N1P);
 #pragma unroll
       for (int i = 0; i < N1P / 2; ++i) { const d2 t = row[i]; cq[2 * i] = t.x; cq[2 * i + 1] = t.y; }
-      vq_apply<N1>(cq, sRec, sAcc, sAcc + NV, tv, rowb, colq, nullptr, U);
+      vq_apply<N1, NV>(cq, sRec, sAcc, sAcc + NV, tv, rowb, colq, nullptr, U);
       __syncthreads();   // every lane is past its reads of the buffer in the accumulator planes, which are zeroed below
     }
     T2_STAMP(1);     // Q landed + Vq
@@ -1058,7 +1064,7 @@ int launch_sigma_tensor2(int N1v, const TensorTables& TT, const MeshDev& M, cons
 template <int N1, bool MODAL, bool VISC>
 static void launch_rhs2(const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U, const double* SG,
                         const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s) {
-  using G = t2::Geo<N1>;
+  using G = t2::GeoR<N1>;
   const int nb = (int)((M.e_count + G::E - 1) / G::E);
   if (M.bc) hipLaunchKernelGGL((t2::kt2_rhs<N1, MODAL, VISC, true>), dim3(nb), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
   else hipLaunchKernelGGL((t2::kt2_rhs<N1, MODAL, VISC, false>), dim3(nb), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
