@@ -787,7 +787,8 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
       // volume-volume rounds: pair (pos, pos + i + 1 mod N1) of direction d; share of the partner -> plane set d * NVV + i / 2
 #pragma unroll
       for (int r = 0; r < 2 * NFULL; ++r) {
-        const int d = r / NFULL, i = r % NFULL;
+        constexpr int NFD = NFULL > 0 ? NFULL : 1;     // (N1 = 2 has no full round: the loop is empty)
+        const int d = r / NFD, i = r % NFD;
         const d2 p0 = sRec[pid[r]], p1 = sRec[NV + pid[r]], p2 = sRec[2 * NV + pid[r]];
         const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
         double Fd[4];
