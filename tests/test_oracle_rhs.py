@@ -149,3 +149,32 @@ def test_shocktube_closures_c_vs_numpy_and_consistency(oracle_lib):
     d = [x - y for x, y in zip(orc.CnsOracle(p2, viscous_dissp=False).rhsRK(p.Q, False)[0], b)]
     cols = np.abs(np.stack(d)).max(axis=(0, 1)).reshape(4, 6)          # (Ky, Kx) element blocks
     assert cols[:, 0].min() > 1e-6 and cols[:, 2:].max() == 0.0
+
+
+def test_truth_evaluator_is_the_same_statements_in_binary128(oracle_lib):
+    """The binary128 build of oracle/oracle_rhs.c (`make liboracle_quad.so`, -DORACLE_QUAD) is what every GPU parity test is
+    gated against.  Pin it on the CPU: it reports a 128-bit working type, agrees with the Float64 build to the Float64 build's
+    own round-off on the vortex states (a few 1e-12 ... 1e-10: the conditioning DESIGN.md section 2 describes) and to
+    ~1e-14 on the well-conditioned state, preserves the free stream far below Float64 round-off, and conserves entropy
+    with the LF penalty off beyond what Float64 can show."""
+    Lq = orc.lib_quad()
+    assert Lq.oracle_real_bits() == 128 and orc.lib().oracle_real_bits() == 64      # storage bits of `real`
+    p = orc.build_euler_problem(3, 6, 5)
+    e64, e128 = orc.EulerOracle(p), orc.EulerOracle(p, quad=True)
+    d_vortex = rel_l2(e64.rhs(p.Q)[0], e128.rhs(p.Q)[0])
+    Qs = steep_state(p.md.xq, p.md.yq)
+    d_steep = rel_l2(e64.rhs(Qs)[0], e128.rhs(Qs)[0])
+    print(f"euler N=3 6x5: |f64 - f128| vortex {d_vortex:.2e}, steep {d_steep:.2e}")
+    assert 1e-14 < d_vortex < 1e-9 and d_steep < 1e-12
+    one = [np.full_like(q, v) for q, v in zip(p.Q, (1.3, 0.4, -0.3, 2.9))]
+    r128 = e128.rhs(one)[0]
+    assert max(np.abs(x).max() for x in r128) < 1e-12      # what is left is the round-off of the Float64 operators it is fed
+    # entropy conservation (LF off): the Float64 build is limited by its own round-off, the binary128 build by the inputs'
+    _, t64 = e64.rhs(p.Q, 0.0, True)
+    _, t128 = e128.rhs(p.Q, 0.0, True)
+    assert abs(t128) <= abs(t64) + 1e-13 and abs(t64) < 1e-10
+    pc = orc.build_cns_problem(3, 4, 4)
+    c64, c128 = orc.CnsOracle(pc), orc.CnsOracle(pc, quad=True)
+    d_cns = rel_l2(c64.rhsRK(pc.Q, False)[0], c128.rhsRK(pc.Q, False)[0])
+    print(f"cns N=3 4x4: |f64 - f128| {d_cns:.2e}")
+    assert 1e-14 < d_cns < 1e-9
