@@ -33,6 +33,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 fp64 lanes x 2 flop x 2.4 GHz
+# What this pool's MI355X boxes deliver to the simplest kernels (tools/ubench, output committed as profiles/r03_ubench.txt):
+# a plain device-to-device copy and independent fp64 FMAs from 4 waves x 8 chains per SIMD.  The two floors of
+# `roofline.floors_ms` are traffic / PRACTICAL_HBM_GBS and fp64 flops / MEASURED_FP64_TFLOPS; `roofline.bound` names the larger.
+PRACTICAL_HBM_GBS = 5300.0
+MEASURED_FP64_TFLOPS = 66.5
 PREWARM_EVALS = 200           # untimed RHS evaluations before the warm-up steps (GPU clock ramp), see run()
 REPS = 5                      # repetitions of the K-step timed region (the first one is the contract's; median/min reported)
 
@@ -202,6 +207,10 @@ def parse_args(argv=None):
                          "torch = torch.distributed P2P driven from Python (default with --backend gloo)")
     ap.add_argument("--oversubscribe", action="store_true", help="rehearsal: allow more ranks than GPUs (recorded in the JSON)")
     ap.add_argument("--master-port", type=int, default=29577)
+    ap.add_argument("--require-rccl", action="store_true",
+                    help="N > 1: exit 4 (after printing the JSON line) unless the library's RCCL transport ran on all N ranks")
+    ap.add_argument("--no-weak-base", action="store_true",
+                    help="N > 1: skip the single-GPU run of the same per-rank shard (config.weak_scaling_base_ms)")
     return ap.parse_args(argv)
 
 
@@ -272,16 +281,24 @@ def run(args):
     out = eng.new_state()
     transport_note = None
     if world > 1 and transport == "rccl":
-        # The library's communicator is attached and proven with two evaluations before anything is timed; if ANY rank
-        # fails (agreed through the bootstrap group), every rank falls back to the torch.distributed transport and the
-        # JSON line says so (config.transport / config.transport_note) -- a scaling number over the slower path is worth
-        # more than none.
+        # Stage 1: the id hand-off and esdg_comm_init (ncclCommInitRank + plan cross-check with the neighbours) on every rank,
+        # then ONE agreement over the bootstrap group before any evaluation is posted.  A failure up to here has left no
+        # send or receive pending, so every rank can fall back to the torch.distributed transport together (the JSON line
+        # says so: config.transport / config.transport_note; --require-rccl turns that into exit code 4).
+        # Stage 2: two proving evaluations.  A rank that fails there may leave its peers inside a posted ncclRecv, which no
+        # collective agreement can reach any more: it prints the reason and the whole job exits non-zero (no fallback, no
+        # re-exec).  A watchdog bounds both stages, so that a hung communicator ends the run instead of the round.
+        import threading
+
+        def _hung():
+            print(f"bench.py: rank {rank}: RCCL attach / proving evaluations did not finish within 300 s -- giving up", file=sys.stderr, flush=True)
+            os._exit(6)
+        dog = threading.Timer(300.0, _hung)
+        dog.daemon = True
+        dog.start()
         err = ""
         try:
             rccl_ranks = eng.attach_rccl()
-            for _ in range(2):
-                eng.rhs_into(Qd, out)
-            torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
             err = f"{type(e).__name__}: {e}"
         flag = torch.tensor([1.0 if err else 0.0], device=torch.device("cuda", dev) if args.backend == "nccl" else "cpu")
@@ -292,9 +309,18 @@ def run(args):
             except Exception:  # noqa: BLE001
                 pass
             eng.transport, transport, rccl_ranks = "torch", "torch", 0
-            transport_note = "library RCCL transport failed on a rank (" + (err or "another rank") + "); fell back to torch.distributed P2P"
+            transport_note = "library RCCL transport could not be attached on a rank (" + (err or "another rank") + "); fell back to torch.distributed P2P"
             if rank == 0:
                 print("bench.py: " + transport_note, file=sys.stderr)
+        else:
+            try:
+                for _ in range(2):
+                    eng.rhs_into(Qd, out)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                print(f"bench.py: rank {rank}: evaluation over the library's RCCL transport failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                os._exit(5)
+        dog.cancel()
     Np, K_local, nfld = eng.Np, eng.K, eng.nfld
 
     def sync_all():
@@ -351,6 +377,7 @@ def run(args):
     # --- PMC-derived figures (rocprofv3 passes of this command, tools/profile_round.sh -> profiles/pmc_traffic.json) ----
     traffic = whole_traffic = prof_us = valu_frac = whole_valu_frac = fp64_flops = None
     pmc_stale = None
+    rec = {}
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
@@ -370,10 +397,38 @@ def run(args):
             pass
     kname = "kh_rhs (last phase: surface flux + flux differencing + lift)" if hexw else \
         "kt2_rhs (last phase: flux differencing + viscous divergence + projection)"
+    # --- which roof binds: computed, per formulation, from the numbers of this line ------------------------------------
+    # HBM floor = bytes moved / the pool's practical copy rate; fp64 floor = counted fp64 flops / the measured vector peak.
+    # Bytes: the PMC traffic of this command where the committed profile is current, else the design bytes per element
+    # (what each phase reads and writes once, no cache reuse assumed).
+    Nfq_ = eng.Nfq if hasattr(eng, "Nfq") else (6 * (N + 1) ** 2 if hexw else 4 * (N + 1))
+    if hexw:
+        design_k = 80.0 * Np + 80.0 * Nfq_                        # Q r + rhs w, own + neighbour trace (5 doubles per node)
+        design_whole = design_k + 40.0 * Np + 40.0 * Nfq_         # + phase 0: Q r, trace w
+    elif args.formulation == "cns":
+        design_k = 64.0 * Np + 128.0 * Nfq_ + 24.0 * Np + 48.0 * Nfq_   # Q, rhs | A_U own+nbr | SG | B own+nbr
+        design_whole = design_k + (32.0 * Np + 64.0 * Nfq_) + (32.0 * Np + 32.0 * Nfq_ + 24.0 * Np + 24.0 * Nfq_)
+    else:
+        design_k = 64.0 * Np + 128.0 * Nfq_
+        design_whole = design_k + 32.0 * Np + 64.0 * Nfq_
+    bytes_k = traffic if traffic else design_k * K_local
+    bytes_whole = whole_traffic if whole_traffic else design_whole * K_local
+    whole_flops = rec.get("whole_rhs_fp64_flops") if (rec and not pmc_stale) else None
+    floors = {"hbm_kernel": bytes_k / (PRACTICAL_HBM_GBS * 1e9) * 1e3,
+              "fp64_kernel": None if not fp64_flops else fp64_flops / (MEASURED_FP64_TFLOPS * 1e12) * 1e3,
+              "hbm_whole_rhs": bytes_whole / (PRACTICAL_HBM_GBS * 1e9) * 1e3,
+              "fp64_whole_rhs": None if not whole_flops else whole_flops / (MEASURED_FP64_TFLOPS * 1e12) * 1e3,
+              "bytes_basis": "pmc" if traffic else "design"}
+
+    def _bound(h, f):
+        return "hbm" if (f is None or h >= f) else "fp64-valu"
     roofline = {
-        # the binding roof is fp64 VALU issue, not HBM (SQ counters, profiles/): `frac` stays the HBM figure the north star
-        # names, `valu_frac` is the counted fp64 flops of the same kernel against the fp64 vector peak
-        "bound": "fp64-valu", "kernel": kname,
+        # `bound`: the larger floor of the dominant kernel (see floors_ms); `frac` stays the HBM figure the north star names
+        # (algorithmic bytes / kernel time / 8 TB/s), `valu_frac` the counted fp64 flops of the same kernel against the fp64
+        # vector peak; `whole_rhs_bound` the same comparison over all phases of one evaluation
+        "bound": _bound(floors["hbm_kernel"], floors["fp64_kernel"]), "kernel": kname,
+        "whole_rhs_bound": _bound(floors["hbm_whole_rhs"], floors["fp64_whole_rhs"]),
+        "floors_ms": floors, "practical_hbm_gbs": PRACTICAL_HBM_GBS, "measured_fp64_tflops": MEASURED_FP64_TFLOPS,
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic, "kernel_ms": kdur_ms, "phase_ms": phase_ms,
         # the same kernel's average under rocprofv3 --kernel-trace --stats (committed profile of this command)
@@ -382,6 +437,31 @@ def run(args):
         "whole_rhs_traffic": whole_traffic,
         "valu_peak_tflops": FP64_VALU_PEAK_TFLOPS, "fp64_flops_per_launch": fp64_flops, "valu_frac": valu_frac,
         "whole_rhs_valu_frac": whole_valu_frac, "pmc_stale": pmc_stale, "kernel_src_sha": kernel_source_hash()}
+
+    # --- N > 1: the single-GPU time of the SAME per-rank shard (stand-alone periodic strip / slab, no exchange), so that a
+    # scaling curve is read against its own weak-scaling base and not against the 512^2 point of --gpus 1 ------------------
+    weak_base_ms = None
+    if world > 1 and rank == 0 and not args.no_weak_base:
+        try:
+            del eng
+            torch.cuda.empty_cache()
+            if hexw:
+                rd1, md1, ops1, Q1 = build_hex_problem(N, Kx, Kx, args.kz_per_gpu, 0, Kx * Kx * args.kz_per_gpu, args.hex_curve)
+                e1 = engine.RhsEngine(rd1, md1, ops1, engine.EULER_HEX_COLLOCATED, lf_scale=args.lf)
+            else:
+                rd1, md1, ops1, Q1 = build_problem(N, Kx, kyr, 0, Kx * kyr, args.formulation)
+                e1 = engine.RhsEngine(rd1, md1, ops1, form)
+            Q1d, o1 = e1.upload(Q1), e1.new_state()
+            for _ in range(PREWARM_EVALS):
+                e1.rhs_into(Q1d, o1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                e1.rhs_into(Q1d, o1)
+            torch.cuda.synchronize()
+            weak_base_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: weak-scaling base run failed: {type(e).__name__}: {e}", file=sys.stderr)
 
     if hexw:
         workload = f"euler3d_hex_N{N}_{Kx}x{Kx}x{Kz_total}_periodic_box_lf{args.lf:g}" + (f"_curved{args.hex_curve:g}" if args.hex_curve else "")
@@ -398,7 +478,8 @@ def run(args):
         "config": {"workload": workload, "elements": K_total, "elements_per_gpu": K_local, "Np": Np, "nfields": nfld,
                    "parallelism": f"element-{'slabs' if hexw else 'strips'} x{world}", "prewarm_evals": PREWARM_EVALS,
                    "backend": args.backend if world > 1 else None, "transport": transport if world > 1 else None, "transport_note": transport_note,
-                   "rccl_ranks": rccl_ranks, "visible_gpus": ndev, "oversubscribed": oversub},
+                   "rccl_ranks": rccl_ranks, "visible_gpus": ndev, "oversubscribed": oversub,
+                   "weak_scaling_base_ms": weak_base_ms},
         "rhs_evals_per_s": evals_per_s, "elements_per_s": K_total * evals_per_s,
         "ms_per_step_median": per[len(per) // 2], "ms_per_step_min": per[0], "ms_per_step_reps": [r / args.steps * 1e3 for r in reps],
         "roofline": roofline,
@@ -412,6 +493,8 @@ def run(args):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if world > 1 and args.require_rccl and (transport != "rccl" or rccl_ranks != world):
+        return 4
     return 0
 
 

@@ -11,21 +11,28 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["csrc/esdg_kernels.hip", "csrc/esdg_kernels_tensor.hip", "csrc/esdg_kernels_tensor2.hip", "csrc/esdg_kernels_hex.hip", "csrc/esdg_kernels_err.hip",
-           "csrc/esdg_api.hip", "csrc/esdg_comm.hip", "csrc/esdg_setup.cpp"]
+           "csrc/esdg_api.hip", "csrc/esdg_setup.cpp"]
 HEADERS = ["csrc/esdg_dev.hpp", "csrc/esdg_devmath.hpp", "csrc/esdg_tensor_tables.hpp", "csrc/esdg_hex_tables.hpp",
-           "csrc/esdg_ctx.hpp", "../include/esdg_hip.h"]
+           "../include/esdg_hip.h"]
 OUT = os.path.join(HERE, "libesdg_hip.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 LINK = ["-L" + os.path.join(ROCM, "lib"), "-lrccl", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
 
 
+def _listed(names):
+    missing = [n for n in names if not os.path.exists(os.path.join(HERE, n))]
+    if missing:   # a typo in a file name must not silently drop the file from the build
+        raise FileNotFoundError("esdg_cns_amd/build.py lists files that do not exist: " + ", ".join(missing))
+    return list(names)
+
+
 def _sources():
-    return [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+    return _listed(SOURCES)
 
 
 def _headers():
-    return [h for h in HEADERS if os.path.exists(os.path.join(HERE, h))]
+    return _listed(HEADERS)
 
 
 def needs_build(out=OUT):

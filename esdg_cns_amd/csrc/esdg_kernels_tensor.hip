@@ -426,7 +426,7 @@ __global__ __launch_bounds__(WgP<N1>::TPB) void kt_project(TensorTables TT, Mesh
   const int64_t e0s = min(e0, M.e_begin + M.e_count - 1);   // in-range base for the geometry reads of idle lanes / idle groups
 
   double x[4];
-  issue_state_loads<N1>(Q, M.K, e0, vactive, ln.tid, x);
+  issue_state_loads<N1>(Q, M.K, ESDG_EW(e0), vactive, ln.tid, x);
   double U[4];
   state_at_quad<N1, MODAL>(ln, sTab, sA, sB, x, U);
   double qh[6], V[4];
@@ -452,9 +452,9 @@ __global__ __launch_bounds__(WgP<N1>::TPB) void kt_project(TensorTables TT, Mesh
     double Uf[4], qf[6];
     u_of_v<MODAL>(Vf, Uf);
     prim_logs<MODAL>(Uf, qf);
-    const double* g = M.geo + (e0 + ln.ef) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
+    const double* g = M.geo + (ESDG_EW(e0) + ln.ef) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
     const double lam = lf_lambda<MODAL>(Uf, g[0], g[1], g[2]);
-    const int64_t n = (e0 + ln.ef) * Nfq + ln.fn;
+    const int64_t n = (ESDG_EW(e0) + ln.ef) * Nfq + ln.fn;
     double2* a = reinterpret_cast<double2*>(A_U + n * FAU_NC);
     double2* a2 = reinterpret_cast<double2*>(A_U + (M.trace_nodes + n) * FAU_NC);
     a[0] = make_double2(qf[0], qf[1]);

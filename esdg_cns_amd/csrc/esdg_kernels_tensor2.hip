@@ -300,11 +300,11 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
     const int64_t e0 = FULL ? min(M.e_begin + grp * E, e_last) : M.e_begin;
     const int nE = FULL ? E : (int)(e_end - e0);
     const unsigned tvl = tv < (unsigned)(nE * Nq) ? tv : 0u, tfl = tf < (unsigned)(nE * Nfq) ? tf : 0u;
-    const unsigned mp = (unsigned)M.mapP[e0 * Nfq + tfl];
+    const unsigned mp = ESDG_EWN((unsigned)M.mapP[ESDG_EW(e0) * Nfq + tfl], Nfq);
 #pragma unroll
-    for (int f = 0; f < 4; ++f) x[f] = Q[f * KN + e0 * Nq + tvl];
+    for (int f = 0; f < 4; ++f) x[f] = Q[f * KN + ESDG_EW(e0) * Nq + tvl];
 #pragma unroll
-    for (int i = 0; i < GPT; ++i) { const unsigned n = tid + i * G::GT; geo[i] = M.geo[e0 * GEO_STRIDE + (n < (unsigned)(nE * GEO_STRIDE) ? n : 0u)]; }
+    for (int i = 0; i < GPT; ++i) { const unsigned n = tid + i * G::GT; geo[i] = M.geo[ESDG_EW(e0) * GEO_STRIDE + (n < (unsigned)(nE * GEO_STRIDE) ? n : 0u)]; }
     const d2* up = reinterpret_cast<const d2*>(A_U + (size_t)mp * FAU_NC);
     up0 = up[0]; up1 = up[1];
   }
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
     int bcf = 0;
     double vlid = 1.0;
     if (WALLS) {   // boundary flag (and lid velocity) of this lane's face node
-      const int64_t nfb = e0 * Nfq + (tf < (unsigned)(nE * Nfq) ? tf : 0u);
+      const int64_t nfb = ESDG_EW(e0) * Nfq + (tf < (unsigned)(nE * Nfq) ? tf : 0u);
       bcf = M.bc[nfb];
       if (M.vlid) vlid = M.vlid[nfb];
     }
@@ -338,12 +338,12 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
     __builtin_amdgcn_sched_barrier(0);
     // mapP first: it is waited for first (vmcnt counts in issue order), the others may then still be in flight.
     // unsigned: a sign-extending load would put its shift, and with it the wait for the load, right here
-    const unsigned mpn = (unsigned)M.mapP[e0n * Nfq + tfn];
+    const unsigned mpn = ESDG_EWN((unsigned)M.mapP[ESDG_EW(e0n) * Nfq + tfn], Nfq);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int f = 0; f < 4; ++f) x[f] = Q[f * KN + e0n * Nq + tvn];
+    for (int f = 0; f < 4; ++f) x[f] = Q[f * KN + ESDG_EW(e0n) * Nq + tvn];
 #pragma unroll
-    for (int i = 0; i < GPT; ++i) { const unsigned n = tid + i * G::GT; geo[i] = M.geo[e0n * GEO_STRIDE + (n < (unsigned)(nEn * GEO_STRIDE) ? n : 0u)]; }
+    for (int i = 0; i < GPT; ++i) { const unsigned n = tid + i * G::GT; geo[i] = M.geo[ESDG_EW(e0n) * GEO_STRIDE + (n < (unsigned)(nEn * GEO_STRIDE) ? n : 0u)]; }
     __builtin_amdgcn_sched_barrier(0);
     T2_STAMP(1);
 
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
         dv2 = __builtin_fma(dg1[j], sS12[colb + N1 * j], dv2);
       }
       if (vact) {
-        double* o = SG + e0 * Nq + tv;
+        double* o = SG + ESDG_EW(e0) * Nq + tv;
         o[0] = dv0; o[KN] = dv1; o[2 * KN] = dv2;
       }
     }
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
         sn[0] = -sj[0]; sn[1] = -sj[1]; sn[2] = -sj[2];
       }
       if (fact) {
-        double* bb = B + (e0 * Nfq + tf) * B_NC;
+        double* bb = B + (ESDG_EW(e0) * Nfq + tf) * B_NC;
         bb[0] = sn[0]; bb[1] = sn[1]; bb[2] = sn[2];
       }
     }
@@ -612,7 +612,9 @@ template <int N1, bool MODAL, bool VISC> struct RhsLds2 {
   static constexpr int ACC = SGF + 4 * NF;                            // NACC x 2 pair planes [NV]
   static constexpr int TABQ = ACC + 4 * NV, TABP = REC + 4 * NV;
   static constexpr int GEO = ACC + NACC * 4 * NV;
-  static constexpr int NLDS = GEO + ((G::E * GEO_STRIDE + 1) & ~1);
+  // (geometry staged by every lane, padded to whole rounds of the group: an `if (n < NGEO)` around the LDS write lets
+  // hipcc sink the global load into the branch and wait there with vmcnt(0) -- for every load in flight, traces included)
+  static constexpr int NLDS = GEO + ((G::E * GEO_STRIDE + G::GT - 1) / G::GT) * G::GT;
   static_assert(N1 * (N1 + (N1 & 1)) <= 2 * NV, "operator fits the third record plane");
 };
 
@@ -656,8 +658,9 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
   const bool inviscid = (ph.parts & 1) != 0, viscous = VISC && (ph.parts & 2) != 0;
   const bool vown = NV == G::GT || tid < (unsigned)NV, fown = NF == G::GT || tid < (unsigned)NF;   // not a duplicate lane
 
-  const int64_t e0 = M.e_begin + (int64_t)blockIdx.x * E;
-  const int nE = (int)min((int64_t)E, M.e_begin + M.e_count - e0);
+  const int64_t e0r = M.e_begin + (int64_t)blockIdx.x * E;
+  const int nE = (int)min((int64_t)E, M.e_begin + M.e_count - e0r);
+  const int64_t e0 = ESDG_EW(e0r);
   const bool vact = tid < (unsigned)(nE * Nq);
   constexpr RhsRows RR(N1);
   T2_STAMP_INIT;
@@ -671,7 +674,25 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
   double x[4], geo[GPT], qM[8], qP[8], bPn[3] = {0, 0, 0}, bOwn[3] = {0, 0, 0}, dvs[3] = {0, 0, 0};
   const unsigned tvl = tv < (unsigned)(nE * Nq) ? tv : 0u, tfl = tf < (unsigned)(nE * Nfq) ? tf : 0u, tvg = tv;
   const int64_t nf = e0 * Nfq + tfl;
-  const unsigned mp = (unsigned)M.mapP[nf];
+  const unsigned mp = ESDG_EWN((unsigned)M.mapP[nf], Nfq);
+  // Structured-neighbour guess ms of mp (-DESDG_T2_SPEC; MeshDev::spec_*, scalar kernel arguments): the neighbour-trace loads
+  // are issued from the guess at entry, beside the mapP load instead of behind it, mp is compared with it where the trace is
+  // first used, and lanes whose guess was wrong reload from mp.  MEASURED SLOWER and therefore off (round 3, same box:
+  // kt2_rhs 0.3745 ms with the guess, 0.3598 without, 0.3658 for the round-2 build): the traces are not needed until after
+  // the volume-volume rounds, and issuing their 2.5 KB per element at entry only puts them in the memory queues ahead of the
+  // next workgroups' state loads, which ARE needed at once.
+#ifndef ESDG_T2_SPEC
+  const unsigned ms = mp;
+#else
+  unsigned ms = (unsigned)nf;
+  if (M.spec_code >> 63) {   // uniform
+    const unsigned efl = tfl / Nfq, fnl = tfl - efl * Nfq, f = fnl / N1, i = fnl - f * N1;
+    const unsigned c = (unsigned)(M.spec_code >> (8 * f)) & 255u;
+    const int eo = f == 0 ? M.spec_eoff[0] : f == 1 ? M.spec_eoff[1] : f == 2 ? M.spec_eoff[2] : M.spec_eoff[3];
+    const int64_t es = min(max(e0 + (int64_t)efl + eo, (int64_t)0), M.K - 1);
+    ms = (unsigned)(es * Nfq) + (c & 7u) * N1 + spec_partner_node<N1, false>(c, i);
+  }
+#endif
   int bcf = 0;
   double vlid = 1.0;
   if (WALLS) {   // boundary flag (1 wall, 2 lid, 3 inflow, 4 copy) and lid velocity of this lane's face node
@@ -684,7 +705,11 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
   for (int i = 0; i < GPT; ++i) { const unsigned n = tid + i * G::GT; geo[i] = M.geo[e0 * GEO_STRIDE + (n < (unsigned)(nE * GEO_STRIDE) ? n : 0u)]; }
   static_assert(N1 * N1 <= G::GT, "one operator entry per lane");
   double tabq = 0.0, tabp = 0.0;
-  if (MODAL) { const unsigned n = tid < (unsigned)(N1 * N1) ? tid : 0u; tabq = TT.dbl[TL.IQ + n]; tabp = TT.dbl[TL.IP + n]; }
+  // (every lane loads and later stages an entry, lanes beyond the N1*N1 entries a duplicate: a store under `if (tid < N1*N1)`
+  // lets hipcc sink the load into the branch and wait there with vmcnt(0), i.e. for every load in flight -- and the other
+  // wave of the group then waits at the barrier behind it)
+  const unsigned tabn = tid % (unsigned)(N1 * N1), tabo = (tabn / N1) * N1P + tabn % N1;
+  if (MODAL) { tabq = TT.dbl[TL.IQ + tabn]; tabp = TT.dbl[TL.IP + tabn]; }
   // packed rows (RhsRows): NPV + NPF coalesced 16-byte loads and one int4 + one int per lane
   double svv[NRND > 0 ? NRND : 1], pw[4], svf[N1], pd, wfac;
   unsigned pid[NRND > 0 ? NRND : 1], fq[4], fnode0, fstride;
@@ -730,8 +755,8 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
 #else
     const d2* aM = reinterpret_cast<const d2*>(A_U + nf * FAU_NC);
     const d2* aM2 = reinterpret_cast<const d2*>(A_U + (M.trace_nodes + nf) * FAU_NC);
-    const d2* aP = reinterpret_cast<const d2*>(A_U + (size_t)mp * FAU_NC);
-    const d2* aP2 = reinterpret_cast<const d2*>(A_U + (M.trace_nodes + (size_t)mp) * FAU_NC);
+    const d2* aP = reinterpret_cast<const d2*>(A_U + (size_t)ms * FAU_NC);
+    const d2* aP2 = reinterpret_cast<const d2*>(A_U + (M.trace_nodes + (size_t)ms) * FAU_NC);
 #endif
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -745,9 +770,9 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
     double U[4];
     T2_STAMP(0);     // table rows + load issue
 #pragma unroll
-    for (int i = 0; i < GPT; ++i) { const unsigned n = tid + i * G::GT; if (n < (unsigned)NGEO) sGeo[n] = geo[i]; }
+    for (int i = 0; i < GPT; ++i) sGeo[tid + i * G::GT] = geo[i];
     if (MODAL) {
-      if (tid < (unsigned)(N1 * N1)) lds[LD::TABQ + (tid / N1) * N1P + tid % N1] = tabq;
+      lds[LD::TABQ + tabo] = tabq;
       sRec[tv] = make_double2(x[0], x[1]);
       sRec[NV + tv] = make_double2(x[2], x[3]);
     } else {
@@ -817,6 +842,17 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
       }
     }
     T2_STAMP(4);   // volume-volume rounds
+#ifndef ESDG_EXP_SMALLTRACE
+    if (mp != ms) {   // the guess was wrong for this lane: the neighbour's trace from the index mapP holds
+      const d2* bP = reinterpret_cast<const d2*>(A_U + (size_t)mp * FAU_NC);
+      const d2* bP2 = reinterpret_cast<const d2*>(A_U + (M.trace_nodes + (size_t)mp) * FAU_NC);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const d2 p = bP[c], p2 = bP2[c];
+        qP[2 * c] = p.x; qP[2 * c + 1] = p.y; qP[4 + 2 * c] = p2.x; qP[5 + 2 * c] = p2.y;
+      }
+    }
+#endif
     if (VISC) {   // needed after the volume-face pairs: issued here, their destinations are not live during the rounds above
 #pragma unroll
       for (int c = 0; c < 3; ++c) { bPn[c] = B[(size_t)mp * B_NC + c]; bOwn[c] = B[nf * B_NC + c]; dvs[c] = SG[c * KN + e0 * Nq + tvl]; }
@@ -940,7 +976,7 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
       d2* sB = sAcc;                       // accumulators: read above, rewritten only after the next barrier
       sA[tv] = make_double2(R[0], R[1]);
       sA[NV + tv] = make_double2(R[2], R[3]);
-      if (tid < (unsigned)(N1 * N1)) lds[LD::TABP + (tid / N1) * N1P + tid % N1] = tabp;   // IP into the (dead) third record plane
+      lds[LD::TABP + tabo] = tabp;   // IP into the (dead) third record plane
       __syncthreads();
       double ipl[N1P], iph[N1P];
       {

@@ -151,11 +151,16 @@ class RhsEngine:
             rank = dist.get_rank(group)
             on_dev = dist.get_backend(group) == "nccl"
             t = torch.zeros(128, dtype=torch.uint8, device=self.device if on_dev else "cpu")
-            if rank == 0:
-                check(L.esdg_comm_unique_id(idb))
-                t.copy_(torch.frombuffer(bytearray(bytes(idb)), dtype=torch.uint8))
+            if rank == 0:      # (an error here must not keep rank 0 out of the broadcast its peers are waiting in)
+                try:
+                    check(L.esdg_comm_unique_id(idb))
+                    t.copy_(torch.frombuffer(bytearray(bytes(idb)), dtype=torch.uint8))
+                except Exception:  # noqa: BLE001
+                    t.zero_()
             dist.broadcast(t, src=0, group=group)
             raw = bytes(t.cpu().numpy().tobytes())
+            if not any(raw):
+                raise RuntimeError("rank 0 could not create the RCCL unique id (esdg_comm_unique_id)")
             check(L.esdg_comm_init(ctx, C.create_string_buffer(raw, 128), rank, dist.get_world_size(group)))
         self.transport = "rccl"
         return int(L.esdg_comm_size(ctx))

@@ -13,7 +13,7 @@ maps can be compared bit-for-bit with what the Julia driver would hold:
 
 Parity status of this file: the reference has no tests for src/ (SURVEY.md section 4), so
 set-up parity is pinned by mathematical definitions only (quadrature exactness,
-mapP involution, free-stream preservation) -- see tests/test_oracle_setup.py.
+mapP involution, free-stream preservation) -- see tests/test_setup.py.
 """
 import math
 

@@ -110,7 +110,7 @@ def test_full_size_properties_cns_512(E):
         assert abs(float((wJ * (rd.Vq @ x)).sum())) <= 2e-9 * max(scale, 1.0)
     Qd = eng.upload(Q)
     r = eng.rhs(Qd)
-    assert eng.rhstest(Qd, r) < 0                                    # LF + viscous dissipation: entropy decays
+    assert eng.rhstest(Qd, r) < 0                                    # LF dissipation (this engine has viscous_dissp=False): entropy decays
     ec = E.RhsEngine(rd, md, ops, E.EULER_MODAL, inviscid_dissp=False)
     r2 = ec.rhs(Qd)
     assert abs(ec.rhstest(Qd, r2)) < 1e-9                            # entropy conservative without LF

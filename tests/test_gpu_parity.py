@@ -56,8 +56,8 @@ def test_euler_collocated_matches_oracle(eng_mod, oracle_lib, N, Kx, Ky):
     truth_gate(f"euler N={N} {Kx}x{Ky} vortex", _gpu_rhs(eng, Q), f64(Q), truth(Q))
     Qw = steep_state(md.xq, md.yq)
     e_gpu, _ = truth_gate(f"euler N={N} {Kx}x{Ky} steep", _gpu_rhs(eng, Qw), f64(Qw), truth(Qw))
-    if N >= 3 and Kx <= 16:
-        assert e_gpu <= TOL, e_gpu         # strict north-star bound where the reference is well conditioned
+    if N >= 3:
+        assert e_gpu <= TOL, e_gpu         # strict north-star bound where the reference is well conditioned (64x64: 4.3e-13)
 
 
 @pytest.mark.parametrize("form,N,Kx,Ky", [("euler", 4, 1, 1), ("euler", 3, 2, 1), ("euler", 2, 1, 3), ("cns", 4, 1, 1), ("cns", 4, 2, 1),
@@ -91,7 +91,7 @@ def test_cns_modal_matches_oracle(eng_mod, oracle_lib, N, Kx, Ky):
     truth_gate(f"cns N={N} {Kx}x{Ky} vortex", _gpu_rhs(eng, Q), o.rhsRK(Q, False)[0], q.rhsRK(Q, False)[0])
     Qw = steep_state(md.x, md.y)
     e_gpu, _ = truth_gate(f"cns N={N} {Kx}x{Ky} steep", _gpu_rhs(eng, Qw), o.rhsRK(Qw, False)[0], q.rhsRK(Qw, False)[0])
-    if N >= 3 and Kx <= 16:
+    if N >= 3:                             # (N=2 7x9: the Float64 oracle itself is 1.7e-12 from the truth; 64x64 N=4: 7.7e-13)
         assert e_gpu <= TOL, e_gpu
 
 
@@ -271,3 +271,80 @@ def test_product_and_oracle_setups_feed_the_same_rhs(eng_mod, oracle_lib):
     print(f"two set-ups, N={N} {Kx}x{Ky}: gpu(product inputs) vs oracle(oracle inputs) {d:.2e}; oracle on both inputs {setup_sens:.2e}")
     truth = orc.CnsOracle(pp, quad=True).rhsRK(Q, False)[0]
     assert d <= max(TOL, 2 * rel_l2(ref_p, truth) + 2 * setup_sens)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Oracle VALUES at the headline sizes.  The Float64 oracle runs on all usable host cores (element
+# loops under OpenMP: 2-3 s at 512^2); the binary128 truth costs ~9 ms per CNS element and thread (512^2: ~4 min on the 16
+# cores of a GPU box), so by default it runs at 256^2 and the 512^2 evaluation is held against the Float64 oracle with a
+# bound derived from it; ESDG_TRUTH_512=1 runs the binary128 evaluation at 512^2 too (recorded once in
+# profiles/parity_r03.json).  Measured on CPU (oracle alone): e_orc of the vortex state doubles with every refinement
+# (CNS N=4: 1.9e-11, 3.0e-11, 6.0e-11, 1.2e-10 at 16^2 ... 128^2; Euler 7e-12 ... 4.5e-11): round-off of O(1) fluxes
+# divided by J ~ h^2.
+# ------------------------------------------------------------------------------------------------------------------------
+def _all_cores():
+    import os
+    from oracle import oracle as orc
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    orc.lib().oracle_set_threads(n)
+    orc.lib_quad().oracle_set_threads(n)
+    return n
+
+
+def _one_core():
+    from oracle import oracle as orc
+    orc.lib().oracle_set_threads(1)
+    orc.lib_quad().oracle_set_threads(1)
+
+
+def test_cfg2_euler_256_exact_size_values_against_oracle_and_truth(eng_mod, oracle_lib):
+    """BASELINE config 2 (2D Euler, N=4, 256x256) at its exact size: `rhs` of examples/dg2D_euler_quad.jl:141-194,
+    GPU vs the Float64 oracle vs the binary128 truth on identical inputs, same gate as every other case."""
+    rd, md, ops, Q = product_euler_problem(4, 256, 256)
+    p = as_oracle_problem(rd, md, ops, Q)
+    f64, truth = _euler(p)
+    eng = eng_mod.RhsEngine(rd, md, p.ops, eng_mod.EULER_COLLOCATED)
+    _all_cores()
+    try:
+        truth_gate("cfg2 euler N=4 256x256 vortex", _gpu_rhs(eng, Q), f64(Q), truth(Q))
+        Qw = steep_state(md.xq, md.yq)
+        # (no strict 1e-12 here: at this resolution neighbouring nodes of the steep state differ by |f| ~ 4e-4, close to
+        # logmean's ill-conditioned window, and the oracle's own error grows like 1/h: 6e-14 at 12x8, 4e-13 at 64x64)
+        truth_gate("cfg2 euler N=4 256x256 steep", _gpu_rhs(eng, Qw), f64(Qw), truth(Qw))
+    finally:
+        _one_core()
+
+
+def test_cfg3_cns_512_exact_size_values_against_oracle(eng_mod, oracle_lib):
+    """BASELINE config 3 (2D CNS, N=4, 512x512, the headline workload) at its exact size: `rhsRK!` of
+    dg2D_CNS_cavity_optimized.jl:955-972, GPU vs the Float64 oracle on all cores.  The binary128 truth runs at 256x256
+    (same state, same gate); at 512x512 the distance to the Float64 oracle must stay below 3 x the e_orc expected there
+    (= twice the e_orc measured at 256x256; |gpu - f64| <= e_gpu + e_orc <= 3 e_orc when the gate holds), unless
+    ESDG_TRUTH_512=1 asks for the binary128 evaluation at the full size as well."""
+    import os
+    _all_cores()
+    try:
+        rd, md, ops, Q = product_cns_problem(4, 256, 256)
+        p = as_oracle_problem(rd, md, ops, Q, **PHYS)
+        o, q = _cns(p)
+        eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, Re=p.Re, mu=p.mu, lam=p.lam, Pr=p.Pr)
+        _, e_orc_256 = truth_gate("cns N=4 256x256 vortex", _gpu_rhs(eng, Q), o.rhsRK(Q, False)[0], q.rhsRK(Q, False)[0])
+        del eng, o, q, p
+        rd, md, ops, Q = product_cns_problem(4, 512, 512)
+        p = as_oracle_problem(rd, md, ops, Q, **PHYS)
+        o, q = _cns(p)
+        eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, Re=p.Re, mu=p.mu, lam=p.lam, Pr=p.Pr)
+        got, ref = _gpu_rhs(eng, Q), o.rhsRK(Q, False)[0]
+        d = rel_l2(got, ref)
+        print(f"cfg3 cns N=4 512x512 vortex: gpu-vs-oracle={d:.2e}  (e_orc at 256x256: {e_orc_256:.2e})")
+        assert d <= 3 * 2 * e_orc_256, (d, e_orc_256)
+        if os.environ.get("ESDG_TRUTH_512", "0") == "1":
+            truth_gate("cfg3 cns N=4 512x512 vortex", got, ref, q.rhsRK(Q, False)[0])
+    finally:
+        _one_core()

@@ -8,9 +8,11 @@ T=/tmp/esdg_asan; mkdir -p $T
 g++ -fsanitize=address,undefined -fno-omit-frame-pointer -g -O1 -Iinclude -x c++ tools/asan_setup.c esdg_cns_amd/csrc/esdg_setup.cpp -o $T/asan_setup
 ASAN_OPTIONS=detect_leaks=1 $T/asan_setup | tail -2
 # 2. the whole library with host-side ASan/UBSan (device code unsanitized), swapped in for the host-only tests
+# (source list and link flags come from esdg_cns_amd/build.py, so a new source file or library cannot be forgotten here)
+SRCS=$(python -c "from esdg_cns_amd import build as b; print(' '.join(b._sources()))")
+LINK=$(python -c "from esdg_cns_amd import build as b; print(' '.join(b.LINK))")
 (cd esdg_cns_amd && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined \
-   -fno-gpu-sanitize -shared-libsan -o $T/libesdg_hip.so csrc/esdg_kernels.hip csrc/esdg_kernels_tensor.hip \
-   csrc/esdg_kernels_hex.hip csrc/esdg_kernels_err.hip csrc/esdg_api.hip csrc/esdg_setup.cpp)
+   -fno-gpu-sanitize -shared-libsan -o $T/libesdg_hip.so $SRCS $LINK)
 cp esdg_cns_amd/libesdg_hip.so $T/keep.so
 trap 'cp $T/keep.so esdg_cns_amd/libesdg_hip.so; touch esdg_cns_amd/libesdg_hip.so' EXIT
 cp $T/libesdg_hip.so esdg_cns_amd/libesdg_hip.so
