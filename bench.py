@@ -64,7 +64,7 @@ def build_problem(N, Kx, Ky_total, e0, e1, formulation):
     return rd, md, ops, Q
 
 
-def build_hex_problem(N, Kx, Ky, Kz_total, e0, e1, curve=0.0):
+def build_hex_problem(N, Kx, Ky, Kz_total, e0, e1, curve=0.0, per_node=False):
     from esdg_cns_amd import physics as ph
     from esdg_cns_amd import setup_dg as sd
     VX, VY, VZ, EToV = sd.uniform_hex_mesh(Kx, Ky, Kz_total)
@@ -73,7 +73,7 @@ def build_hex_problem(N, Kx, Ky, Kz_total, e0, e1, curve=0.0):
     sd.make_periodic_3d(md, rd)
     ops = sd.hex_ops(rd)
     # affine: one metric row per element (geo_ld = 1); curved (--hex-curve a, the script's mapping :67-73): all Nh rows
-    sd.hex_driver_geometry(md, rd, hybrid=bool(curve), a=curve)
+    sd.hex_driver_geometry(md, rd, hybrid=bool(curve) or per_node, a=curve)
     x, y, z = md.xq, md.yq, md.zq
     rho = 2 + .5 * np.sin(np.pi * x) * np.cos(np.pi * y)
     u, v, w = .3 * np.sin(np.pi * z + .2), 1 + .1 * np.cos(np.pi * x), .1 * np.sin(np.pi * (x + y) + .3)
@@ -198,6 +198,8 @@ def parse_args(argv=None):
     ap.add_argument("--kz-per-gpu", type=int, default=16, help="element layers per GPU (weak scaling, hex)")
     ap.add_argument("--lf", type=float, default=0.0, help="hex: LF factor (the reference has 0*.25)")
     ap.add_argument("--hex-curve", type=float, default=0.0, help="hex: amplitude a of the script's curved mapping (0 = affine)")
+    ap.add_argument("--hex-per-node", action="store_true", help="hex: pass the metric arrays at all hybrid nodes (with "
+                    "ESDG_HEX_PER_NODE=1 the library then uses every node's own values on affine meshes too)")
     ap.add_argument("--formulation", choices=["cns", "euler", "hex"], default="cns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the process group (nccl = RCCL; gloo only to "
@@ -264,7 +266,7 @@ def run(args):
         Kz_total = args.kz_per_gpu * world
         rank_offsets = np.array([Kx * Kx * args.kz_per_gpu * r for r in range(world + 1)], dtype=np.int64)   # z-slabs
         e0, e1 = int(rank_offsets[rank]), int(rank_offsets[rank + 1])
-        rd, md, ops, Q = build_hex_problem(N, Kx, Kx, Kz_total, e0, e1, args.hex_curve)
+        rd, md, ops, Q = build_hex_problem(N, Kx, Kx, Kz_total, e0, e1, args.hex_curve, args.hex_per_node)
         eng = engine.RhsEngine(rd, md, ops, engine.EULER_HEX_COLLOCATED, lf_scale=args.lf, rank=rank, nranks=world,
                                rank_offsets=rank_offsets)
         K_total = Kx * Kx * Kz_total

@@ -566,7 +566,7 @@ struct esdg_ctx {
   int Np = 0, Nq = 0, Nfq = 0;
   // device storage
   DevBuf d_pair_ij, d_pair_c, d_inc_ptr, d_inc, d_Ef_i, d_Ef_v, d_Ph_i, d_Ph_v, d_Lf_i, d_Lf_v, d_Dr_i, d_Dr_v, d_Ds_i,
-      d_Ds_v, d_Vq, d_Pq, d_geo, d_mapP, d_bc, d_vlid, d_wJq, d_sendlist, d_partial;
+      d_Ds_v, d_Vq, d_Pq, d_geo, d_fnrm, d_mapP, d_bc, d_vlid, d_wJq, d_sendlist, d_partial;
   DevBuf t_dbl, t_int, d_G9, d_Jq, d_nrm;
   DevBuf t_nd, t_ni, t_fd, t_fi;   // per-node rows of the v2 tensor kernels
   DevBuf t_rvd, t_rvi, t_rfd, t_rfi;   // packed rows of kt2_rhs (RhsRows)
@@ -943,6 +943,11 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   UP(d_Dr_i, eDr.idx); UP(d_Dr_v, eDr.val); UP(d_Ds_i, eDs.idx); UP(d_Ds_v, eDs.val);
   UP(d_Vq, Vq.a); UP(d_Pq, Pq.a);
   UP(d_geo, geo); UP(d_mapP, mapP); UP(d_sendlist, sendlist);
+  {   // per-node normals exactly as passed (MeshDev::fnrm)
+    std::vector<double> fn3((size_t)K * Nfq * 3);
+    for (size_t n = 0; n < (size_t)K * Nfq; ++n) { fn3[3 * n] = mesh->nxJ[n]; fn3[3 * n + 1] = mesh->nyJ[n]; fn3[3 * n + 2] = mesh->sJ[n]; }
+    UP(d_fnrm, fn3);
+  }
   // wall-boundary flags per local face node: 1 wall, 2 lid (init_BC_funs, cavity :135-155)
   std::vector<uint8_t> bcflag;
   std::vector<double> vlid;
@@ -1041,6 +1046,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   T.Vq = c->d_Vq.as<double>(); T.Pq = c->d_Pq.as<double>();
   c->M.K = K; c->M.e_begin = 0; c->M.e_count = K;
   c->M.geo = c->d_geo.as<double>(); c->M.mapP = c->d_mapP.as<int32_t>(); c->M.bc = bcflag.empty() ? nullptr : c->d_bc.as<uint8_t>();
+  c->M.fnrm = c->d_fnrm.as<double>();
   c->M.vlid = vlid.empty() ? nullptr : c->d_vlid.as<double>();
   set_interior(c, pl.mapP, K, Nfq);
   if (use_fast) detect_structured(c->M, pl.mapP, K, 4, N1, false);
@@ -1169,6 +1175,10 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
   }
   // curved elements (the `a != 0` mapping of dg3D_euler_hex.jl:67-73): per-node metric terms at the hybrid nodes, J at
   // the quadrature nodes and per-node normals, as the script's sparse_hadamard_sum / rhs use them (:145-151, :193-198)
+  // ESDG_HEX_PER_NODE=1: the per-node path for affine meshes too (every node's own metric terms and normals, as the script
+  // uses them; the element record above replaces them by means, which filters the round-off of the driver's set-up)
+  if (const char* env = getenv("ESDG_HEX_PER_NODE"))
+    if (env[0] == '1' && ld == Nh) curved = true;
   std::vector<double> G9, Jq, nrm;
   if (curved) {
     if (ld != Nh) return fail(ESDG_ERR_STRUCTURE, "curved hexahedra need the metric arrays at all Nh = %d hybrid nodes (geo_ld = %d)", Nh, ld);
@@ -1257,7 +1267,7 @@ static bool v2_on_walls(const esdg_ctx* ctx) {
 }
 
 static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs, const LsrkFuse& lf, void* stream,
-                          int64_t e_begin = 0, int64_t e_count = -1) {
+                          int64_t e_begin = 0, int64_t e_count = -1, int role = 0) {
   if (!ctx || !Q) return fail(ESDG_ERR_ARG, "null argument");
   const bool ranged = e_count >= 0;
   if (ranged) {
@@ -1268,9 +1278,9 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
   }
   struct RangeGuard {   // full-range launches leave the mesh record untouched
     MeshDev& M; int64_t K;
-    ~RangeGuard() { M.e_begin = 0; M.e_count = K; }
+    ~RangeGuard() { M.e_begin = 0; M.e_count = K; M.launch_role = 0; }
   } rg{ctx->M, ctx->K};
-  if (ranged) { ctx->M.e_begin = e_begin; ctx->M.e_count = e_count; }
+  if (ranged) { ctx->M.e_begin = e_begin; ctx->M.e_count = e_count; ctx->M.launch_role = role; }
   if (!ctx->ws) return fail(ESDG_ERR_STATE, "workspace not bound (esdg_bind_workspace)");
   if (phase < 0 || phase >= ctx->nphases) return fail(ESDG_ERR_ARG, "bad phase %d", phase);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1305,7 +1315,7 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
     if (!rhs && !lf.Qw) return fail(ESDG_ERR_ARG, "rhs output is null");
     if (lf.Qw && !ctx->use_fast) return fail(ESDG_ERR_STATE, "the fused RK update needs the tensor kernels");
     rc = -1;
-    if (ctx->use_fast && !ctx->ph.dbg && (ctx->M.bc ? v2_on_walls(ctx) : !(ctx->v1 & 2)))      // v2 kernel: degrees N <= 7
+    if (ctx->use_fast && !ctx->ph.dbg && (ctx->M.bc ? v2_on_walls(ctx) : !(ctx->v1 & 2)))      // v2 kernel: N1 = N + 1 = 2 ... 8
       rc = launch_rhs_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s);
     if (rc == -1)
       rc = ctx->use_fast ? launch_rhs_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s)
@@ -1567,13 +1577,13 @@ static int rhs_sharded_impl(esdg_ctx* ctx, const double* Q, double* rhs, const L
     if (b == s && ph == 0) {
       // one stream: boundary strips first so that the exchange is in flight during the interior
     } else {
-      if ((rc = rhs_phase_impl(ctx, ph, Q, rhs, f, stream, ilo, ihi - ilo)) != 0) return rc;
+      if ((rc = rhs_phase_impl(ctx, ph, Q, rhs, f, stream, ilo, ihi - ilo, b != s ? 1 : 0)) != 0) return rc;
       if (b != s) HIP_TRY(hipEventRecord(ctx->ev_int[ph], s));
     }
     if (b != s && ph > 0) HIP_TRY(hipStreamWaitEvent(b, ctx->ev_int[ph - 1], 0));
     if ((rc = wait_exchanges(ctx, ph, b)) != 0) return rc;
-    if ((rc = rhs_phase_impl(ctx, ph, Q, rhs, f, b, 0, ilo)) != 0) return rc;
-    if ((rc = rhs_phase_impl(ctx, ph, Q, rhs, f, b, ihi, K - ihi)) != 0) return rc;
+    if ((rc = rhs_phase_impl(ctx, ph, Q, rhs, f, b, 0, ilo, b != s ? 2 : 0)) != 0) return rc;
+    if ((rc = rhs_phase_impl(ctx, ph, Q, rhs, f, b, ihi, K - ihi, b != s ? 2 : 0)) != 0) return rc;
     for (int x = 0; x < (int)ctx->xch.size(); ++x)
       if (ctx->xch[x].after_phase == ph && (rc = esdg_halo_pack(ctx, x, b)) != 0) return rc;
     if (outgoing && (rc = post_exchanges(ctx, ph, b)) != 0) return rc;

@@ -72,6 +72,11 @@ struct MeshDev {
   const int32_t* mapP;     // [K][Nfq]  local face-node index, or ghost slot >= K*Nfq
   const uint8_t* bc;       // [K][Nfq]  0 interior/periodic, 1 wall, 2 lid, 3 Dirichlet inflow, 4 copy; may be null
   const double* vlid;      // [K][Nfq]  lid velocity where bc == 2; null = 1 everywhere
+  const double* fnrm;      // quads: [K][Nfq][3] = nxJ, nyJ, sJ of every face node AS THE DRIVER HOLDS THEM.  On an affine face they
+                           // differ from node to node by the round-off of the driver's set-up (~1e-13 relative), and the reference
+                           // uses them per node: replacing them by the face mean moves the RHS by 1e-10 ... 4e-10 relative on
+                           // 128^2 ... 256^2 meshes, several times the Float64 reference's own rounding error (round 3,
+                           // tools/parity_scaling.py).  The geometry record keeps the means for code that needs a face constant.
   const double* wJq;       // [K][Nq] (diagnostics) may be null
   // curved (non-affine) hexahedra only, null otherwise: per-node metric terms [K][9][Nh] (row m9 = comp*3 + operator:
   // rxJ sxJ txJ ryJ syJ tyJ rzJ szJ tzJ), J at the quadrature nodes [K][Nq], normals [K][4][Nfq] = nxJ nyJ nzJ sJ
@@ -86,6 +91,10 @@ struct MeshDev {
   // stays the only source of truth.
   int32_t spec_eoff[6];
   uint64_t spec_code;
+  // Role of a ranged launch in the overlapped sharded schedule (set by rhs_sharded_impl only; 0 everywhere else, incl.
+  // esdg_rhs_phase_range): 1 = the interior beside which boundary strips run, 2 = a boundary strip.  The persistent
+  // kt2_sigma leaves a few workgroup slots free in role 1 and asks for no more than those in role 2 (ESDG_T2_RESERVE).
+  int32_t launch_role;
 };
 
 // node of the partner face that the structured-neighbour guess pairs with node n of a face (c: the face's byte of

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(ESDG_TPB) void k_project(Tables T, MeshDev M, Phys 
     }
     double U[4];
     u_of_v<MODAL>(V, U);
-    const double* g = M.geo + (e0 + e) * GEO_STRIDE + 5 + 3 * (fn / N1);
+    const double* g = M.fnrm + ((e0 + e) * Nfq + fn) * 3   /* per-node (nxJ, nyJ, sJ), MeshDev::fnrm */;
     const double lam = lf_lambda<MODAL>(U, g[0], g[1], g[2]);
     const int64_t n = (e0 + e) * Nfq + fn;
     double* a = A_U + n * AU_NC;
@@ -296,7 +296,7 @@ __device__ __forceinline__ void visc_sigma(const Tables& T, const MeshDev& M, co
     for (int t = 0; t < T.wLf; ++t) {
       const double a = T.Lf_val[q * T.wLf + t];
       const int fn = T.Lf_idx[q * T.wLf + t];
-      const double* gn = g + 5 + 3 * (fn / N1);
+      const double* gn = M.fnrm + ((e0 + e) * Nfq + fn) * 3;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const double d = sDv[(e * 3 + c) * Nfq + fn];
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(ESDG_TPB) void k_sigma(Tables T, MeshDev M, Phys ph
   __syncthreads();
   for (int idx = tid; idx < nE * Nfq; idx += ESDG_TPB) {
     const int e = idx / Nfq, fn = idx - e * Nfq;
-    const double* gn = M.geo + (e0 + e) * GEO_STRIDE + 5 + 3 * (fn / N1);
+    const double* gn = M.fnrm + ((e0 + e) * Nfq + fn) * 3   /* per-node (nxJ, nyJ, sJ), MeshDev::fnrm */;
     double sn[3];
     face_normal_stress<N1>(T, sS, e, fn, gn[0], gn[1], sn);
     double* b = B + ((e0 + e) * Nfq + fn) * B_NC;
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(ESDG_TPB) void k_rhs(Tables T, MeshDev M, Phys ph, 
     for (int c = 0; c < 6; ++c) d[c] = qM[c];
     double Fx[4], Fy[4];
     ec_flux<MODAL>(qM, qP, Fx, Fy);
-    const double* gn = M.geo + (e0 + e) * GEO_STRIDE + 5 + 3 * (fn / N1);
+    const double* gn = M.fnrm + ((e0 + e) * Nfq + fn) * 3   /* per-node (nxJ, nyJ, sJ), MeshDev::fnrm */;
     const double LFc = ph.lf_scale * fmax(lamM, lamP) * gn[2];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(ESDG_TPB) void k_rhs(Tables T, MeshDev M, Phys ph, 
     // (the neighbour's outward normal is minus ours), dg_div! :606
     for (int idx = tid; idx < nE * Nfq; idx += ESDG_TPB) {
       const int e = idx / Nfq, fn = idx - e * Nfq;
-      const double* gn = M.geo + (e0 + e) * GEO_STRIDE + 5 + 3 * (fn / N1);
+      const double* gn = M.fnrm + ((e0 + e) * Nfq + fn) * 3   /* per-node (nxJ, nyJ, sJ), MeshDev::fnrm */;
       double sn[3];
       face_normal_stress<N1>(T, sS, e, fn, gn[0], gn[1], sn);
       const int64_t n = (e0 + e) * Nfq + fn;

@@ -141,6 +141,31 @@ __device__ __forceinline__ void stage_tables(const HexTables& HT, double* sTab, 
   for (int i = threadIdx.x; i < L.NINT; i += HW * HNWV) sInt[i] = HT.ints[i];
 }
 
+// The same copy in two halves, for kernels whose other loads are in flight at the same time: load() issues every table load
+// into registers without waiting (all lanes, the index clamped: lanes beyond the table re-read its last entry), store() writes
+// them to LDS (duplicate lanes write the same value to the same slot).  A strided `for (i = tid; i < n; ...)` copy, or any
+// LDS store under `if (lane < n)`, makes hipcc put the load next to the store and wait for it with vmcnt(0) -- i.e. for
+// every load of the wave in flight, state and neighbour traces included, once per round of the copy.
+template <int N1>
+struct TableRegs {
+  static constexpr HexLayout L = HexLayout(N1);
+  static constexpr int T = HW * HNWV, ND = (L.NDBL + T - 1) / T, NI = (L.NINT + T - 1) / T;
+  double d[ND];
+  int i[NI];
+  __device__ __forceinline__ void load(const HexTables& HT) {
+#pragma unroll
+    for (int r = 0; r < ND; ++r) d[r] = HT.dbl[min((int)threadIdx.x + r * T, L.NDBL - 1)];
+#pragma unroll
+    for (int r = 0; r < NI; ++r) i[r] = HT.ints[min((int)threadIdx.x + r * T, L.NINT - 1)];
+  }
+  __device__ __forceinline__ void store(double* sTab, int* sInt) const {
+#pragma unroll
+    for (int r = 0; r < ND; ++r) sTab[min((int)threadIdx.x + r * T, L.NDBL - 1)] = d[r];
+#pragma unroll
+    for (int r = 0; r < NI; ++r) sInt[min((int)threadIdx.x + r * T, L.NINT - 1)] = i[r];
+  }
+};
+
 // XCD-aware element-block id (see the header); returns -1 for padding workgroups
 __device__ __forceinline__ int64_t block_of(int64_t nblk, bool remap) {
   const int64_t b = blockIdx.x;
@@ -174,12 +199,15 @@ __global__ __launch_bounds__(HW * HNWV) void kh_project(HexTables HT, MeshDev M,
   const bool active = e < M.e_begin + M.e_count;
   const int64_t ec = active ? e : M.e_begin + M.e_count - 1;
   const bool vin = lane < Nq;
-  double U[HEX_NFLD] = {1.0, 0.0, 0.0, 0.0, 1.0};
-  if (vin) {
+  double U[HEX_NFLD];
+  TableRegs<N1> tr;
+  tr.load(HT);
+  {
+    const int lu = vin ? lane : 0;   // (lanes without a node compute on node 0's data; their results are not stored)
 #pragma unroll
-    for (int c = 0; c < HEX_NFLD; ++c) U[c] = Q[(int64_t)c * M.K * Nq + ec * Nq + lane];
+    for (int c = 0; c < HEX_NFLD; ++c) U[c] = Q[(int64_t)c * M.K * Nq + ec * Nq + lu];
   }
-  stage_tables<N1>(HT, sTab, sInt);
+  tr.store(sTab, sInt);
   double q[7], V[HEX_NFLD];
   prim_logs3(U, q);
   v_of_prim3(q, V);
@@ -245,26 +273,31 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
   constexpr int Nh = Nq + Nfq;
 
   // ---- issue the global loads ---------------------------------------------------------------------
-  double U[HEX_NFLD] = {1.0, 0.0, 0.0, 0.0, 1.0};
-  if (vin) {
+  // Every load below is unconditional and issued before anything is waited for (see TableRegs): the neighbour index first
+  // (the neighbour's traces depend on it), then tables, geometry and state, which the pointwise stage needs, and the
+  // traces of the first face round last; the waits that follow are counted, none is vmcnt(0).
+  double rm[HEX_AU_NC], rp[HEX_AU_NC];
+  const int fc0 = lane < Nfq ? lane : Nfq - 1;
+  const int64_t nm0 = ec * Nfq + fc0;
+  const int64_t np0 = M.mapP[nm0];
+  TableRegs<N1> tr;
+  tr.load(HT);
+  const int gl = lane < HEX_GEO_STRIDE ? lane : HEX_GEO_STRIDE - 1;
+  const double geo_r = M.geo[ec * HEX_GEO_STRIDE + gl];
+  double U[HEX_NFLD];
+  {
+    const int lu = vin ? lane : 0;
 #pragma unroll
-    for (int c = 0; c < HEX_NFLD; ++c) U[c] = Q[(int64_t)c * M.K * Nq + ec * Nq + lane];
+    for (int c = 0; c < HEX_NFLD; ++c) U[c] = Q[(int64_t)c * M.K * Nq + ec * Nq + lu];
   }
   // raw traces of the first face-node round (own + neighbour through mapP); later rounds are prefetched one
   // round ahead inside the face loop
-  double rm[HEX_AU_NC], rp[HEX_AU_NC];
-  {
-    const int fc = lane < Nfq ? lane : Nfq - 1;
-    const int64_t nm = ec * Nfq + fc;
-    const int64_t np = M.mapP[nm];
 #pragma unroll
-    for (int c = 0; c < HEX_AU_NC; ++c) {
-      rm[c] = A_U[nm * HEX_AU_NC + c];
-      rp[c] = A_U[np * HEX_AU_NC + c];
-    }
-  }
-  if (lane < HEX_GEO_STRIDE) sGeo[wv][lane] = M.geo[ec * HEX_GEO_STRIDE + lane];
-  stage_tables<N1>(HT, sTab, sInt);
+  for (int c = 0; c < HEX_AU_NC; ++c) rm[c] = A_U[nm0 * HEX_AU_NC + c];
+#pragma unroll
+  for (int c = 0; c < HEX_AU_NC; ++c) rp[c] = A_U[np0 * HEX_AU_NC + c];
+  sGeo[wv][gl] = geo_r;
+  tr.store(sTab, sInt);
 #pragma unroll
   for (int c = 0; c < HEX_NFLD; ++c) sAcc[c * HW + lane] = 0.0;
   const int myslot = slot_of(lane);
@@ -476,17 +509,20 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
     }
     const double miJ = -rcp_refined(CURVED ? M.Jq[ec * Nq + lq] : geo[9]);
     if (active) {
+      if (lf.Qw) {   // fused low-storage RK stage (same rounding sequence as k_lsrk); res and Qw are distinct arrays: all
+        double ro[HEX_NFLD], qo[HEX_NFLD];   // loads first, then the stores (one round trip instead of ten)
 #pragma unroll
-      for (int c = 0; c < HEX_NFLD; ++c) {
-        const int64_t idx = (int64_t)c * M.K * Nq + e * Nq + lane;
-        const double out = tot[c] * miJ;
-        if (lf.Qw) {   // fused low-storage RK stage (same rounding sequence as k_lsrk)
-          const double r = __builtin_fma(lf.a, lf.res[idx], lf.dt * out);
+        for (int c = 0; c < HEX_NFLD; ++c) { const int64_t idx = (int64_t)c * M.K * Nq + e * Nq + lane; ro[c] = lf.res[idx]; qo[c] = lf.Qw[idx]; }
+#pragma unroll
+        for (int c = 0; c < HEX_NFLD; ++c) {
+          const int64_t idx = (int64_t)c * M.K * Nq + e * Nq + lane;
+          const double r = __builtin_fma(lf.a, ro[c], lf.dt * (tot[c] * miJ));
           lf.res[idx] = r;
-          lf.Qw[idx] = __builtin_fma(lf.b, r, lf.Qw[idx]);
-        } else {
-          rhs[idx] = out;
+          lf.Qw[idx] = __builtin_fma(lf.b, r, qo[c]);
         }
+      } else {
+#pragma unroll
+        for (int c = 0; c < HEX_NFLD; ++c) rhs[(int64_t)c * M.K * Nq + e * Nq + lane] = tot[c] * miJ;
       }
     }
   }

@@ -282,6 +282,31 @@ __device__ __forceinline__ void stage_tables(const TensorTables& TT, double* sTa
   for (int i = threadIdx.x; i < L.NINT; i += (int)blockDim.x) sInt[i] = TT.ints[i];
 }
 
+// The same copy in two halves for kernels that have other loads in flight: load() issues every table load into registers
+// without waiting (all lanes, index clamped: lanes beyond the table re-read its last entry), store() writes them to LDS
+// (duplicate lanes write the same value to the same slot).  The strided copy above -- like any LDS store under
+// `if (lane < n)` -- makes hipcc put each load next to its store and wait for it with vmcnt(0), i.e. for every load the
+// wave has in flight, once per round of the copy (tools/asm_waits.sh shows the waits of a kernel).
+template <int N1, int TPB>
+struct TableRegs {
+  static constexpr TensorLayout L = TensorLayout(N1);
+  static constexpr int ND = (L.NDBL + TPB - 1) / TPB, NI = (L.NINT + TPB - 1) / TPB;
+  double d[ND];
+  int i[NI];
+  __device__ __forceinline__ void load(const TensorTables& TT) {
+#pragma unroll
+    for (int r = 0; r < ND; ++r) d[r] = TT.dbl[min((int)threadIdx.x + r * TPB, L.NDBL - 1)];
+#pragma unroll
+    for (int r = 0; r < NI; ++r) i[r] = TT.ints[min((int)threadIdx.x + r * TPB, L.NINT - 1)];
+  }
+  __device__ __forceinline__ void store(double* sTab, int* sInt) const {
+#pragma unroll
+    for (int r = 0; r < ND; ++r) sTab[min((int)threadIdx.x + r * TPB, L.NDBL - 1)] = d[r];
+#pragma unroll
+    for (int r = 0; r < NI; ++r) sInt[min((int)threadIdx.x + r * TPB, L.NINT - 1)] = i[r];
+  }
+};
+
 template <int N1>
 __device__ __forceinline__ void issue_state_loads(const double* __restrict__ Q, int64_t K, int64_t e0, bool active,
                                                   int tid, double* x) {
@@ -324,6 +349,45 @@ __device__ __forceinline__ void state_at_quad(const LN& ln, const double* sTab, 
   }
   __syncthreads();
   // stage 2: Uq[a + N1 b] = sum_j IQ[a,j] W[b + N1 j]   (this lane: a = lo, b = hi)
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const double* src = sB + (ev * 4 + f) * Nq + hi;
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < N1; ++j) s += c[j] * src[N1 * j];
+    U[f] = s;
+  }
+}
+
+// The same for kt_project, whose state loads are issued at entry: EVERY lane stages its x (slot sl: its own, or for the few
+// lanes beyond the group's volume slots that of lane tid - E*Nq, whose data they loaded too -- a duplicate write).  With the
+// store under `if (ln.vin)` hipcc sinks the global loads into that branch, below the table barrier.
+template <int N1, bool MODAL, class LN>
+__device__ __forceinline__ void state_at_quad_dup(const LN& ln, const double* sTab, double* sA, double* sB, const double* x,
+                                                  int sl_e, int sl_q, double* U) {
+  constexpr int Nq = N1 * N1;
+  constexpr TensorLayout L(N1);
+  if (!MODAL) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) U[f] = x[f];
+    return;
+  }
+  const int lo = ln.a, hi = ln.b, ev = ln.ev, q = ln.q;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) sA[(sl_e * 4 + f) * Nq + sl_q] = x[f];
+  double c[N1];
+#pragma unroll
+  for (int i = 0; i < N1; ++i) c[i] = sTab[L.IQ + lo * N1 + i];
+  __syncthreads();
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const double* src = sA + (ev * 4 + f) * Nq + N1 * hi;
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < N1; ++i) s += c[i] * src[i];
+    if (ln.vin) sB[(ev * 4 + f) * Nq + q] = s;
+  }
+  __syncthreads();
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
     const double* src = sB + (ev * 4 + f) * Nq + hi;
@@ -418,17 +482,36 @@ __global__ __launch_bounds__(WgP<N1>::TPB) void kt_project(TensorTables TT, Mesh
   const Lane<N1, W::GW> ln;
   double* sA = sA_ + ln.grp * (E * 4 * Nq);
   double* sB = sB_ + ln.grp * (E * 4 * Nq);
-  stage_tables<N1>(TT, sTab, sInt);
-  __syncthreads();
   const int64_t e0 = M.e_begin + ((int64_t)blockIdx.x * W::NG + ln.grp) * E;
   const int nE = (int)max((int64_t)0, min((int64_t)E, M.e_begin + M.e_count - e0));
   const bool vactive = ln.tid < nE * Nq, factive = ln.tid < nE * Nfq;
-  const int64_t e0s = min(e0, M.e_begin + M.e_count - 1);   // in-range base for the geometry reads of idle lanes / idle groups
+  const int64_t e0s = min(e0, M.e_begin + M.e_count - 1);   // in-range base for the reads of idle lanes / idle groups
 
+  // All global loads of the kernel are issued here, unconditionally and before anything is waited for: tables, state,
+  // and the face lanes' normals (used only after the projection; loaded at the point of use they cost the wave a third
+  // serial memory round trip after tables -> barrier -> state).  Idle lanes read node 0 / face 0 of an in-range element.
+  TableRegs<N1, W::TPB> tr;
+  tr.load(TT);
   double x[4];
-  issue_state_loads<N1>(Q, M.K, ESDG_EW(e0), vactive, ln.tid, x);
+  const int ta = ln.vin ? ln.tid : ln.tid - E * Nq;   // lanes beyond the group's E*Nq volume slots duplicate lane tid - E*Nq
+  const int sl_e = ta / Nq, sl_q = ta - sl_e * Nq;
+  {
+    const bool va = ta < nE * Nq;                      // (slots of elements beyond the mesh: node 0 of an in-range element)
+    const int64_t eb = ESDG_EW(va ? e0 : e0s);
+    const int tq = va ? ta : 0;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) x[f] = Q[(int64_t)f * M.K * Nq + eb * Nq + tq];
+  }
+  double gnf[3];
+  {
+    const double* g = M.fnrm + (ESDG_EW(factive ? e0 + ln.ef : e0s) * Nfq + (factive ? ln.fn : 0)) * 3;   // this node's (nxJ, nyJ, sJ)
+    gnf[0] = g[0]; gnf[1] = g[1]; gnf[2] = g[2];
+  }
+  __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise moves the state loads below the barrier, next to their first use)
+  tr.store(sTab, sInt);
+  __syncthreads();
   double U[4];
-  state_at_quad<N1, MODAL>(ln, sTab, sA, sB, x, U);
+  state_at_quad_dup<N1, MODAL>(ln, sTab, sA, sB, x, sl_e, sl_q, U);
   double qh[6], V[4];
   prim_logs<MODAL>(U, qh);
   v_of_prim<MODAL>(qh, V);
@@ -452,8 +535,7 @@ __global__ __launch_bounds__(WgP<N1>::TPB) void kt_project(TensorTables TT, Mesh
     double Uf[4], qf[6];
     u_of_v<MODAL>(Vf, Uf);
     prim_logs<MODAL>(Uf, qf);
-    const double* g = M.geo + (ESDG_EW(e0) + ln.ef) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
-    const double lam = lf_lambda<MODAL>(Uf, g[0], g[1], g[2]);
+    const double lam = lf_lambda<MODAL>(Uf, gnf[0], gnf[1], gnf[2]);
     const int64_t n = (ESDG_EW(e0) + ln.ef) * Nfq + ln.fn;
     double2* a = reinterpret_cast<double2*>(A_U + n * FAU_NC);
     double2* a2 = reinterpret_cast<double2*>(A_U + (M.trace_nodes + n) * FAU_NC);
@@ -545,9 +627,9 @@ __device__ __forceinline__ void visc_face_jumps(const LN& ln, const double* sTab
 // volume lanes: BR1 gradient of (v2,v3,v4) at the node and sigma = K(v) grad v
 template <int N1, class LN>
 __device__ __forceinline__ void visc_sigma(const LN& ln, const double* sTab, const int* sInt,
-                                           const TensorTables& TT, const Phys& ph, const double* g,
+                                           const TensorTables& TT, const Phys& ph, const double* g, const double* fn3e,
                                            const double* sVn, const double* sDv, double* sgx, double* sgy,
-                                           double* gradx = nullptr, double* grady = nullptr) {
+                                           double* gradx = nullptr, double* grady = nullptr) {   // fn3e: MeshDev::fnrm of the element
   constexpr int Nq = N1 * N1, Nfq = 4 * N1;
   constexpr TensorLayout L(N1);
   double tx[3] = {0, 0, 0}, ty[3] = {0, 0, 0};
@@ -572,7 +654,7 @@ __device__ __forceinline__ void visc_sigma(const LN& ln, const double* sTab, con
     for (int t = 0; t < 2; ++t) {
       const int f = sInt[L.FN + (d * 2 + t) * N1 + oth];
       const double lw = sTab[L.PF + (d * 2 + t) * N1 + pos] * sTab[L.PTF + (d * 2 + t) * N1 + oth] * sTab[L.WFAC + f];
-      const double* gn = g + 5 + 3 * (f / N1);
+      const double* gn = fn3e + 3 * f;   // the face node's own normal (the reference multiplies the jump by nxJ per node)
       const double lx = lw * gn[0], ly = lw * gn[1];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -672,13 +754,14 @@ __global__ __launch_bounds__(WgS<N1>::TPB) void kt_sigma(TensorTables TT, MeshDe
     const int64_t nn = (e0 + (factive ? ln.ef : 0)) * Nfq + ln.fn;
     const int bc = (M.bc && factive) ? M.bc[nn] : 0;
     const double vlid = (bc == 2 && M.vlid) ? M.vlid[nn] : 1.0;
-    visc_face_jumps<N1>(ln, sTab, sInt, sA, vP, bc, vlid, M.geo + (e0s + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1), ph, sDv, nullptr);
+    visc_face_jumps<N1>(ln, sTab, sInt, sA, vP, bc, vlid, M.fnrm + ((e0s + (factive ? ln.ef : 0)) * Nfq + ln.fn) * 3, ph, sDv, nullptr);
   }
   __syncthreads();
   double vt = 0.0;
   if (ln.vin) {
     double sgx[3], sgy[3], gx[3], gy[3];
-    visc_sigma<N1>(ln, sTab, sInt, TT, ph, M.geo + (e0s + (vactive ? ln.ev : 0)) * GEO_STRIDE, sA, sDv, sgx, sgy,
+    visc_sigma<N1>(ln, sTab, sInt, TT, ph, M.geo + (e0s + (vactive ? ln.ev : 0)) * GEO_STRIDE,
+                   M.fnrm + (e0s + (vactive ? ln.ev : 0)) * Nfq * 3, sA, sDv, sgx, sgy,
                    DIAG ? gx : nullptr, DIAG ? gy : nullptr);
     double2* r = reinterpret_cast<double2*>(sB + (ln.ev * Nq + ln.q) * 6);
     r[0] = make_double2(sgx[0], sgx[1]);
@@ -721,7 +804,7 @@ __global__ __launch_bounds__(WgS<N1>::TPB) void kt_sigma(TensorTables TT, MeshDe
     }
   }
   if (factive) {
-    const double* gn = M.geo + (e0 + ln.ef) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
+    const double* gn = M.fnrm + ((e0 + ln.ef) * Nfq + ln.fn) * 3;
     double sn[3], fx[3], fy[3];
     face_normal_stress<N1>(ln, sTab, sInt, sB, gn[0], gn[1], sn, fx, fy);
     double* bb = B + ((e0 + ln.ef) * Nfq + ln.fn) * B_NC;
@@ -866,7 +949,7 @@ __global__ __launch_bounds__((WgR<N1, VISC>::TPB)) void kt_rhs(TensorTables TT, 
     dq[0] = make_double2(qM[0], qM[1]);
     dq[1] = make_double2(qM[2], qM[3]);
     dq[2] = make_double2(qM[4], qM[5]);
-    const double* gn = M.geo + (e0s + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
+    const double* gn = M.fnrm + ((e0s + (factive ? ln.ef : 0)) * Nfq + ln.fn) * 3;
     if (VISC && ph.viscous_dissp) {
       // penalty tau*[[v]] (:817-837): own and neighbour projected entropy variables are the entropy variables of the
       // two trace states (see kt_project), so no interpolation of nodal values is needed here
@@ -1052,7 +1135,7 @@ __global__ __launch_bounds__((WgR<N1, VISC>::TPB)) void kt_rhs(TensorTables TT, 
     // stress jumps .5*((sxP-sxf)*nxJ + (syP-syf)*nyJ): the neighbour's normal stress from B carries
     // its own outward normal = minus ours (dg_div! :606)
     if (ln.fin) {
-      const double* gn = M.geo + (e0s + (factive ? ln.ef : 0)) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
+      const double* gn = M.fnrm + ((e0s + (factive ? ln.ef : 0)) * Nfq + ln.fn) * 3;
       double sn[3], fx[3] = {0, 0, 0}, fy[3] = {0, 0, 0}, sj[3];
       if (WALLS) {
         face_normal_stress<N1>(ln, sTab, sInt, sS, gn[0], gn[1], sn, fx, fy);

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
   // the half jumps (pair + single, face nodes) and the geometry records of the group's elements.
   constexpr int NVP = NV + (NV & 1), NFP = NF + (NF & 1);   // single planes padded to an even length: pair planes stay 16-B aligned
   constexpr int NGEO = E * GEO_STRIDE, GPT = (NGEO + G::GT - 1) / G::GT;   // geometry doubles of a group / per thread
-  constexpr int R0 = 0, R1 = 8 * NV, RV = R1 + 2 * NV + 2 * NVP, RD = RV + 2 * NV + NVP, RG = RD + 2 * NF + NFP,
+  constexpr int R0 = 0, R1 = 8 * NV, RV = R1 + 2 * NV + 2 * NVP, RD = RV + 2 * NV + NVP, RG = RD + 6 * NF,
                 NLDS = RG + GPT * G::GT;
   __shared__ __align__(16) double lds[NLDS];
   d2* sSg = reinterpret_cast<d2*>(lds + R0);          // [3][NV] sigma pairs
@@ -248,10 +248,12 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
   double* sS12 = lds + R1 + 2 * NV + NVP;             // [NV] S^1_2
   d2* sVp = reinterpret_cast<d2*>(lds + RV);          // [NV] (v2, v3)
   double* sV4 = lds + RV + 2 * NV;                    // [NV] v4
-  d2* sDp = reinterpret_cast<d2*>(lds + RD);          // [NF] half jumps of (v2, v3)
-  double* sD4 = lds + RD + 2 * NF;                    // [NF] half jump of v4
+  // half jumps times the face node's own normal (the reference multiplies per node, dg_grad! :560-566), three pair planes:
+  d2* sDx = reinterpret_cast<d2*>(lds + RD);          // [NF] nxJ * half jump of (v2, v3)
+  d2* sD4 = reinterpret_cast<d2*>(lds + RD + 2 * NF); // [NF] (nxJ, nyJ) * half jump of v4
+  d2* sDy = reinterpret_cast<d2*>(lds + RD + 4 * NF); // [NF] nyJ * half jump of (v2, v3)
   double* sGeo = lds + RG;
-  static_assert((R1 % 2) == 0 && (RV % 2) == 0 && (RD % 2) == 0, "pair planes must be 16-byte aligned");
+  static_assert((R1 % 2) == 0 && (RV % 2) == 0 && (RD % 2) == 0 && (RG % 2) == 0, "pair planes must be 16-byte aligned");
 
 #ifdef ESDG_T2_POISON   // diagnostic build: LDS starts as NaN, so a read of a slot nobody wrote shows in the result
   for (int i = threadIdx.x; i < NLDS; i += G::GT) lds[i] = __builtin_nan("");
@@ -280,7 +282,6 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
 #pragma unroll
   for (int k = 0; k < 4; ++k) { lw[k] = nd_[(NL.LW + k) * Nq]; fq[k] = ev * Nfq + ni_[(NL.FQ + k) * Nq]; }
   const unsigned fnode0 = ef * Nq + fi_[(FL.NODE0) * Nfq], fstride = fi_[(FL.STRIDE) * Nfq];
-  const unsigned gfo = 5 + 3 * (fn / N1);
 
   const int64_t e_end = M.e_begin + M.e_count;
   // FULL: ceil(e_count / E) groups, the last one shifted back so that it is complete too: it recomputes up to E - 1
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
   // after their last use (x and the geometry are written to LDS first thing; the neighbour traces are consumed by the
   // face-jump stage), so that every load has most of an iteration to land and no copy ever waits for one.
   int64_t grp = FULL ? (int64_t)blockIdx.x : nfull;
-  double x[4], geo[GPT];
+  double x[4], geo[GPT], nrn[3];   // nrn: this lane's face-node normal (nxJ, nyJ, sJ; MeshDev::fnrm), prefetched like the rest
   d2 up0, up1;
   {
     const int64_t e0 = FULL ? min(M.e_begin + grp * E, e_last) : M.e_begin;
@@ -307,6 +308,8 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
     for (int i = 0; i < GPT; ++i) { const unsigned n = tid + i * G::GT; geo[i] = M.geo[ESDG_EW(e0) * GEO_STRIDE + (n < (unsigned)(nE * GEO_STRIDE) ? n : 0u)]; }
     const d2* up = reinterpret_cast<const d2*>(A_U + (size_t)mp * FAU_NC);
     up0 = up[0]; up1 = up[1];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) nrn[c] = M.fnrm[(ESDG_EW(e0) * Nfq + tfl) * 3 + c];
   }
 
   T2_STAMP_INIT;
@@ -340,6 +343,9 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
     // unsigned: a sign-extending load would put its shift, and with it the wait for the load, right here
     const unsigned mpn = ESDG_EWN((unsigned)M.mapP[ESDG_EW(e0n) * Nfq + tfn], Nfq);
     __builtin_amdgcn_sched_barrier(0);
+    const double nr[3] = {nrn[0], nrn[1], nrn[2]};   // this group's normals; the registers take the next group's
+#pragma unroll
+    for (int c = 0; c < 3; ++c) nrn[c] = M.fnrm[(ESDG_EW(e0n) * Nfq + tfn) * 3 + c];
 #pragma unroll
     for (int f = 0; f < 4; ++f) x[f] = Q[f * KN + ESDG_EW(e0n) * Nq + tvn];
 #pragma unroll
@@ -385,10 +391,12 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
       }
       if (WALLS && bcf) {
         const double vfo[3] = {vf0, vf1, vf2};
-        wall_exterior_v(vfo, bcf, vlid, sGeo + ef * GEO_STRIDE + gfo, ph, vP);
+        wall_exterior_v(vfo, bcf, vlid, nr, ph, vP);
       }
-      sDp[tf] = make_double2(.5 * (vP[0] - vf0), .5 * (vP[1] - vf1));     // (duplicate lanes: duplicate writes)
-      sD4[tf] = .5 * (vP[2] - vf2);
+      const double h0 = .5 * (vP[0] - vf0), h1 = .5 * (vP[1] - vf1), h2 = .5 * (vP[2] - vf2);
+      sDx[tf] = make_double2(nr[0] * h0, nr[0] * h1);     // (duplicate lanes: duplicate writes)
+      sD4[tf] = make_double2(nr[0] * h2, nr[1] * h2);
+      sDy[tf] = make_double2(nr[1] * h0, nr[1] * h1);
     }
     __syncthreads();
     T2_STAMP(4);
@@ -418,14 +426,11 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
         ty[c] = __builtin_fma(gy1, d1[c], gy0 * d0[c]);
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {   // lift of the half jumps on the four faces at the ends of this node's lines
-        const double* gn = g + 5 + 3 * TT.gface[k];
-        const double lx = lw[k] * gn[0], ly = lw[k] * gn[1];
-        const d2 dj = sDp[fq[k]];
-        const double dj2 = sD4[fq[k]];
-        tx[0] = __builtin_fma(lx, dj.x, tx[0]); ty[0] = __builtin_fma(ly, dj.x, ty[0]);
-        tx[1] = __builtin_fma(lx, dj.y, tx[1]); ty[1] = __builtin_fma(ly, dj.y, ty[1]);
-        tx[2] = __builtin_fma(lx, dj2, tx[2]); ty[2] = __builtin_fma(ly, dj2, ty[2]);
+      for (int k = 0; k < 4; ++k) {   // lift of the (normal x half jump)s on the four faces at the ends of this node's lines
+        const d2 jx = sDx[fq[k]], j4 = sD4[fq[k]], jy = sDy[fq[k]];
+        tx[0] = __builtin_fma(lw[k], jx.x, tx[0]); ty[0] = __builtin_fma(lw[k], jy.x, ty[0]);
+        tx[1] = __builtin_fma(lw[k], jx.y, tx[1]); ty[1] = __builtin_fma(lw[k], jy.y, ty[1]);
+        tx[2] = __builtin_fma(lw[k], j4.x, tx[2]); ty[2] = __builtin_fma(lw[k], j4.y, ty[2]);
       }
       const double iJ = rcp_refined(g[4]);
 #pragma unroll
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
     T2_STAMP(6);
     // ---- face lanes: own normal stress (Ef*sigma_x)*nxJ + (Ef*sigma_y)*nyJ -> B ----------------------------------------
     {
-      const double* gn = sGeo + ef * GEO_STRIDE + gfo;
+      const double* gn = nr;
       const double nx = gn[0], ny = gn[1];
       d2 p0 = sSg[fnode0], p1 = sSg[NV + fnode0], p2 = sSg[2 * NV + fnode0];
       double fx0 = ee[0] * p0.x, fx1 = ee[0] * p0.y, fx2 = ee[0] * p1.x, fy0 = ee[0] * p1.y, fy1 = ee[0] * p2.x, fy2 = ee[0] * p2.y;
@@ -699,6 +704,7 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
     bcf = M.bc[nf];
     if (M.vlid) vlid = M.vlid[nf];
   }
+  double gn[3];   // this lane's face-node normal (nxJ, nyJ, sJ) as the driver holds it (MeshDev::fnrm)
 #pragma unroll
   for (int f = 0; f < 4; ++f) x[f] = Q[f * KN + e0 * Nq + tvl];
 #pragma unroll
@@ -738,8 +744,9 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
     fnode0 = ef * Nq + (wf & 255u); fstride = (wf >> 8) & 255u;
     fdir = (int)(wf >> 17); ad = (N1 % 2 == 0) ? wi.w : 0;
   }
-  const unsigned gfo = 5 + 3 * (fn / N1);
   const int opf = fdir ? TT.op1 : TT.op0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) gn[c] = M.fnrm[nf * 3 + c];
 
     T2_STAMP(9);     // loads that need no neighbour index issued
 #ifdef ESDG_T2_STAMP
@@ -861,7 +868,6 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
     const double* gf = sGeo + ef * GEO_STRIDE;     // (slots of elements beyond the mesh hold the clamped loads: finite, unused)
     double Gf[4], pnr[3] = {0, 0, 0};
     {
-      const double* gn = gf + gfo;
       if (VISC) {   // penalty tau*[[v]] (:817-837): the projected entropy variables are those OF the trace states
         const double bM = 2 * Gas2<MODAL>::GM1 * qM[3], bP = 2 * Gas2<MODAL>::GM1 * qP[3];
         const double tau = ph.viscous_dissp ? -rcp_refined(-bM) * ph.inv_Re : 0.0;
@@ -1070,13 +1076,15 @@ static void launch_sigma2w(const TensorTables& TT, const MeshDev& M, const Phys&
     // Ranged launches (sharded schedule): the interior leaves a few slots free and the boundary strips ask for no more
     // than those, so that a strip never takes the slot of an interior workgroup, which would start late and still do its
     // full static share (ESDG_T2_RESERVE: slots, default 64; 0 = off)
-    if (M.e_count != M.K) {
+    // (the schedule says which launch is which -- MeshDev::launch_role; any other ranged launch, e.g. the pieces of
+    // esdg_rhs_phase_range, gets the full grid)
+    if (M.launch_role) {
       static int reserve = -1;
       if (reserve < 0) { const char* env = getenv("ESDG_T2_RESERVE"); reserve = env ? atoi(env) : 64; }
       if (reserve > 0) {
         const int cap = t2::persistent_grid<t2::kt2_sigma<N1, true, WALLS>>(G::GT, (int64_t)1 << 40);
-        if (nfull >= cap) nb = cap - reserve > 0 ? cap - reserve : nb;   // interior
-        else if (nb > reserve) nb = reserve;                           // strip
+        if (M.launch_role == 1) { if (nb > cap - reserve && cap - reserve > 0) nb = cap - reserve; }   // interior
+        else if (nb > reserve) nb = reserve;                                                            // strip
       }
     }
     hipLaunchKernelGGL((t2::kt2_sigma<N1, true, WALLS>), dim3(nb), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);

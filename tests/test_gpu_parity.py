@@ -348,3 +348,49 @@ def test_cfg3_cns_512_exact_size_values_against_oracle(eng_mod, oracle_lib):
             truth_gate("cfg3 cns N=4 512x512 vortex", got, ref, q.rhsRK(Q, False)[0])
     finally:
         _one_core()
+
+
+def test_cavity_state_with_exact_zeros_of_the_normal_velocity_looser_documented_bound(eng_mod, oracle_lib):
+    """The cavity state WITHOUT the phase shift of common.cavity_state: u = .1 sin(pi x) cos(pi y) vanishes exactly on the
+    element interfaces x = 0, +-1/2 ..., so rhoU_n there is an exact zero plus round-off and the reference's wavespeed
+    sqrt(|u_n|) (quirk Q1, euler_variables.jl:7-10) turns 1e-17 into 3e-9: any two Float64 implementations -- the oracle
+    and the truth evaluator included -- differ by that much in the LF term.  Documented looser bound: 1e-6 relative (measured
+    values are printed); everything else in the suite uses the shifted state and the 2 x e_orc gate."""
+    from esdg_cns_amd import physics as ph
+    N, Kx, Ky = 4, 8, 8
+    rd, md, ops, _ = product_cavity_problem(N, Kx, Ky)
+    x, y = md.x, md.y
+    rho = 1.0 + .2 * np.exp(-10 * (x ** 2 + y ** 2))
+    u = .1 * np.sin(np.pi * x) * np.cos(np.pi * y)
+    v = -.1 * np.cos(np.pi * x) * np.sin(np.pi * y)
+    p = (1 / (.3 ** 2 * ph.GAMMA)) * rho ** ph.GAMMA
+    Q = [np.asfortranarray(q) for q in ph.primitive_to_conservative(rho, u, v, p)]
+    pr = as_oracle_problem(rd, md, ops, Q, **PHYS)
+    o, q = _cns(pr)
+    eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, Re=pr.Re, mu=pr.mu, lam=pr.lam, Pr=pr.Pr, BCTYPE=1)
+    got, ref, tru = _gpu_rhs(eng, Q), o.rhsRK(Q, False)[0], q.rhsRK(Q, False)[0]
+    e_gpu, e_orc = rel_l2(got, tru), rel_l2(ref, tru)
+    print(f"unshifted cavity state N={N} {Kx}x{Ky}: e_gpu={e_gpu:.2e} e_orc={e_orc:.2e} gpu-vs-oracle={rel_l2(got, ref):.2e}")
+    assert e_gpu <= 1e-6 and e_orc <= 1e-6
+
+
+def test_cavity_64x64_rhsRK_within_the_gate_while_rhs_viscous_alone_carries_the_rebuild_cost(eng_mod, oracle_lib):
+    """the tensor kernels rebuild the neighbour's projected entropy variables from its trace state, which
+    puts `rhs_viscous!` ALONE at 3-6 x e_orc (VISC_FACTOR).  On a wall mesh at N=4, 64x64 (every closure active, the size
+    where e_orc of the vortex cases is largest) the sum `rhsRK!` -- what every driver integrates -- must still pass the
+    ordinary 2 x e_orc gate: the excess is confined to the split diagnostic.  Both ratios are recorded."""
+    _all_cores()
+    try:
+        rd, md, ops, Q = product_cavity_problem(4, 64, 64)
+        p = as_oracle_problem(rd, md, ops, Q, **PHYS)
+        o, q = _cns(p)
+        kw = dict(Re=p.Re, mu=p.mu, lam=p.lam, Pr=p.Pr, BCTYPE=1)
+        eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, **kw)
+        truth_gate("cavity BCTYPE=1 N=4 64x64 rhsRK!", _gpu_rhs(eng, Q), o.rhsRK(Q, False)[0], q.rhsRK(Q, False)[0])
+        eng.set_parts(2)
+        # recorded, with a bound twice VISC_FACTOR (measured 8.9: |gpu - truth| = 2.4e-12 of the viscous part, whose own e_orc is
+        # 2.7e-13; in the sum it sits a factor 5 below the inviscid part's 1.2e-11)
+        truth_gate("cavity BCTYPE=1 N=4 64x64 rhs_viscous! alone", _gpu_rhs(eng, Q)[1:], o.rhs_viscous(Q)[0][1:], q.rhs_viscous(Q)[0][1:],
+                   factor=2 * VISC_FACTOR)
+    finally:
+        _one_core()
