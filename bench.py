@@ -198,8 +198,9 @@ def parse_args(argv=None):
     ap.add_argument("--kz-per-gpu", type=int, default=16, help="element layers per GPU (weak scaling, hex)")
     ap.add_argument("--lf", type=float, default=0.0, help="hex: LF factor (the reference has 0*.25)")
     ap.add_argument("--hex-curve", type=float, default=0.0, help="hex: amplitude a of the script's curved mapping (0 = affine)")
-    ap.add_argument("--hex-per-node", action="store_true", help="hex: pass the metric arrays at all hybrid nodes (with "
-                    "ESDG_HEX_PER_NODE=1 the library then uses every node's own values on affine meshes too)")
+    ap.add_argument("--hex-geometry", choices=["per-node", "element"], default="per-node",
+                    help="hex: per-node = the metric arrays at all hybrid nodes, as the reference script holds them (the library "
+                         "then reproduces its per-node use: geometry mode 2 of kh_rhs); element = one row per element (mode 0)")
     ap.add_argument("--formulation", choices=["cns", "euler", "hex"], default="cns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the process group (nccl = RCCL; gloo only to "
@@ -266,7 +267,7 @@ def run(args):
         Kz_total = args.kz_per_gpu * world
         rank_offsets = np.array([Kx * Kx * args.kz_per_gpu * r for r in range(world + 1)], dtype=np.int64)   # z-slabs
         e0, e1 = int(rank_offsets[rank]), int(rank_offsets[rank + 1])
-        rd, md, ops, Q = build_hex_problem(N, Kx, Kx, Kz_total, e0, e1, args.hex_curve, args.hex_per_node)
+        rd, md, ops, Q = build_hex_problem(N, Kx, Kx, Kz_total, e0, e1, args.hex_curve, args.hex_geometry == "per-node")
         eng = engine.RhsEngine(rd, md, ops, engine.EULER_HEX_COLLOCATED, lf_scale=args.lf, rank=rank, nranks=world,
                                rank_offsets=rank_offsets)
         K_total = Kx * Kx * Kz_total
@@ -448,7 +449,8 @@ def run(args):
             del eng
             torch.cuda.empty_cache()
             if hexw:
-                rd1, md1, ops1, Q1 = build_hex_problem(N, Kx, Kx, args.kz_per_gpu, 0, Kx * Kx * args.kz_per_gpu, args.hex_curve)
+                rd1, md1, ops1, Q1 = build_hex_problem(N, Kx, Kx, args.kz_per_gpu, 0, Kx * Kx * args.kz_per_gpu, args.hex_curve,
+                                                          args.hex_geometry == "per-node")
                 e1 = engine.RhsEngine(rd1, md1, ops1, engine.EULER_HEX_COLLOCATED, lf_scale=args.lf)
             else:
                 rd1, md1, ops1, Q1 = build_problem(N, Kx, kyr, 0, Kx * kyr, args.formulation)
@@ -466,7 +468,8 @@ def run(args):
             print(f"bench.py: weak-scaling base run failed: {type(e).__name__}: {e}", file=sys.stderr)
 
     if hexw:
-        workload = f"euler3d_hex_N{N}_{Kx}x{Kx}x{Kz_total}_periodic_box_lf{args.lf:g}" + (f"_curved{args.hex_curve:g}" if args.hex_curve else "")
+        workload = (f"euler3d_hex_N{N}_{Kx}x{Kx}x{Kz_total}_periodic_box_lf{args.lf:g}" + (f"_curved{args.hex_curve:g}" if args.hex_curve else "")
+                    + ("" if args.hex_geometry == "per-node" else "_element_geometry"))
         metric = f"element-DOF updates/sec (RHS evals/s) at N={N}, 3D hex Euler"
     else:
         workload = (f"{args.formulation}2d_N{N}_{Kx}x{Ky_total}_quads_periodic_vortex"

@@ -566,8 +566,8 @@ struct esdg_ctx {
   int Np = 0, Nq = 0, Nfq = 0;
   // device storage
   DevBuf d_pair_ij, d_pair_c, d_inc_ptr, d_inc, d_Ef_i, d_Ef_v, d_Ph_i, d_Ph_v, d_Lf_i, d_Lf_v, d_Dr_i, d_Dr_v, d_Ds_i,
-      d_Ds_v, d_Vq, d_Pq, d_geo, d_fnrm, d_mapP, d_bc, d_vlid, d_wJq, d_sendlist, d_partial;
-  DevBuf t_dbl, t_int, d_G9, d_Jq, d_nrm;
+      d_Ds_v, d_Vq, d_Pq, d_geo, d_fnrm, d_fnd, d_fsd, d_mapP, d_bc, d_vlid, d_wJq, d_sendlist, d_partial;
+  DevBuf t_dbl, t_int, d_G9, d_Jq, d_nrm, d_hdv, d_hdf, d_hdn;
   DevBuf t_nd, t_ni, t_fd, t_fi;   // per-node rows of the v2 tensor kernels
   DevBuf t_rvd, t_rvi, t_rfd, t_rfi;   // packed rows of kt2_rhs (RhsRows)
   DevBuf e_Vq2, e_wq2, e_x, e_y, e_J, e_Vf, e_wf;   // error functionals (esdg_error_setup)
@@ -947,6 +947,27 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
     std::vector<double> fn3((size_t)K * Nfq * 3);
     for (size_t n = 0; n < (size_t)K * Nfq; ++n) { fn3[3 * n] = mesh->nxJ[n]; fn3[3 * n + 1] = mesh->nyJ[n]; fn3[3 * n + 2] = mesh->sJ[n]; }
     UP(d_fnrm, fn3);
+    // ... and as float differences to the face means of the record (MeshDev::fnd / fsd), exact by construction: verified
+    std::vector<float> fnd((size_t)K * Nfq * 2), fsd((size_t)K * Nfq);
+    for (int64_t e = 0; e < K; ++e)
+      for (int f = 0; f < 4; ++f) {
+        const double* gm = &geo[(size_t)e * GEO_STRIDE + 5 + 3 * f];
+        for (int i = 0; i < N1; ++i) {
+          const size_t n = (size_t)e * Nfq + (size_t)f * N1 + i;
+          const double v[3] = {mesh->nxJ[n], mesh->nyJ[n], mesh->sJ[n]};
+          float d[3];
+          for (int c3 = 0; c3 < 3; ++c3) {
+            d[c3] = (float)(v[c3] - gm[c3]);
+            // (the component that carries the face comes back bit for bit; one that is zero up to round-off, e.g. nyJ on a
+            // vertical face, loses what lies 2^-24 below its own round-off.  Bound: 1e-19 of the face's sJ -- a thousandth of
+            // an ulp of the normal's length -- or the float rounding of the difference itself)
+            if (std::fabs((gm[c3] + (double)d[c3]) - v[c3]) > std::max(1e-19 * std::fabs(gm[2]), 2.4e-7 * std::fabs(v[c3] - gm[c3])))
+              return fail(ESDG_ERR_STRUCTURE, "element %lld face %d: node normals are not representable as mean + float difference", (long long)e, f);
+          }
+          fnd[2 * n] = d[0]; fnd[2 * n + 1] = d[1]; fsd[n] = d[2];
+        }
+      }
+    UP(d_fnd, fnd); UP(d_fsd, fsd);
   }
   // wall-boundary flags per local face node: 1 wall, 2 lid (init_BC_funs, cavity :135-155)
   std::vector<uint8_t> bcflag;
@@ -1046,7 +1067,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   T.Vq = c->d_Vq.as<double>(); T.Pq = c->d_Pq.as<double>();
   c->M.K = K; c->M.e_begin = 0; c->M.e_count = K;
   c->M.geo = c->d_geo.as<double>(); c->M.mapP = c->d_mapP.as<int32_t>(); c->M.bc = bcflag.empty() ? nullptr : c->d_bc.as<uint8_t>();
-  c->M.fnrm = c->d_fnrm.as<double>();
+  c->M.fnrm = c->d_fnrm.as<double>(); c->M.fnd = c->d_fnd.as<float>(); c->M.fsd = c->d_fsd.as<float>();
   c->M.vlid = vlid.empty() ? nullptr : c->d_vlid.as<double>();
   set_interior(c, pl.mapP, K, Nfq);
   if (use_fast) detect_structured(c->M, pl.mapP, K, 4, N1, false);
@@ -1192,6 +1213,49 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
     }
   }
 
+  // Affine mesh, per-node arrays passed (geo_ld = Nh): geometry mode 2 of kh_rhs -- every node's difference to the element
+  // record as signed bytes in units of one scale per element (metrics: largest |difference| of any of the 9 rows at any
+  // hybrid node / 127; normals likewise over the 6 faces), so the reference's per-node use is reproduced to 1/254 of the
+  // amplitude of those differences.  ESDG_HEX_GEOMETRY=element keeps the plain element record (mode 0).
+  std::vector<uint32_t> hdv, hdf, hdn;
+  {
+    const char* env = getenv("ESDG_HEX_GEOMETRY");
+    const bool element_only = env && env[0] == 'e';
+    if (!curved && ld == Nh && !element_only) {
+      hdv.assign((size_t)K * 3 * Nq, 0u); hdf.assign((size_t)K * Nfq, 0u); hdn.assign((size_t)K * Nfq, 0u);
+      const double* nsrc[3] = {mesh->nxJ, mesh->nyJ, mesh->nzJ};
+      auto q8 = [](double d, double inv) { const double r = std::nearbyint(d * inv); return (uint32_t)(uint8_t)(int8_t)std::max(-127.0, std::min(127.0, r)); };
+      for (int64_t e = 0; e < K; ++e) {
+        double* g = &geo[(size_t)e * HEX_GEO_STRIDE];
+        double mG = 0.0, mN = 0.0;
+        for (int m = 0; m < 9; ++m)
+          for (int i = 0; i < Nh; ++i) mG = std::max(mG, std::fabs(gsrc[m][(size_t)e * Nh + i] - g[m]));
+        for (int f = 0; f < 6; ++f)
+          for (int i = 0; i < NN; ++i)
+            for (int c3 = 0; c3 < 3; ++c3) mN = std::max(mN, std::fabs(nsrc[c3][(size_t)e * Nfq + f * NN + i] - g[10 + 4 * f + c3]));
+        const double sG = mG / 127.0, sN = mN / 127.0, iG = sG > 0 ? 1.0 / sG : 0.0, iN = sN > 0 ? 1.0 / sN : 0.0;
+        g[34] = sG; g[35] = sN;
+        for (int o3 = 0; o3 < 3; ++o3)        // operator o3: Cartesian components are the rows o3, 3 + o3, 6 + o3
+          for (int i = 0; i < Nq; ++i) {
+            uint32_t w = 0;
+            for (int c3 = 0; c3 < 3; ++c3) w |= q8(gsrc[3 * c3 + o3][(size_t)e * Nh + i] - g[3 * c3 + o3], iG) << (8 * c3);
+            hdv[((size_t)e * 3 + o3) * Nq + i] = w;
+          }
+        for (int f = 0; f < Nfq; ++f) {
+          const int code = hh.ints[HexLayout(N1).FINV + f];
+          const int o3 = hh.op[code & 3];   // operator of the face node's line direction
+          uint32_t w = 0, wn = 0;
+          for (int c3 = 0; c3 < 3; ++c3) {
+            w |= q8(gsrc[3 * c3 + o3][(size_t)e * Nh + Nq + f] - g[3 * c3 + o3], iG) << (8 * c3);
+            wn |= q8(nsrc[c3][(size_t)e * Nfq + f] - g[10 + 4 * (f / NN) + c3], iN) << (8 * c3);
+          }
+          hdf[(size_t)e * Nfq + f] = w;
+          hdn[(size_t)e * Nfq + f] = wn;
+        }
+      }
+    }
+  }
+
   // ---- mapP -> local int32 with ghost slots; halo plan -----------------------------------------
   esdg_halo_plan pl;
   {
@@ -1211,6 +1275,7 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
   UP(d_geo, geo); UP(d_mapP, pl.mapP); UP(d_sendlist, pl.sendlist);
   UP(t_dbl, hh.dbl); UP(t_int, hh.ints);
   if (curved) { UP(d_G9, G9); UP(d_Jq, Jq); UP(d_nrm, nrm); }
+  if (!hdv.empty()) { UP(d_hdv, hdv); UP(d_hdf, hdf); UP(d_hdn, hdn); }
   if (mesh->wJq) {
     std::vector<double> w(mesh->wJq, mesh->wJq + (size_t)K * Nq);
     UP(d_wJq, w);
@@ -1225,6 +1290,9 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
   c->M.G9 = curved ? c->d_G9.as<double>() : nullptr;
   c->M.Jq = curved ? c->d_Jq.as<double>() : nullptr;
   c->M.nrm = curved ? c->d_nrm.as<double>() : nullptr;
+  c->M.hdv = hdv.empty() ? nullptr : c->d_hdv.as<uint32_t>();
+  c->M.hdf = hdv.empty() ? nullptr : c->d_hdf.as<uint32_t>();
+  c->M.hdn = hdv.empty() ? nullptr : c->d_hdn.as<uint32_t>();
   set_interior(c, pl.mapP, K, Nfq);
   detect_structured(c->M, pl.mapP, K, 6, N1, true);
   c->M.wJq = mesh->wJq ? c->d_wJq.as<double>() : nullptr;

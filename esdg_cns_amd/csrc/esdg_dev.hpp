@@ -77,12 +77,26 @@ struct MeshDev {
                            // uses them per node: replacing them by the face mean moves the RHS by 1e-10 ... 4e-10 relative on
                            // 128^2 ... 256^2 meshes, several times the Float64 reference's own rounding error (round 3,
                            // tools/parity_scaling.py).  The geometry record keeps the means for code that needs a face constant.
+  // The same per-node normals for the v2 tensor kernels, as single-precision DIFFERENCES to the face means of the geometry
+  // record: fnd[K][Nfq][2] = (nxJ, nyJ) - mean, fsd[K][Nfq] = sJ - mean (read by the wall instantiations only).  On an affine
+  // face a node's value differs from the mean by some thousand ulps at most, so mean + (double)(float)(v - mean) == v bit for
+  // bit (checked at esdg_create) -- a third of the bytes of fnrm.  Where only a quantity that is itself a small jump is
+  // scaled by the normal (LF wavespeed and penalty: sJ, lambda) the kernels use the mean.
+  const float* fnd;
+  const float* fsd;
   const double* wJq;       // [K][Nq] (diagnostics) may be null
   // curved (non-affine) hexahedra only, null otherwise: per-node metric terms [K][9][Nh] (row m9 = comp*3 + operator:
   // rxJ sxJ txJ ryJ syJ tyJ rzJ szJ tzJ), J at the quadrature nodes [K][Nq], normals [K][4][Nfq] = nxJ nyJ nzJ sJ
   const double* G9;
   const double* Jq;
   const double* nrm;
+  // affine hexahedra whose driver passed per-node arrays (geometry mode 2 of kh_rhs), null otherwise: each node's difference to
+  // the element record, three signed bytes (x, y, z) per word, in units of the record's scales [34] / [35]:
+  // hdv[K][3 operators][Nq] metric rows at the volume nodes, hdf[K][Nfq] the row of its own direction at every face node
+  // (hybrid node Nq + f), hdn[K][Nfq] normals (nxJ, nyJ, nzJ) minus the face means
+  const uint32_t* hdv;
+  const uint32_t* hdf;
+  const uint32_t* hdn;
   // Structured-neighbour guess (esdg_api.hip: detect_structured): on most faces of a structured mesh the partner of face
   // node (e, f, i) is (e + spec_eoff[f], face of, node i or its mirror) -- one byte per face in spec_code (bits 0-2: of,
   // bit 3: first index reversed, bit 4: second index reversed, bit 5: indices swapped (hex faces only)), bit 63: valid.

@@ -44,7 +44,9 @@ struct HexTables {
 //   [0..8]  rxJ sxJ txJ ryJ syJ tyJ rzJ szJ tzJ   (first row of the driver's metric arrays)
 //   [9]     J at the quadrature nodes (dg3D_euler_hex.jl:94)
 //   [10+4f .. 13+4f]  nxJ nyJ nzJ sJ of face f
-constexpr int HEX_GEO_STRIDE = 34;
+//   [34] scale of the packed per-node metric differences, [35] scale of the packed per-node normal differences (geometry
+//        mode 2 of kh_rhs, MeshDev::hdv / hdf / hdn; 0 otherwise)
+constexpr int HEX_GEO_STRIDE = 36;
 constexpr int HEX_NFLD = 5;
 constexpr int HEX_AU_NC = 5;  // face trace record: (rho, u, v, w, beta)
 

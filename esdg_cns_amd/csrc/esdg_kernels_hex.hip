@@ -242,9 +242,28 @@ __global__ __launch_bounds__(HW * HNWV) void kh_project(HexTables HT, MeshDev M,
 }
 
 // ---- phase 1 -----------------------------------------------------------------------------------------------
-// CURVED: per-node metric terms / normals / J (M.G9, M.nrm, M.Jq) and the reference's per-pair metric average
-// .5 (G_i + G_j) (dg3D_euler_hex.jl:145-151) instead of one affine record per element
-template <int N1, bool CURVED>
+// Geometry mode GM:
+//   1 (curved meshes): per-node metric terms / normals / J (M.G9, M.nrm, M.Jq) and the reference's per-pair metric average
+//     .5 (G_i + G_j) (dg3D_euler_hex.jl:145-151);
+//   0: one affine record per element (means of what the driver passed) -- what a driver that passes one metric row per
+//     element (geo_ld = 1) gets, or ESDG_HEX_GEOMETRY=element asks for;
+//   2 (affine meshes whose driver passed per-node arrays, the default there): the same per-node use as mode 1 from the
+//     element record plus each node's DIFFERENCE to it, 8 bits per number (M.hdv / hdf / hdn, scales in the record).  The
+//     per-node arrays of an affine mesh are constants plus the round-off of the driver's set-up (1e-13 ... 1e-12 relative),
+//     and the reference's per-node use turns that into 2.5 x (16^3) ... 3.8 x (24^3) ... its own rounding error in the RHS
+//     (tools/hex_geometry_probe.py); mode 0 filters it out, mode 1 costs 10.4 KB more traffic per element (kh_rhs 1.17 ->
+//     1.69 ms at 128x128x16), mode 2 reproduces it to 1/254 of its amplitude for 1.5 KB.
+template <int N1, int GM> struct HexGeo { static constexpr bool CURVED = GM == 1, DELTA = GM == 2; };
+
+// (x, y, z) differences of one node packed as three signed bytes; g = base + scale * (k_i + k_j) averages a pair when scale
+// carries the factor 1/2
+__device__ __forceinline__ void unpack3(unsigned p, int& a, int& b, int& c) {
+  a = (int)(p << 24) >> 24;
+  b = (int)(p << 16) >> 24;
+  c = (int)(p << 8) >> 24;
+}
+
+template <int N1, int GM>
 __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phys ph, int remap,
                                                      const double* __restrict__ Q, const double* __restrict__ A_U,
                                                      double* __restrict__ rhs, LsrkFuse lf) {
@@ -256,7 +275,9 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
   __shared__ double sPs[HNWV][7 * HW];
   __shared__ double sAccs[HNWV][HEX_NFLD * HW];
   __shared__ double sGs[HNWV][HEX_NFLD * Nfq];
+  constexpr bool CURVED = HexGeo<N1, GM>::CURVED, DELTA = HexGeo<N1, GM>::DELTA;
   __shared__ double sMs[CURVED ? HNWV : 1][CURVED ? 9 * HW : 1];   // metric terms of the volume nodes, [c*3 + op][slot]
+  __shared__ unsigned sDs[DELTA ? HNWV : 1][DELTA ? 3 * HW : 1];   // packed metric differences of the volume nodes, [op][slot]
   const int64_t nblk = (M.e_count + HNWV - 1) / HNWV;
   const int64_t blk = block_of(nblk, remap != 0);
   if (blk < 0) return;
@@ -270,6 +291,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
   double* sG = sGs[wv];
   const double* geo = sGeo[wv];
   double* sM = sMs[CURVED ? wv : 0];
+  unsigned* sD = sDs[DELTA ? wv : 0];
   constexpr int Nh = Nq + Nfq;
 
   // ---- issue the global loads ---------------------------------------------------------------------
@@ -296,6 +318,14 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
   for (int c = 0; c < HEX_AU_NC; ++c) rm[c] = A_U[nm0 * HEX_AU_NC + c];
 #pragma unroll
   for (int c = 0; c < HEX_AU_NC; ++c) rp[c] = A_U[np0 * HEX_AU_NC + c];
+  unsigned kv[3] = {0u, 0u, 0u}, kf0 = 0u, kn0 = 0u;   // DELTA: this node's packed metric differences per operator; face round 0's
+  if (DELTA) {
+    const int lu = vin ? lane : 0;
+#pragma unroll
+    for (int o3 = 0; o3 < 3; ++o3) kv[o3] = M.hdv[(ec * 3 + o3) * Nq + lu];
+    kf0 = M.hdf[nm0];
+    kn0 = M.hdn[nm0];
+  }
   sGeo[wv][gl] = geo_r;
   tr.store(sTab, sInt);
 #pragma unroll
@@ -305,8 +335,13 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
 #pragma unroll
     for (int m9 = 0; m9 < 9; ++m9) sM[m9 * HW + myslot] = M.G9[(ec * 9 + m9) * Nh + lane];
   }
+  if (DELTA) {
+#pragma unroll
+    for (int o3 = 0; o3 < 3; ++o3) sD[o3 * HW + myslot] = kv[o3];
+  }
 
   // ---- pointwise: primitives + logs ------------------------------------------------------------------
+  double hsG = 0.0, sNs = 0.0;   // DELTA: half the scale of the packed metric differences, scale of the packed normal differences
   double acc[HEX_NFLD] = {0.0, 0.0, 0.0, 0.0, 0.0};
   const int lq = vin ? lane : 0;
   const int i0 = lq % N1, i1 = (lq / N1) % N1, i2 = lq / NN;
@@ -316,6 +351,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
 #pragma unroll
     for (int c = 0; c < 7; ++c) sP[c * HW + myslot] = qv[c];
     __syncthreads();
+    if (DELTA) { hsG = .5 * geo[HEX_GEO_STRIDE - 2]; sNs = geo[HEX_GEO_STRIDE - 1]; }
 
     // ---- volume lanes: circulant line schedule, each unordered pair once -------------------------------
     // full rounds: lane at position i of a line takes the pair (i, i+m mod N1), m = 1..(N1-1)/2
@@ -343,6 +379,12 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
             W *= .5;
             ec_flux_dir(qv, qn, sM[opd * HW + myslot] + sM[opd * HW + ns], sM[(3 + opd) * HW + myslot] + sM[(3 + opd) * HW + ns],
                         sM[(6 + opd) * HW + myslot] + sM[(6 + opd) * HW + ns], F);
+          } else if (DELTA) {   // the same average: record + half the scale times the two nodes' differences
+            int a0, a1, a2, b0, b1, b2;
+            unpack3(opd == 0 ? kv[0] : (opd == 1 ? kv[1] : kv[2]), a0, a1, a2);
+            unpack3(sD[opd * HW + ns], b0, b1, b2);
+            ec_flux_dir(qv, qn, __builtin_fma(hsG, (double)(a0 + b0), gx), __builtin_fma(hsG, (double)(a1 + b1), gy),
+                        __builtin_fma(hsG, (double)(a2 + b2), gz), F);
           } else {
             ec_flux_dir(qv, qn, gx, gy, gz, F);
           }
@@ -385,6 +427,12 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
           W *= .5;
           ec_flux_dir(qv, qn, sM[opd * HW + myslot] + sM[opd * HW + ns], sM[(3 + opd) * HW + myslot] + sM[(3 + opd) * HW + ns],
                       sM[(6 + opd) * HW + myslot] + sM[(6 + opd) * HW + ns], F);
+        } else if (DELTA) {
+          int a0, a1, a2, b0, b1, b2;
+          unpack3(opd == 0 ? kv[0] : (opd == 1 ? kv[1] : kv[2]), a0, a1, a2);
+          unpack3(sD[opd * HW + ns], b0, b1, b2);
+          ec_flux_dir(qv, qn, __builtin_fma(hsG, (double)(a0 + b0), gx), __builtin_fma(hsG, (double)(a1 + b1), gy),
+                      __builtin_fma(hsG, (double)(a2 + b2), gz), F);
         } else {
           ec_flux_dir(qv, qn, gx, gy, gz, F);
         }
@@ -412,6 +460,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
       qm[c] = rm[c];
       qp[c] = rp[c];
     }
+    const unsigned kf = kf0, kn = kn0;
     if (it + 1 < NIT) {   // prefetch the next round
       const int f2 = f + HW;
       const int fc2 = f2 < Nfq ? f2 : Nfq - 1;
@@ -422,6 +471,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
         rm[c] = A_U[nm * HEX_AU_NC + c];
         rp[c] = A_U[np * HEX_AU_NC + c];
       }
+      if (DELTA) { kf0 = M.hdf[nm]; kn0 = M.hdn[nm]; }
     }
     qm[5] = log_pos(qm[0]);
     qm[6] = log_pos(qm[4]);
@@ -432,6 +482,11 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
     if (CURVED) {
       const double* nr = M.nrm + ec * 4 * Nfq + fc;
       nx = nr[0]; ny = nr[Nfq]; nz = nr[2 * Nfq]; sJ = nr[3 * Nfq];
+    }
+    if (DELTA) {   // this node's own normal = face mean + scale * packed difference (sJ: the mean; it only scales the LF term)
+      int a0, a1, a2;
+      unpack3(kn, a0, a1, a2);
+      nx = __builtin_fma(sNs, (double)a0, nx); ny = __builtin_fma(sNs, (double)a1, ny); nz = __builtin_fma(sNs, (double)a2, nz);
     }
     double G[HEX_NFLD];
     ec_flux_dir(qm, qp, nx, ny, nz, G);
@@ -458,6 +513,8 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
       const double* gm = M.G9 + (ec * 9 + opd) * Nh + Nq + fc;
       gx = gm[0]; gy = gm[3 * Nh]; gz = gm[6 * Nh];
     }
+    int f0 = 0, f1 = 0, f2d = 0;
+    if (DELTA) unpack3(kf, f0, f1, f2d);   // this face node's metric differences of direction d
     const double wtf = sTab[L.WTF + (d * 2 + t) * NN + o];
     int ii = t ? (N1 + 1) / 2 : 0;
 #pragma unroll 1
@@ -471,6 +528,11 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
       if (CURVED) {
         W *= .5;
         ec_flux_dir(qn, qm, gx + sM[opd * HW + ns], gy + sM[(3 + opd) * HW + ns], gz + sM[(6 + opd) * HW + ns], F);
+      } else if (DELTA) {
+        int b0, b1, b2;
+        unpack3(sD[opd * HW + ns], b0, b1, b2);
+        ec_flux_dir(qn, qm, __builtin_fma(hsG, (double)(f0 + b0), gx), __builtin_fma(hsG, (double)(f1 + b1), gy),
+                    __builtin_fma(hsG, (double)(f2d + b2), gz), F);
       } else {
         ec_flux_dir(qn, qm, gx, gy, gz, F);
       }
@@ -584,9 +646,11 @@ int launch_rhs_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phys& p
   if (M.e_count <= 0) return 0;
   const int remap = (ph.dbg & 16) ? 0 : 1;
   if (M.G9) {
-    ESDG_HEX_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_rhs<N1, true>), dim3(hex_grid(M.e_count, remap)), dim3(hdev::HW * hdev::HNWV), 0, s, HT, M, ph, remap, Q, A_U, rhs, lf));
+    ESDG_HEX_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_rhs<N1, 1>), dim3(hex_grid(M.e_count, remap)), dim3(hdev::HW * hdev::HNWV), 0, s, HT, M, ph, remap, Q, A_U, rhs, lf));
+  } else if (M.hdv) {
+    ESDG_HEX_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_rhs<N1, 2>), dim3(hex_grid(M.e_count, remap)), dim3(hdev::HW * hdev::HNWV), 0, s, HT, M, ph, remap, Q, A_U, rhs, lf));
   } else {
-    ESDG_HEX_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_rhs<N1, false>), dim3(hex_grid(M.e_count, remap)), dim3(hdev::HW * hdev::HNWV), 0, s, HT, M, ph, remap, Q, A_U, rhs, lf));
+    ESDG_HEX_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_rhs<N1, 0>), dim3(hex_grid(M.e_count, remap)), dim3(hdev::HW * hdev::HNWV), 0, s, HT, M, ph, remap, Q, A_U, rhs, lf));
   }
   return (int)hipGetLastError();
 }

@@ -504,7 +504,9 @@ __global__ __launch_bounds__(WgP<N1>::TPB) void kt_project(TensorTables TT, Mesh
   }
   double gnf[3];
   {
-    const double* g = M.fnrm + (ESDG_EW(factive ? e0 + ln.ef : e0s) * Nfq + (factive ? ln.fn : 0)) * 3;   // this node's (nxJ, nyJ, sJ)
+    // (the face means of the record: the wavespeed only scales the LF term, itself a small jump -- the 1e-13 by which a node's
+    // own normal differs from the mean is not amplified there, unlike in the central flux of the last phase)
+    const double* g = M.geo + ESDG_EW(factive ? e0 + ln.ef : e0s) * GEO_STRIDE + 5 + 3 * ((factive ? ln.fn : 0) / N1);
     gnf[0] = g[0]; gnf[1] = g[1]; gnf[2] = g[2];
   }
   __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise moves the state loads below the barrier, next to their first use)

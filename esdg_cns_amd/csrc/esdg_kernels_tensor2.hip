@@ -295,7 +295,9 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
   // after their last use (x and the geometry are written to LDS first thing; the neighbour traces are consumed by the
   // face-jump stage), so that every load has most of an iteration to land and no copy ever waits for one.
   int64_t grp = FULL ? (int64_t)blockIdx.x : nfull;
-  double x[4], geo[GPT], nrn[3];   // nrn: this lane's face-node normal (nxJ, nyJ, sJ; MeshDev::fnrm), prefetched like the rest
+  double x[4], geo[GPT];
+  float2 ndn;        // this lane's face-node normal (nxJ, nyJ) minus the face mean (MeshDev::fnd), prefetched like the rest
+  float sdn = 0.f;   // the same for sJ (wall closures only)
   d2 up0, up1;
   {
     const int64_t e0 = FULL ? min(M.e_begin + grp * E, e_last) : M.e_begin;
@@ -308,9 +310,10 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
     for (int i = 0; i < GPT; ++i) { const unsigned n = tid + i * G::GT; geo[i] = M.geo[ESDG_EW(e0) * GEO_STRIDE + (n < (unsigned)(nE * GEO_STRIDE) ? n : 0u)]; }
     const d2* up = reinterpret_cast<const d2*>(A_U + (size_t)mp * FAU_NC);
     up0 = up[0]; up1 = up[1];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) nrn[c] = M.fnrm[(ESDG_EW(e0) * Nfq + tfl) * 3 + c];
+    ndn = reinterpret_cast<const float2*>(M.fnd)[ESDG_EW(e0) * Nfq + tfl];
+    if (WALLS) sdn = M.fsd[ESDG_EW(e0) * Nfq + tfl];
   }
+  const unsigned gfo = 5 + 3 * (fn / N1);
 
   T2_STAMP_INIT;
 #pragma unroll 1
@@ -343,9 +346,10 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
     // unsigned: a sign-extending load would put its shift, and with it the wait for the load, right here
     const unsigned mpn = ESDG_EWN((unsigned)M.mapP[ESDG_EW(e0n) * Nfq + tfn], Nfq);
     __builtin_amdgcn_sched_barrier(0);
-    const double nr[3] = {nrn[0], nrn[1], nrn[2]};   // this group's normals; the registers take the next group's
-#pragma unroll
-    for (int c = 0; c < 3; ++c) nrn[c] = M.fnrm[(ESDG_EW(e0n) * Nfq + tfn) * 3 + c];
+    const float2 nd = ndn;   // this group's normal differences; the registers take the next group's
+    const float sd = sdn;
+    ndn = reinterpret_cast<const float2*>(M.fnd)[ESDG_EW(e0n) * Nfq + tfn];
+    if (WALLS) sdn = M.fsd[ESDG_EW(e0n) * Nfq + tfn];
 #pragma unroll
     for (int f = 0; f < 4; ++f) x[f] = Q[f * KN + ESDG_EW(e0n) * Nq + tvn];
 #pragma unroll
@@ -370,6 +374,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
     T2_STAMP(3);
 
     // ---- face lanes: projected entropy variables at the face node, half jump to the neighbour's ---------------------
+    double nr[3];
     {
       const double b2 = 2 * GM1 * up1.y;                           // neighbour: (v2,v3,v4) = (b u, b v, -b), b = 2 (gamma-1) beta
       double vP[3] = {b2 * up0.y, b2 * up1.x, -b2};
@@ -389,6 +394,8 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
         vf0 = __builtin_fma(ee[j], p.x, vf0); vf1 = __builtin_fma(ee[j], p.y, vf1);
         vf2 = __builtin_fma(ee[j], sV4[fnode0 + j * fstride], vf2);
       }
+      const double* gm = sGeo + ef * GEO_STRIDE + gfo;   // face means; + this node's difference = its own normal, exactly
+      nr[0] = gm[0] + (double)nd.x; nr[1] = gm[1] + (double)nd.y; nr[2] = WALLS ? gm[2] + (double)sd : gm[2];
       if (WALLS && bcf) {
         const double vfo[3] = {vf0, vf1, vf2};
         wall_exterior_v(vfo, bcf, vlid, nr, ph, vP);
@@ -704,7 +711,9 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
     bcf = M.bc[nf];
     if (M.vlid) vlid = M.vlid[nf];
   }
-  double gn[3];   // this lane's face-node normal (nxJ, nyJ, sJ) as the driver holds it (MeshDev::fnrm)
+  // this lane's face-node normal as the driver holds it = face mean of the record + float difference (MeshDev::fnd / fsd)
+  const float2 nd = reinterpret_cast<const float2*>(M.fnd)[nf];
+  const float sd = WALLS ? M.fsd[nf] : 0.f;
 #pragma unroll
   for (int f = 0; f < 4; ++f) x[f] = Q[f * KN + e0 * Nq + tvl];
 #pragma unroll
@@ -745,8 +754,7 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
     fdir = (int)(wf >> 17); ad = (N1 % 2 == 0) ? wi.w : 0;
   }
   const int opf = fdir ? TT.op1 : TT.op0;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) gn[c] = M.fnrm[nf * 3 + c];
+  const unsigned gfo = 5 + 3 * (fn / N1);
 
     T2_STAMP(9);     // loads that need no neighbour index issued
 #ifdef ESDG_T2_STAMP
@@ -868,6 +876,9 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
     const double* gf = sGeo + ef * GEO_STRIDE;     // (slots of elements beyond the mesh hold the clamped loads: finite, unused)
     double Gf[4], pnr[3] = {0, 0, 0};
     {
+      const double* gm = gf + gfo;
+      // (sJ: the face mean unless a wall closure turns it into a unit normal -- it only scales the LF term, a small jump)
+      const double gn[3] = {gm[0] + (double)nd.x, gm[1] + (double)nd.y, WALLS ? gm[2] + (double)sd : gm[2]};
       if (VISC) {   // penalty tau*[[v]] (:817-837): the projected entropy variables are those OF the trace states
         const double bM = 2 * Gas2<MODAL>::GM1 * qM[3], bP = 2 * Gas2<MODAL>::GM1 * qP[3];
         const double tau = ph.viscous_dissp ? -rcp_refined(-bM) * ph.inv_Re : 0.0;
