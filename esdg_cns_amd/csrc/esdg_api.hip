@@ -1115,7 +1115,7 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
   if (!ops || !mesh || !phys || !out) return fail(ESDG_ERR_ARG, "null argument");
   *out = nullptr;
   const int N1 = ops->N + 1, NN = N1 * N1, Nq = ops->Nq, Nfq = ops->Nfq, Nh = Nq + Nfq;
-  if (!hex_supported_degree(N1)) return fail(ESDG_ERR_ARG, "unsupported hex degree N=%d (need 1..3: one wavefront per element)", ops->N);
+  if (!hex_supported_degree(N1)) return fail(ESDG_ERR_ARG, "unsupported hex degree N=%d (need 1..7)", ops->N);
   if (Nq != NN * N1 || Nfq != 6 * NN)
     return fail(ESDG_ERR_STRUCTURE, "need tensor hex sizes Nq=(N+1)^3, Nfq=6(N+1)^2; got Nq=%d Nfq=%d", Nq, Nfq);
   if (phys->formulation != ESDG_EULER_HEX_COLLOCATED) return fail(ESDG_ERR_ARG, "esdg_create_hex needs formulation ESDG_EULER_HEX_COLLOCATED");
@@ -1214,9 +1214,10 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
   }
 
   // Affine mesh, per-node arrays passed (geo_ld = Nh): geometry mode 2 of kh_rhs -- every node's difference to the element
-  // record as signed bytes in units of one scale per element (metrics: largest |difference| of any of the 9 rows at any
-  // hybrid node / 127; normals likewise over the 6 faces), so the reference's per-node use is reproduced to 1/254 of the
-  // amplitude of those differences.  ESDG_HEX_GEOMETRY=element keeps the plain element record (mode 0).
+  // record as signed 10-bit numbers, three (x, y, z) to a word, in units of one scale per element (metrics: largest
+  // |difference| of any of the 9 rows at any hybrid node / 511; normals likewise over the 6 faces), so the reference's
+  // per-node use is reproduced to 1/1022 of the largest of those differences.  ESDG_HEX_GEOMETRY=element keeps the plain
+  // element record (mode 0).
   std::vector<uint32_t> hdv, hdf, hdn;
   {
     const char* env = getenv("ESDG_HEX_GEOMETRY");
@@ -1224,7 +1225,7 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
     if (!curved && ld == Nh && !element_only) {
       hdv.assign((size_t)K * 3 * Nq, 0u); hdf.assign((size_t)K * Nfq, 0u); hdn.assign((size_t)K * Nfq, 0u);
       const double* nsrc[3] = {mesh->nxJ, mesh->nyJ, mesh->nzJ};
-      auto q8 = [](double d, double inv) { const double r = std::nearbyint(d * inv); return (uint32_t)(uint8_t)(int8_t)std::max(-127.0, std::min(127.0, r)); };
+      auto q8 = [](double d, double inv) { const double r = std::nearbyint(d * inv); return (uint32_t)((int32_t)std::max(-511.0, std::min(511.0, r)) & 1023); };
       for (int64_t e = 0; e < K; ++e) {
         double* g = &geo[(size_t)e * HEX_GEO_STRIDE];
         double mG = 0.0, mN = 0.0;
@@ -1233,12 +1234,12 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
         for (int f = 0; f < 6; ++f)
           for (int i = 0; i < NN; ++i)
             for (int c3 = 0; c3 < 3; ++c3) mN = std::max(mN, std::fabs(nsrc[c3][(size_t)e * Nfq + f * NN + i] - g[10 + 4 * f + c3]));
-        const double sG = mG / 127.0, sN = mN / 127.0, iG = sG > 0 ? 1.0 / sG : 0.0, iN = sN > 0 ? 1.0 / sN : 0.0;
+        const double sG = mG / 511.0, sN = mN / 511.0, iG = sG > 0 ? 1.0 / sG : 0.0, iN = sN > 0 ? 1.0 / sN : 0.0;
         g[34] = sG; g[35] = sN;
         for (int o3 = 0; o3 < 3; ++o3)        // operator o3: Cartesian components are the rows o3, 3 + o3, 6 + o3
           for (int i = 0; i < Nq; ++i) {
             uint32_t w = 0;
-            for (int c3 = 0; c3 < 3; ++c3) w |= q8(gsrc[3 * c3 + o3][(size_t)e * Nh + i] - g[3 * c3 + o3], iG) << (8 * c3);
+            for (int c3 = 0; c3 < 3; ++c3) w |= q8(gsrc[3 * c3 + o3][(size_t)e * Nh + i] - g[3 * c3 + o3], iG) << (10 * c3);
             hdv[((size_t)e * 3 + o3) * Nq + i] = w;
           }
         for (int f = 0; f < Nfq; ++f) {
@@ -1246,8 +1247,8 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
           const int o3 = hh.op[code & 3];   // operator of the face node's line direction
           uint32_t w = 0, wn = 0;
           for (int c3 = 0; c3 < 3; ++c3) {
-            w |= q8(gsrc[3 * c3 + o3][(size_t)e * Nh + Nq + f] - g[3 * c3 + o3], iG) << (8 * c3);
-            wn |= q8(nsrc[c3][(size_t)e * Nfq + f] - g[10 + 4 * (f / NN) + c3], iN) << (8 * c3);
+            w |= q8(gsrc[3 * c3 + o3][(size_t)e * Nh + Nq + f] - g[3 * c3 + o3], iG) << (10 * c3);
+            wn |= q8(nsrc[c3][(size_t)e * Nfq + f] - g[10 + 4 * (f / NN) + c3], iN) << (10 * c3);
           }
           hdf[(size_t)e * Nfq + f] = w;
           hdn[(size_t)e * Nfq + f] = wn;

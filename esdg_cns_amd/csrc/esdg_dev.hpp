@@ -91,7 +91,7 @@ struct MeshDev {
   const double* Jq;
   const double* nrm;
   // affine hexahedra whose driver passed per-node arrays (geometry mode 2 of kh_rhs), null otherwise: each node's difference to
-  // the element record, three signed bytes (x, y, z) per word, in units of the record's scales [34] / [35]:
+  // the element record, three signed 10-bit numbers (x, y, z) per word, in units of the record's scales [34] / [35]:
   // hdv[K][3 operators][Nq] metric rows at the volume nodes, hdf[K][Nfq] the row of its own direction at every face node
   // (hybrid node Nq + f), hdn[K][Nfq] normals (nxJ, nyJ, nzJ) minus the face means
   const uint32_t* hdv;

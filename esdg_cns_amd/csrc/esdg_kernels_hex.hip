@@ -248,19 +248,20 @@ __global__ __launch_bounds__(HW * HNWV) void kh_project(HexTables HT, MeshDev M,
 //   0: one affine record per element (means of what the driver passed) -- what a driver that passes one metric row per
 //     element (geo_ld = 1) gets, or ESDG_HEX_GEOMETRY=element asks for;
 //   2 (affine meshes whose driver passed per-node arrays, the default there): the same per-node use as mode 1 from the
-//     element record plus each node's DIFFERENCE to it, 8 bits per number (M.hdv / hdf / hdn, scales in the record).  The
+//     element record plus each node's DIFFERENCE to it, 10 bits per number (M.hdv / hdf / hdn, scales in the record).  The
 //     per-node arrays of an affine mesh are constants plus the round-off of the driver's set-up (1e-13 ... 1e-12 relative),
 //     and the reference's per-node use turns that into 2.5 x (16^3) ... 3.8 x (24^3) ... its own rounding error in the RHS
 //     (tools/hex_geometry_probe.py); mode 0 filters it out, mode 1 costs 10.4 KB more traffic per element (kh_rhs 1.17 ->
-//     1.69 ms at 128x128x16), mode 2 reproduces it to 1/254 of its amplitude for 1.5 KB.
+//     1.69 ms at 128x128x16), mode 2 reproduces it to 1/1022 of its largest amplitude for 1.5 KB (emulated in the oracle at
+//     16^3: 8 bits move the RHS by 0.33 e_orc, 10 bits by 0.08, 12 by 0.02, 16 by 0.005).
 template <int N1, int GM> struct HexGeo { static constexpr bool CURVED = GM == 1, DELTA = GM == 2; };
 
-// (x, y, z) differences of one node packed as three signed bytes; g = base + scale * (k_i + k_j) averages a pair when scale
-// carries the factor 1/2
+// (x, y, z) differences of one node packed as three signed 10-bit fields of one word (v_bfe_i32 each); g = base + scale *
+// (k_i + k_j) averages a pair when scale carries the factor 1/2
 __device__ __forceinline__ void unpack3(unsigned p, int& a, int& b, int& c) {
-  a = (int)(p << 24) >> 24;
-  b = (int)(p << 16) >> 24;
-  c = (int)(p << 8) >> 24;
+  a = __builtin_amdgcn_sbfe((int)p, 0, 10);
+  b = __builtin_amdgcn_sbfe((int)p, 10, 10);
+  c = __builtin_amdgcn_sbfe((int)p, 20, 10);
 }
 
 template <int N1, int GM>
@@ -590,6 +591,264 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
   }
 }
 
+// =====================================================================================================================
+// Degrees N >= 4 (N1 = 5 ... 8: more than one wavefront of Gauss nodes): one WORKGROUP per element, thread t owns the
+// volume nodes t, t + T, ... and the face nodes t, t + T, ....  Same tables, trace protocol, geometry modes and formulas as
+// kh_project / kh_rhs above (`rhs` and sparse_hadamard_sum of examples/dg3D_euler_hex.jl:122-222 are degree-generic), but
+// ROW-WISE like the reference: every node evaluates all pairs of its own row of the hybridised operators (2 x the fluxes
+// of the pair-once schedule), so nothing is accumulated across lanes -- no LDS atomics, every sum in program order, results
+// bitwise reproducible however the waves of the workgroup are scheduled.  Coverage first: these kernels are not tuned.
+// =====================================================================================================================
+template <int N1> struct GCfg {
+  static constexpr int Nq = N1 * N1 * N1, NN = N1 * N1, Nfq = 6 * NN;
+  static constexpr int T = Nq <= 128 ? 128 : 256;                       // threads per workgroup
+  static constexpr int NPT = (Nq + T - 1) / T, NFT = (Nfq + T - 1) / T; // volume / face nodes per thread
+};
+
+template <int N1>
+__global__ __launch_bounds__(GCfg<N1>::T) void kh_project_g(HexTables HT, MeshDev M, const double* __restrict__ Q, double* __restrict__ A_U) {
+  using C = GCfg<N1>;
+  constexpr HexLayout L(N1);
+  constexpr int Nq = C::Nq, Nfq = C::Nfq, T = C::T;
+  __shared__ double sTab[L.NDBL];
+  __shared__ int sInt[L.NINT];
+  __shared__ double sV[HEX_NFLD * Nq];
+  const int64_t e = M.e_begin + blockIdx.x;
+  if (e >= M.e_begin + M.e_count) return;
+  for (int i = threadIdx.x; i < L.NDBL; i += T) sTab[i] = HT.dbl[i];
+  for (int i = threadIdx.x; i < L.NINT; i += T) sInt[i] = HT.ints[i];
+  for (int n = threadIdx.x; n < Nq; n += T) {
+    double U[HEX_NFLD], q[7], V[HEX_NFLD];
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) U[c] = Q[(int64_t)c * M.K * Nq + e * Nq + n];
+    prim_logs3(U, q);
+    v_of_prim3(q, V);
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) sV[c * Nq + n] = V[c];
+  }
+  __syncthreads();
+  for (int f = threadIdx.x; f < Nfq; f += T) {
+    const int code = sInt[L.FINV + f];
+    const int d = code & 3, t = (code >> 2) & 1, o = code >> 3;
+    int base, stride;
+    line_of<N1>(d, o, base, stride);
+    double Vf[HEX_NFLD] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < N1; ++i) {
+      const double w = sTab[L.EE + (d * 2 + t) * N1 + i];
+#pragma unroll
+      for (int c = 0; c < HEX_NFLD; ++c) Vf[c] += w * sV[c * Nq + base + i * stride];
+    }
+    double qf[HEX_NFLD];
+    prim_of_v3(Vf, qf);
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) A_U[(e * Nfq + f) * HEX_AU_NC + c] = qf[c];
+  }
+}
+
+template <int N1, int GM>
+__global__ __launch_bounds__(GCfg<N1>::T) void kh_rhs_g(HexTables HT, MeshDev M, Phys ph, const double* __restrict__ Q,
+                                                       const double* __restrict__ A_U, double* __restrict__ rhs, LsrkFuse lf) {
+  using C = GCfg<N1>;
+  constexpr HexLayout L(N1);
+  constexpr int Nq = C::Nq, NN = C::NN, Nfq = C::Nfq, T = C::T, Nh = Nq + Nfq;
+  constexpr bool CURVED = GM == 1, DELTA = GM == 2;
+  __shared__ double sTab[L.NDBL];
+  __shared__ int sInt[L.NINT];
+  __shared__ double geo[HEX_GEO_STRIDE];
+  __shared__ double sP[7 * Nq];                        // (rho,u,v,w,beta,log rho,log beta) of the volume nodes
+  __shared__ double sF[7 * Nfq];                       // the same of the own face trace
+  __shared__ double sG[HEX_NFLD * Nfq];                // face totals
+  __shared__ double sM[CURVED ? 9 * Nh : 1];           // curved: metric terms of all hybrid nodes, [c*3 + op][node]
+  __shared__ unsigned sD[DELTA ? 3 * Nq + Nfq : 1];    // packed metric differences: volume nodes [op][node], then face nodes
+  const int64_t e = M.e_begin + blockIdx.x;
+  if (e >= M.e_begin + M.e_count) return;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < L.NDBL; i += T) sTab[i] = HT.dbl[i];
+  for (int i = tid; i < L.NINT; i += T) sInt[i] = HT.ints[i];
+  for (int i = tid; i < HEX_GEO_STRIDE; i += T) geo[i] = M.geo[e * HEX_GEO_STRIDE + i];
+  for (int n = tid; n < Nq; n += T) {
+    double U[HEX_NFLD], q[7];
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) U[c] = Q[(int64_t)c * M.K * Nq + e * Nq + n];
+    prim_logs3(U, q);
+#pragma unroll
+    for (int c = 0; c < 7; ++c) sP[c * Nq + n] = q[c];
+    if (DELTA) {
+#pragma unroll
+      for (int o3 = 0; o3 < 3; ++o3) sD[o3 * Nq + n] = M.hdv[(e * 3 + o3) * Nq + n];
+    }
+  }
+  if (CURVED)
+    for (int i = tid; i < 9 * Nh; i += T) sM[i] = M.G9[e * 9 * Nh + i];
+  for (int f = tid; f < Nfq; f += T) {
+    const int64_t nm = e * Nfq + f;
+    double q[7];
+#pragma unroll
+    for (int c = 0; c < HEX_AU_NC; ++c) q[c] = A_U[nm * HEX_AU_NC + c];
+    q[5] = log_pos(q[0]);
+    q[6] = log_pos(q[4]);
+#pragma unroll
+    for (int c = 0; c < 7; ++c) sF[c * Nfq + f] = q[c];
+    if (DELTA) sD[3 * Nq + f] = M.hdf[nm];
+  }
+  __syncthreads();
+  const double hsG = DELTA ? .5 * geo[HEX_GEO_STRIDE - 2] : 0.0, sNs = DELTA ? geo[HEX_GEO_STRIDE - 1] : 0.0;
+  // metric vector of the pair (hybrid nodes a, b; b >= Nq: face node b - Nq) for operator family op, as the reference
+  // averages it (:145-151); mode 0: the element record
+  auto pair_metric = [&](int op, int a, int b, double* g) {
+    if (CURVED) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) g[c] = .5 * (sM[(3 * c + op) * Nh + a] + sM[(3 * c + op) * Nh + b]);
+    } else if (DELTA) {
+      int a0, a1, a2, b0, b1, b2;
+      unpack3(sD[op * Nq + a], a0, a1, a2);
+      unpack3(b < Nq ? sD[op * Nq + b] : sD[3 * Nq + (b - Nq)], b0, b1, b2);
+      g[0] = __builtin_fma(hsG, (double)(a0 + b0), geo[op]);
+      g[1] = __builtin_fma(hsG, (double)(a1 + b1), geo[3 + op]);
+      g[2] = __builtin_fma(hsG, (double)(a2 + b2), geo[6 + op]);
+    } else {
+      g[0] = geo[op]; g[1] = geo[3 + op]; g[2] = geo[6 + op];
+    }
+  };
+
+  // ---- face nodes: surface flux (:185-198) minus the volume-face pairs of the node's line ----------------------------
+  for (int f = tid; f < Nfq; f += T) {
+    const int64_t nm = e * Nfq + f;
+    const int64_t np = M.mapP[nm];
+    double qm[7], qp[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) qm[c] = sF[c * Nfq + f];
+#pragma unroll
+    for (int c = 0; c < HEX_AU_NC; ++c) qp[c] = A_U[np * HEX_AU_NC + c];
+    qp[5] = log_pos(qp[0]);
+    qp[6] = log_pos(qp[4]);
+    const int face = f / NN;
+    double nx = geo[10 + 4 * face], ny = geo[11 + 4 * face], nz = geo[12 + 4 * face], sJ = geo[13 + 4 * face];
+    if (CURVED) {
+      const double* nr = M.nrm + e * 4 * Nfq + f;
+      nx = nr[0]; ny = nr[Nfq]; nz = nr[2 * Nfq]; sJ = nr[3 * Nfq];
+    }
+    if (DELTA) {
+      int a0, a1, a2;
+      unpack3(M.hdn[nm], a0, a1, a2);
+      nx = __builtin_fma(sNs, (double)a0, nx); ny = __builtin_fma(sNs, (double)a1, ny); nz = __builtin_fma(sNs, (double)a2, nz);
+    }
+    double G[HEX_NFLD];
+    ec_flux_dir(qm, qp, nx, ny, nz, G);
+    if (ph.lf_scale != 0.0) {
+      double UM[HEX_NFLD], UP[HEX_NFLD];
+      const double isJ = rcp_refined(sJ);
+      const double lM = lf_lambda3(qm, nx, ny, nz, isJ, UM);
+      const double lP = lf_lambda3(qp, nx, ny, nz, isJ, UP);
+      const double LFc = ph.lf_scale * fmax(lM, lP) * sJ;
+#pragma unroll
+      for (int c = 0; c < HEX_NFLD; ++c) G[c] -= LFc * (UP[c] - UM[c]);
+    }
+    const double wfac = sTab[L.WFAC + f];
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) G[c] *= wfac;
+    const int code = sInt[L.FINV + f];
+    const int d = code & 3, t = (code >> 2) & 1, o = code >> 3;
+    int base, stride;
+    line_of<N1>(d, o, base, stride);
+    const int opd = d == 0 ? HT.op[0] : (d == 1 ? HT.op[1] : HT.op[2]);
+    const double wtf = sTab[L.WTF + (d * 2 + t) * NN + o];
+    for (int i = 0; i < N1; ++i) {
+      const int node = base + i * stride;
+      double qn[7], F[HEX_NFLD], g[3];
+#pragma unroll
+      for (int c = 0; c < 7; ++c) qn[c] = sP[c * Nq + node];
+      pair_metric(opd, node, Nq + f, g);
+      ec_flux_dir(qn, qm, g[0], g[1], g[2], F);
+      const double W = sTab[L.SF + (d * 2 + t) * N1 + i] * wtf;
+#pragma unroll
+      for (int c = 0; c < HEX_NFLD; ++c) G[c] -= W * F[c];
+    }
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) sG[c * Nfq + f] = G[c];
+  }
+
+  // ---- volume nodes: their own row of the flux differencing (volume and face partners), kept in registers -------------
+  double acc[C::NPT][HEX_NFLD];
+#pragma unroll
+  for (int k = 0; k < C::NPT; ++k) {
+    const int n = tid + k * T;
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) acc[k][c] = 0.0;
+    if (n >= Nq) continue;
+    const int i0 = n % N1, i1 = (n / N1) % N1, i2 = n / NN;
+    double qv[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) qv[c] = sP[c * Nq + n];
+    for (int d = 0; d < 3; ++d) {
+      const int opd = d == 0 ? HT.op[0] : (d == 1 ? HT.op[1] : HT.op[2]);
+      const int id = d == 0 ? i0 : (d == 1 ? i1 : i2);
+      const int o = d == 0 ? i1 + N1 * i2 : (d == 1 ? i0 + N1 * i2 : i0 + N1 * i1);
+      const int stride = d == 0 ? 1 : (d == 1 ? N1 : NN);
+      const double wt = sTab[L.WT + d * NN + o];
+      for (int j = 0; j < N1; ++j) {
+        if (j == id) continue;
+        const int node = n + (j - id) * stride;
+        double qn[7], F[HEX_NFLD], g[3];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) qn[c] = sP[c * Nq + node];
+        pair_metric(opd, n, node, g);
+        ec_flux_dir(qv, qn, g[0], g[1], g[2], F);
+        const double W = sTab[L.S + (d * N1 + id) * N1 + j] * wt;
+#pragma unroll
+        for (int c = 0; c < HEX_NFLD; ++c) acc[k][c] += W * F[c];
+      }
+      for (int t = 0; t < 2; ++t) {   // the two face nodes at the ends of this line
+        const int f = sInt[L.FN + (d * 2 + t) * NN + o];
+        double qf[7], F[HEX_NFLD], g[3];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) qf[c] = sF[c * Nfq + f];
+        pair_metric(opd, n, Nq + f, g);
+        ec_flux_dir(qv, qf, g[0], g[1], g[2], F);
+        const double W = sTab[L.SF + (d * 2 + t) * N1 + id] * sTab[L.WTF + (d * 2 + t) * NN + o];
+#pragma unroll
+        for (int c = 0; c < HEX_NFLD; ++c) acc[k][c] += W * F[c];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- Ph*QF + Lf*flux, -(.)/J (:198-212) ------------------------------------------------------------------------------
+#pragma unroll
+  for (int k = 0; k < C::NPT; ++k) {
+    const int n = tid + k * T;
+    if (n >= Nq) continue;
+    const int i0 = n % N1, i1 = (n / N1) % N1, i2 = n / NN;
+    double tot[HEX_NFLD];
+    const double pd = sTab[L.PD + n];
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) tot[c] = pd * acc[k][c];
+    for (int d = 0; d < 3; ++d) {
+      const int id = d == 0 ? i0 : (d == 1 ? i1 : i2);
+      const int o = d == 0 ? i1 + N1 * i2 : (d == 1 ? i0 + N1 * i2 : i0 + N1 * i1);
+      for (int t = 0; t < 2; ++t) {
+        const int fi = sInt[L.FN + (d * 2 + t) * NN + o];
+        const double w = sTab[L.PF + (d * 2 + t) * N1 + id] * sTab[L.PTF + (d * 2 + t) * NN + o];
+#pragma unroll
+        for (int c = 0; c < HEX_NFLD; ++c) tot[c] += w * sG[c * Nfq + fi];
+      }
+    }
+    const double miJ = -rcp_refined(CURVED ? M.Jq[e * Nq + n] : geo[9]);
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) {
+      const int64_t idx = (int64_t)c * M.K * Nq + e * Nq + n;
+      const double out = tot[c] * miJ;
+      if (lf.Qw) {   // fused low-storage RK stage (same rounding sequence as k_lsrk)
+        const double r = __builtin_fma(lf.a, lf.res[idx], lf.dt * out);
+        lf.res[idx] = r;
+        lf.Qw[idx] = __builtin_fma(lf.b, r, lf.Qw[idx]);
+      } else {
+        rhs[idx] = out;
+      }
+    }
+  }
+}
+
 // rhstest = sum(wJq .* v(Q) .* rhs) (dg3D_euler_hex.jl:214-219): per-block partial sums
 __global__ void kh_rhstest(int64_t n, const double* __restrict__ wJq, const double* __restrict__ Q,
                            const double* __restrict__ rhs, double* __restrict__ partial) {
@@ -617,13 +876,22 @@ __global__ void kh_rhstest(int64_t n, const double* __restrict__ wJq, const doub
 
 }  // namespace hdev
 
-bool hex_supported_degree(int N1) { return N1 >= 2 && N1 <= 4; }
+// N1 = 2 ... 4: one wavefront per element (kh_project / kh_rhs); N1 = 5 ... 8: one workgroup per element (kh_*_g)
+bool hex_supported_degree(int N1) { return N1 >= 2 && N1 <= 8; }
 
 #define ESDG_HEX_DISPATCH(N1v, STMT)   \
   switch (N1v) {                        \
     case 2: { constexpr int N1 = 2; STMT; } break; \
     case 3: { constexpr int N1 = 3; STMT; } break; \
     case 4: { constexpr int N1 = 4; STMT; } break; \
+    default: return (int)hipErrorInvalidValue;     \
+  }
+#define ESDG_HEXG_DISPATCH(N1v, STMT)  \
+  switch (N1v) {                        \
+    case 5: { constexpr int N1 = 5; STMT; } break; \
+    case 6: { constexpr int N1 = 6; STMT; } break; \
+    case 7: { constexpr int N1 = 7; STMT; } break; \
+    case 8: { constexpr int N1 = 8; STMT; } break; \
     default: return (int)hipErrorInvalidValue;     \
   }
 
@@ -637,6 +905,10 @@ int launch_project_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phy
                        hipStream_t s) {
   if (M.e_count <= 0) return 0;
   const int remap = (ph.dbg & 16) ? 0 : 1;
+  if (N1v > 4) {
+    ESDG_HEXG_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_project_g<N1>), dim3((unsigned)M.e_count), dim3(hdev::GCfg<N1>::T), 0, s, HT, M, Q, A_U));
+    return (int)hipGetLastError();
+  }
   ESDG_HEX_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_project<N1>), dim3(hex_grid(M.e_count, remap)), dim3(hdev::HW * hdev::HNWV), 0, s, HT, M, remap, Q, A_U));
   return (int)hipGetLastError();
 }
@@ -645,6 +917,13 @@ int launch_rhs_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phys& p
                    double* rhs, const LsrkFuse& lf, hipStream_t s) {
   if (M.e_count <= 0) return 0;
   const int remap = (ph.dbg & 16) ? 0 : 1;
+  if (N1v > 4) {
+    const dim3 grid((unsigned)M.e_count);
+    if (M.G9) { ESDG_HEXG_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_rhs_g<N1, 1>), grid, dim3(hdev::GCfg<N1>::T), 0, s, HT, M, ph, Q, A_U, rhs, lf)); }
+    else if (M.hdv) { ESDG_HEXG_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_rhs_g<N1, 2>), grid, dim3(hdev::GCfg<N1>::T), 0, s, HT, M, ph, Q, A_U, rhs, lf)); }
+    else { ESDG_HEXG_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_rhs_g<N1, 0>), grid, dim3(hdev::GCfg<N1>::T), 0, s, HT, M, ph, Q, A_U, rhs, lf)); }
+    return (int)hipGetLastError();
+  }
   if (M.G9) {
     ESDG_HEX_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_rhs<N1, 1>), dim3(hex_grid(M.e_count, remap)), dim3(hdev::HW * hdev::HNWV), 0, s, HT, M, ph, remap, Q, A_U, rhs, lf));
   } else if (M.hdv) {

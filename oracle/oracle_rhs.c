@@ -885,7 +885,7 @@ typedef struct {
 static void sparse_hadamard_sum_hex(const oracle_hex_t* c, const real* Qhe /*[5][Nh]*/, const real* ge /*[9][Nh]*/,
                                     real* out /*[5][Nh]*/) {
   const int Nh = c->Nq + c->Nfq;
-  real lrho[512], lbeta[512];
+  real lrho[1024], lbeta[1024];   /* Nh <= 1024: degrees N <= 7 (checked in hex_rhs_r) */
   for (int i = 0; i < Nh; ++i) {
     lrho[i] = R_(log)(Qhe[i]);
     lbeta[i] = R_(log)(Qhe[4 * Nh + i]);
@@ -914,7 +914,7 @@ static void sparse_hadamard_sum_hex(const oracle_hex_t* c, const real* Qhe /*[5]
 static real hex_rhs_r(const oracle_hex_t* c, const real* Q, int compute_rhstest, real* rhs) {
   const int K = c->K, Nq = c->Nq, Nfq = c->Nfq, Nh = Nq + Nfq;
   const size_t KNq = (size_t)K * Nq, KNf = (size_t)K * Nfq, KNh = (size_t)K * Nh;
-  if (Nh > 512) return NAN;
+  if (Nh > 1024) return NAN;
   real* VU = (real*)malloc(5 * KNq * sizeof(real));
   real* VUf = (real*)malloc(5 * KNf * sizeof(real));
   real* Uf = (real*)malloc(5 * KNf * sizeof(real));

@@ -439,3 +439,20 @@ def test_rccl_transport_inside_the_library_loopback(E, form, N, Kx, Kyr):
             E.check(eng.L.esdg_viscous_entropy_test(eng.ctx, C.c_void_p(Qd.data_ptr()), C.byref(v), eng._stream()))
             vt.append(v.value)
         assert vt[0] == vt[1] and vt[0] != 0.0
+
+
+def test_generic_fallback_refuses_wall_meshes_explicitly(E):
+    """The generic pair-list kernels (the fallback when the operators do not factor into 1D tables, or ESDG_FORCE_GENERIC=1)
+    implement the periodic path only: a mesh with wall nodes (init_BC_funs, dg2D_CNS_cavity_optimized.jl:135-265) must be
+    refused at esdg_create with ESDG_ERR_STRUCTURE, never run without its closures."""
+    from common import product_cavity_problem
+    from esdg_cns_amd._lib import EsdgError
+    rd, md, ops, Q = product_cavity_problem(3, 4, 4)
+    os.environ["ESDG_FORCE_GENERIC"] = "1"
+    try:
+        with pytest.raises(EsdgError, match="wall boundary conditions need tensor-structured operators"):
+            E.RhsEngine(rd, md, ops, E.CNS_MODAL, BCTYPE=1)
+    finally:
+        del os.environ["ESDG_FORCE_GENERIC"]
+    eng = E.RhsEngine(rd, md, ops, E.CNS_MODAL, BCTYPE=1)        # the tensor kernels take the same mesh
+    assert eng.L.esdg_uses_tensor_kernels(eng.ctx) == 1

@@ -21,7 +21,8 @@ def _gpu_rhs(eng, Q):
     return eng.download(eng.rhs(eng.upload(Q)))
 
 
-@pytest.mark.parametrize("N,K3", [(3, (4, 4, 4)), (3, (5, 3, 2)), (2, (3, 4, 5)), (1, (4, 3, 3))])
+# (N >= 4: more than one wavefront of Gauss nodes per element -> the degree-generic kernels kh_project_g / kh_rhs_g)
+@pytest.mark.parametrize("N,K3", [(3, (4, 4, 4)), (3, (5, 3, 2)), (2, (3, 4, 5)), (1, (4, 3, 3)), (4, (3, 2, 2)), (5, (2, 2, 3)), (6, (2, 2, 2)), (7, (2, 2, 2))])
 @pytest.mark.parametrize("lf", [0.0, 0.25])
 def test_hex_matches_oracle(eng_mod, oracle_lib, N, K3, lf):
     from oracle import oracle as orc
@@ -278,7 +279,7 @@ def test_hex_per_node_geometry_of_affine_meshes_at_a_size_where_it_matters(eng_m
     """Round 3: the reference uses every node's own metric terms and normals (sparse_hadamard_sum :145-151, rhs :193-198); on an
     affine mesh those arrays are constants plus the set-up's round-off, and the per-node use turns it into a multiple of the
     reference's own rounding error that grows with refinement (element record: 1.08 x e_orc at 8^3, 2.5 x at 16^3, 3.8 x at
-    24^3).  Default on affine meshes whose driver passed per-node arrays: the record plus 8-bit differences (geometry mode 2
+    24^3).  Default on affine meshes whose driver passed per-node arrays: the record plus 10-bit differences (geometry mode 2
     of kh_rhs) -- inside the ordinary 2 x e_orc gate; ESDG_HEX_GEOMETRY=element (mode 0) and ESDG_HEX_PER_NODE=1 (mode 1, the
     kernels of curved meshes) are recorded beside it."""
     import os
@@ -286,11 +287,13 @@ def test_hex_per_node_geometry_of_affine_meshes_at_a_size_where_it_matters(eng_m
     n = len(os.sched_getaffinity(0))
     orc.lib().oracle_set_threads(n); orc.lib_quad().oracle_set_threads(n)
     try:
-        rd, md, ops, Q = product_hex_problem(3, K, K, K)
-        p = as_oracle_problem(rd, md, ops, Q)
+        # (the set-up as the reference performs it, oracle/ref_setup.py: its metric arrays carry more round-off than those of
+        # the product's own set-up, with which the element record is at 1.03 x e_orc at this size)
+        p = orc.build_hex_problem(3, K)
+        rd, md, ops, Q = p.rd, p.md, p.ops, p.Q
         ref, tru = orc.HexOracle(p, 0.0).rhs(Q)[0], orc.HexOracle(p, 0.0, quad=True).rhs(Q)[0]
         eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.EULER_HEX_COLLOCATED, lf_scale=0.0)
-        e2, e_orc = truth_gate(f"hex N=3 {K}^3 smooth (per-node geometry, 8-bit differences)", _gpu_rhs(eng, Q), ref, tru)
+        e2, e_orc = truth_gate(f"hex N=3 {K}^3 smooth (per-node geometry, 10-bit differences)", _gpu_rhs(eng, Q), ref, tru)
         os.environ["ESDG_HEX_PER_NODE"] = "1"
         try:
             e1, _ = truth_gate(f"hex N=3 {K}^3 smooth (per-node geometry, full arrays)", _gpu_rhs(eng_mod.RhsEngine(rd, md, ops, eng_mod.EULER_HEX_COLLOCATED, lf_scale=0.0), Q), ref, tru)
@@ -302,7 +305,7 @@ def test_hex_per_node_geometry_of_affine_meshes_at_a_size_where_it_matters(eng_m
         finally:
             del os.environ["ESDG_HEX_GEOMETRY"]
         print(f"hex N=3 {K}^3: e_orc {e_orc:.2e}; e_gpu mode 2 {e2:.2e}, mode 1 {e1:.2e}, mode 0 (element record) {e0:.2e}")
-        assert e2 <= 1.1 * max(e1, e_orc)      # the 8-bit differences cost at most a few per cent over the full arrays
+        assert e2 <= 1.1 * max(e1, e_orc)      # the 10-bit differences cost at most a few per cent over the full arrays
         assert e0 <= 20 * e_orc                # the element record filters the set-up's round-off: documented deviation
     finally:
         orc.lib().oracle_set_threads(1); orc.lib_quad().oracle_set_threads(1)

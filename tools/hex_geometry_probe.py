@@ -1,5 +1,6 @@
-"""Hex path: e_gpu / e_orc against the binary128 truth with the element-constant geometry record (default on affine meshes)
-and with every node's own metric terms and normals (ESDG_HEX_PER_NODE=1, the kernels of curved meshes), for K^3 boxes.
+"""Hex path: e_gpu / e_orc against the binary128 truth with the element-constant geometry record (ESDG_HEX_GEOMETRY=element),
+with the record plus 10-bit per-node differences (default on affine meshes whose driver passes per-node arrays) and with every
+node's own metric terms and normals in full (ESDG_HEX_PER_NODE=1, the kernels of curved meshes), for K^3 boxes.
     python tools/hex_geometry_probe.py [K ...]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,6 +26,6 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--one":
         one(int(sys.argv[2]), sys.argv[3]); sys.exit(0)
     for K in [int(a) for a in sys.argv[1:]] or [8, 16]:
-        for mode, env in (("element", {}), ("per-node", {"ESDG_HEX_PER_NODE": "1"})):
+        for mode, env in (("element", {"ESDG_HEX_GEOMETRY": "element"}), ("10-bit", {}), ("per-node", {"ESDG_HEX_PER_NODE": "1"})):
             e = dict(os.environ); e.update(env)
             subprocess.call([sys.executable, os.path.abspath(__file__), "--one", str(K), mode], env=e)
