@@ -315,6 +315,17 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
   }
   const unsigned gfo = 5 + 3 * (fn / N1);
 
+  // The stores of a group are issued at the top of the NEXT iteration (ESDG_T2_SIGMA_DEFER_STORES, default on): on gfx9
+  // loads and stores share the vmcnt counter and complete out of order with respect to each other, so the wait for the
+  // prefetched loads at the loop head is a vmcnt(0) that also drains every store issued since -- with the stores at the end
+  // of the iteration that was ~19 % of an iteration (round-2 stamps).  Issued right after that wait, and before the next
+  // prefetch loads, they have a whole iteration to drain.
+#ifndef ESDG_T2_SIGMA_DEFER_STORES
+#define ESDG_T2_SIGMA_DEFER_STORES 1
+#endif
+  double cdv[3] = {0, 0, 0}, csn[3] = {0, 0, 0};
+  int64_t ce0 = 0;
+  bool cva = false, cfa = false;
   T2_STAMP_INIT;
 #pragma unroll 1
   for (; grp < ngrp; grp += gridDim.x) {
@@ -342,6 +353,11 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
     sA[tv] = make_double2(x[0], x[1]);
     sA[NV + tv] = make_double2(x[2], x[3]);
     __builtin_amdgcn_sched_barrier(0);
+    if (ESDG_T2_SIGMA_DEFER_STORES) {   // the previous group's results (none in the first iteration: cva = cfa = false)
+      if (cva) { double* o = SG + ESDG_EW(ce0) * Nq + tv; o[0] = cdv[0]; o[KN] = cdv[1]; o[2 * KN] = cdv[2]; }
+      if (cfa) { double* bb = B + (ESDG_EW(ce0) * Nfq + tf) * B_NC; bb[0] = csn[0]; bb[1] = csn[1]; bb[2] = csn[2]; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // mapP first: it is waited for first (vmcnt counts in issue order), the others may then still be in flight.
     // unsigned: a sign-extending load would put its shift, and with it the wait for the load, right here
     const unsigned mpn = ESDG_EWN((unsigned)M.mapP[ESDG_EW(e0n) * Nfq + tfn], Nfq);
@@ -473,7 +489,9 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
         dv0 = __builtin_fma(dg1[j], p.x, dv0); dv1 = __builtin_fma(dg1[j], p.y, dv1);
         dv2 = __builtin_fma(dg1[j], sS12[colb + N1 * j], dv2);
       }
-      if (vact) {
+      if (ESDG_T2_SIGMA_DEFER_STORES) {
+        cdv[0] = dv0; cdv[1] = dv1; cdv[2] = dv2; cva = vact;
+      } else if (vact) {
         double* o = SG + ESDG_EW(e0) * Nq + tv;
         o[0] = dv0; o[KN] = dv1; o[2 * KN] = dv2;
       }
@@ -499,7 +517,9 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
         wall_stress_jump(sn, fx, fy, bcf, vlid, gn, ph, sj);
         sn[0] = -sj[0]; sn[1] = -sj[1]; sn[2] = -sj[2];
       }
-      if (fact) {
+      if (ESDG_T2_SIGMA_DEFER_STORES) {
+        csn[0] = sn[0]; csn[1] = sn[1]; csn[2] = sn[2]; cfa = fact; ce0 = e0;
+      } else if (fact) {
         double* bb = B + (ESDG_EW(e0) * Nfq + tf) * B_NC;
         bb[0] = sn[0]; bb[1] = sn[1]; bb[2] = sn[2];
       }
@@ -507,6 +527,10 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
     T2_STAMP(7);
     __syncthreads();   // the LDS planes are rewritten by the next iteration
     T2_STAMP(8);
+  }
+  if (ESDG_T2_SIGMA_DEFER_STORES) {   // the last group's results
+    if (cva) { double* o = SG + ESDG_EW(ce0) * Nq + tv; o[0] = cdv[0]; o[KN] = cdv[1]; o[2 * KN] = cdv[2]; }
+    if (cfa) { double* bb = B + (ESDG_EW(ce0) * Nfq + tf) * B_NC; bb[0] = csn[0]; bb[1] = csn[1]; bb[2] = csn[2]; }
   }
   T2_STAMP_FLUSH;
 }
