@@ -450,9 +450,16 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
   }
 
   // ---- face lanes: surface flux (:185-198) and the four volume partners of every face node -----------
+  // SPLIT (N = 3: 96 face nodes = 1.5 rounds): the last round holds at most half a wave of face nodes, so each of them gets
+  // TWO lanes -- lane l and lane l + 32 -- which take half of the node's N1 volume partners each and add their parts of the
+  // face total through a cross-lane swap: 5 + 3 flux evaluations per lane instead of 5 + 5 with half the wave idle.
+  constexpr int REM = Nfq - HW * (NIT - 1);
+  constexpr bool SPLIT = NIT >= 2 && REM <= HW / 2 && N1 >= 2;
 #pragma unroll 1
   for (int it = 0; it < NIT; ++it) {
-    const int f = lane + HW * it;
+    const bool split = SPLIT && it == NIT - 1;                    // uniform
+    const int half = split ? (lane >> 5) : 0;
+    const int f = split ? HW * it + (lane & 31) : lane + HW * it;
     const bool fin = f < Nfq;
     const int fc = fin ? f : Nfq - 1;
     double qm[7], qp[7];
@@ -462,8 +469,8 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
       qp[c] = rp[c];
     }
     const unsigned kf = kf0, kn = kn0;
-    if (it + 1 < NIT) {   // prefetch the next round
-      const int f2 = f + HW;
+    if (it + 1 < NIT) {   // prefetch the next round (the split round: both lanes of a node fetch its records)
+      const int f2 = (SPLIT && it + 1 == NIT - 1) ? HW * (it + 1) + (lane & 31) : f + HW;
       const int fc2 = f2 < Nfq ? f2 : Nfq - 1;
       const int64_t nm = ec * Nfq + fc2;
       const int64_t np = M.mapP[nm];
@@ -517,9 +524,19 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
     int f0 = 0, f1 = 0, f2d = 0;
     if (DELTA) unpack3(kf, f0, f1, f2d);   // this face node's metric differences of direction d
     const double wtf = sTab[L.WTF + (d * 2 + t) * NN + o];
-    int ii = t ? (N1 + 1) / 2 : 0;
+    // walk of the line's nodes: position (start + k) mod N1, k = 0, 1, ... (the two ends of a line start at opposite offsets).
+    // Split round: the first lane of a node takes k = 0 ... N1/2 - 1 upwards, the second k = N1 - 1 ... N1/2 downwards -- in
+    // every step the four (end, lane) combinations of a line are then at four different nodes.
+    if (split && half) {
+#pragma unroll
+      for (int c = 0; c < HEX_NFLD; ++c) G[c] = 0.0;   // the surface term belongs to the first lane's part
+    }
+    const int kstart = t ? (N1 + 1) / 2 : 0, nsteps = split ? N1 / 2 : N1, kstep = (split && half) ? -1 : 1;
+    int k = (split && half) ? N1 - 1 : 0;
 #pragma unroll 1
-    for (int i = 0; i < N1; ++i) {
+    for (int i = 0; i < nsteps; ++i) {
+      int ii = kstart + k;
+      ii = ii >= N1 ? ii - N1 : ii;
       const int node = base + ii * stride;
       double qn[7], F[HEX_NFLD];
       const int ns = slot_of(node);
@@ -543,7 +560,11 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
         G[c] -= wf;
         if (fin) lds_add(&sAcc[c * HW + ns], wf);
       }
-      ii = ii + 1 == N1 ? 0 : ii + 1;
+      k += kstep;
+    }
+    if (split) {   // the two lanes of a node exchange their parts: both hold the face total (a + b, whichever lane adds)
+#pragma unroll
+      for (int c = 0; c < HEX_NFLD; ++c) G[c] += __shfl_xor(G[c], 32);
     }
     if (fin) {
 #pragma unroll

@@ -536,15 +536,34 @@ __global__ __launch_bounds__(WgP<N1>::TPB) void kt_project(TensorTables TT, Mesh
     }
     double Uf[4], qf[6];
     u_of_v<MODAL>(Vf, Uf);
+#ifdef ESDG_EXP_HALF1   // experiment: phase 0 writes the first trace half only (no logs, wavespeed, energy)
+    {
+      constexpr double GM1e = Gas<MODAL>::GM1;
+      const double m2 = Uf[1] * Uf[1] + Uf[2] * Uf[2];
+      const double rre = Uf[0] * Uf[3] - .5 * m2;
+      const double R = rcp_refined(Uf[0] * rre);
+      const double ir = R * rre;
+      qf[0] = Uf[0]; qf[1] = Uf[1] * ir; qf[2] = Uf[2] * ir;
+      qf[3] = (Uf[0] * Uf[0]) * (Uf[0] * R) * (1.0 / (2 * GM1e));
+      qf[4] = 0.0; qf[5] = 0.0;
+    }
+    const double lam = 0.0;
+    (void)gnf;
+#else
     prim_logs<MODAL>(Uf, qf);
     const double lam = lf_lambda<MODAL>(Uf, gnf[0], gnf[1], gnf[2]);
+#endif
     const int64_t n = (ESDG_EW(e0) + ln.ef) * Nfq + ln.fn;
     double2* a = reinterpret_cast<double2*>(A_U + n * FAU_NC);
     double2* a2 = reinterpret_cast<double2*>(A_U + (M.trace_nodes + n) * FAU_NC);
     a[0] = make_double2(qf[0], qf[1]);
     a[1] = make_double2(qf[2], qf[3]);
+#ifndef ESDG_EXP_HALF1
     a2[0] = make_double2(qf[4], qf[5]);
     a2[1] = make_double2(lam, Uf[3]);
+#else
+    (void)a2; (void)lam;
+#endif
   }
   (void)A_v;
 }

@@ -126,7 +126,7 @@ typedef struct {
 /* Hexahedral path: operators of examples/dg3D_euler_hex.jl:34-98 (quadrature basis) and the 3D MeshData
  * fields the driver holds when it calls `rhs` (:167).  Same conventions as above. */
 typedef struct {
-  int32_t N;    /* polynomial degree, 1..3 (one 64-lane wavefront per element) */
+  int32_t N;    /* polynomial degree, 1..7 (N <= 3: one 64-lane wavefront per element; N >= 4: one workgroup per element) */
   int32_t Nq;   /* (N+1)^3 */
   int32_t Nfq;  /* 6 (N+1)^2 */
   const double *Qrhskew, *Qshskew, *Qthskew; /* (Nh x Nh), dg3D_euler_hex.jl:49-51 */
@@ -138,9 +138,13 @@ typedef struct {
 
 typedef struct {
   int64_t K;
-  int32_t geo_ld;  /* rows of the metric arrays: Nh as stored by the driver (:88-90); affine meshes may pass any >= 1
-                    * (row 1 is used).  Curved elements (the `a != 0` mapping, :67-73) are detected at create and need
-                    * all Nh rows: per-node metrics, per-pair averages (:145-151), per-node normals and J are then used */
+  int32_t geo_ld;  /* rows of the metric arrays.  Nh as stored by the driver (:88-90): every node's own metric terms and
+                    * normals are used, averaged per pair as sparse_hadamard_sum does (:145-151) -- on affine meshes from an
+                    * element record plus 10-bit per-node differences (the arrays then are constants plus the set-up's
+                    * round-off, which the reference's per-node use passes on to the RHS), on curved meshes (the `a != 0`
+                    * mapping, :67-73, detected at create) from the full arrays, which need all Nh rows.  Any other value
+                    * >= 1 on an affine mesh says the geometry is element-constant: the mean of the passed rows is used.
+                    * Environment: ESDG_HEX_GEOMETRY=element / ESDG_HEX_PER_NODE=1 force the plain record / the full arrays */
   const double *rxJ, *sxJ, *txJ, *ryJ, *syJ, *tyJ, *rzJ, *szJ, *tzJ; /* (geo_ld x K) */
   const double* J;    /* (Nq x K) = Vq*J, :94 */
   const double* wJq;  /* (Nq x K), diagnostics only, may be NULL */

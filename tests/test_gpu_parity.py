@@ -323,29 +323,33 @@ def test_cfg2_euler_256_exact_size_values_against_oracle_and_truth(eng_mod, orac
 
 def test_cfg3_cns_512_exact_size_values_against_oracle(eng_mod, oracle_lib):
     """BASELINE config 3 (2D CNS, N=4, 512x512, the headline workload) at its exact size: `rhsRK!` of
-    dg2D_CNS_cavity_optimized.jl:955-972, GPU vs the Float64 oracle on all cores.  The binary128 truth runs at 256x256
-    (same state, same gate); at 512x512 the distance to the Float64 oracle must stay below 3 x the e_orc expected there
-    (= twice the e_orc measured at 256x256; |gpu - f64| <= e_gpu + e_orc <= 3 e_orc when the gate holds), unless
-    ESDG_TRUTH_512=1 asks for the binary128 evaluation at the full size as well."""
+    dg2D_CNS_cavity_optimized.jl:955-972, GPU vs the Float64 oracle vs the binary128 truth on identical inputs, all host
+    cores (measured on a GPU box's 16-core share: the truth takes ~100 s; round 3: e_gpu 5.09e-10, e_orc 5.03e-10).
+    ESDG_TRUTH_512=0 runs the truth at 256x256 instead and holds the 512x512 evaluation against the Float64 oracle alone:
+    |gpu - f64| <= 3 x the e_orc expected there (twice the e_orc measured at 256x256; e_gpu + e_orc <= 3 e_orc under the gate)."""
     import os
     _all_cores()
     try:
-        rd, md, ops, Q = product_cns_problem(4, 256, 256)
-        p = as_oracle_problem(rd, md, ops, Q, **PHYS)
-        o, q = _cns(p)
-        eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, Re=p.Re, mu=p.mu, lam=p.lam, Pr=p.Pr)
-        _, e_orc_256 = truth_gate("cns N=4 256x256 vortex", _gpu_rhs(eng, Q), o.rhsRK(Q, False)[0], q.rhsRK(Q, False)[0])
-        del eng, o, q, p
+        full_truth = os.environ.get("ESDG_TRUTH_512", "1") != "0"
+        e_orc_256 = None
+        if not full_truth:
+            rd, md, ops, Q = product_cns_problem(4, 256, 256)
+            p = as_oracle_problem(rd, md, ops, Q, **PHYS)
+            o, q = _cns(p)
+            eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, Re=p.Re, mu=p.mu, lam=p.lam, Pr=p.Pr)
+            _, e_orc_256 = truth_gate("cns N=4 256x256 vortex", _gpu_rhs(eng, Q), o.rhsRK(Q, False)[0], q.rhsRK(Q, False)[0])
+            del eng, o, q, p
         rd, md, ops, Q = product_cns_problem(4, 512, 512)
         p = as_oracle_problem(rd, md, ops, Q, **PHYS)
         o, q = _cns(p)
         eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, Re=p.Re, mu=p.mu, lam=p.lam, Pr=p.Pr)
         got, ref = _gpu_rhs(eng, Q), o.rhsRK(Q, False)[0]
-        d = rel_l2(got, ref)
-        print(f"cfg3 cns N=4 512x512 vortex: gpu-vs-oracle={d:.2e}  (e_orc at 256x256: {e_orc_256:.2e})")
-        assert d <= 3 * 2 * e_orc_256, (d, e_orc_256)
-        if os.environ.get("ESDG_TRUTH_512", "0") == "1":
+        if full_truth:
             truth_gate("cfg3 cns N=4 512x512 vortex", got, ref, q.rhsRK(Q, False)[0])
+        else:
+            d = rel_l2(got, ref)
+            print(f"cfg3 cns N=4 512x512 vortex: gpu-vs-oracle={d:.2e}  (e_orc at 256x256: {e_orc_256:.2e})")
+            assert d <= 3 * 2 * e_orc_256, (d, e_orc_256)
     finally:
         _one_core()
 

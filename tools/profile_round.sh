@@ -10,6 +10,9 @@ EXTRA="${@:2}"   # extra bench.py arguments, e.g. --formulation hex
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
+# the hash of the kernel sources these passes measure (summarize_pmc.py stamps it into pmc_traffic.json; bench.py drops the
+# PMC-derived fields when the sources have changed since)
+python3 -c "import bench; print(bench.kernel_source_hash())" > $OUT/kernel_src_sha.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline $EXTRA > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/write.log 2>&1

@@ -65,7 +65,10 @@ rhs_name = [k for k in out if "_rhs<" in k]
 sys.path.insert(0, root)
 import bench  # noqa: E402
 main = {k: v for k, v in out.items() if any(t in k for t in ("kt_project", "kt_sigma", "kt_rhs", "kt2_sigma", "kt2_rhs", "kh_project", "kh_rhs"))}
-extra = {"kernel_src_sha": bench.kernel_source_hash(),
+# the hash recorded on the GPU box when the passes ran (tools/profile_round.sh); never the hash of whatever the sources are now
+sha_file = os.path.join(src, "kernel_src_sha.txt")
+measured_sha = open(sha_file).read().strip() if os.path.exists(sha_file) else None
+extra = {"kernel_src_sha": measured_sha,
          "whole_rhs_hbm_bytes": sum(v["hbm_bytes_per_launch"] for v in main.values()),
          "whole_rhs_fp64_flops": sum(v.get("fp64_flops", 0.0) for v in main.values()) or None,
          "k_rhs_fp64_flops_per_launch": (rhs[0].get("fp64_flops") if rhs else None)}
