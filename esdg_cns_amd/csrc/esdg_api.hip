@@ -1077,8 +1077,8 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t nodes = (size_t)(K * Nfq + c->nghost);
   size_t off = 0;
-  // A_U: generic kernels one array of 5-double records; tensor kernels two arrays of 4-double records back to back
-  c->off_AU = off; off = align(off + nodes * (use_fast ? 2 * FAU_NC : AU_NC) * sizeof(double));
+  // A_U: generic kernels one array of 5-double records; tensor kernels one array of 4-double records (rho, u, v, beta)
+  c->off_AU = off; off = align(off + nodes * (use_fast ? FAU_NC : AU_NC) * sizeof(double));
   c->M.trace_nodes = (int64_t)nodes;
   const bool need_Av = visc && !use_fast;   // the tensor kernels rebuild the neighbour's (v2,v3,v4) from its A_U record
   if (visc) {
@@ -1090,11 +1090,6 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   Exchange x0{0, (visc && use_fast) ? 1 : c->nphases - 1, c->au_nc, c->off_AU, off};
   off = align(off + (size_t)c->nsend * c->au_nc * sizeof(double));
   c->xch.push_back(x0);
-  if (use_fast) {   // second half of the trace (log rho, log beta, lam, E): only the last phase reads it
-    Exchange x0b{0, c->nphases - 1, FAU_NC, c->off_AU + nodes * FAU_NC * sizeof(double), off};
-    off = align(off + (size_t)c->nsend * FAU_NC * sizeof(double));
-    c->xch.push_back(x0b);
-  }
   if (need_Av) {
     Exchange x1{0, 1, AV_NC, c->off_Av, off};
     off = align(off + (size_t)c->nsend * AV_NC * sizeof(double));

@@ -40,8 +40,9 @@ struct Tables {
   const double* Pq;        // [Np][Nq] row-major (modal)
 };
 
-// Trace of the tensor kernels (esdg_kernels_tensor.hip): (rho, u, v, beta | log rho, log beta, lam, E), stored as two
-// arrays of FAU_NC-double records so that phase 1 (which needs u, v, beta only) fetches half the bytes
+// Trace of the tensor kernels: (rho, u, v, beta) of the entropy-projected face state, one 32-B record per face node.  Its logs,
+// energy and LF wavespeed -- a second 32-B record until round 3 -- are rebuilt by the consumer (devmath::trace_rest): phase 0
+// writes and exchanges half the bytes, the last phase reads 1280 B per element less and pays ~240 VALU instructions.
 constexpr int FAU_NC = 4;
 
 struct TensorTables;
@@ -65,8 +66,7 @@ int launch_rhs_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Ph
 
 struct MeshDev {
   int64_t K;               // local elements
-  int64_t trace_nodes;       // K*Nfq + ghost slots: the tensor kernels keep the A_U trace as two arrays of 4-double
-                             // records, (rho,u,v,beta) at A_U and (log rho,log beta,lam,E) at A_U + 4*trace_nodes
+  int64_t trace_nodes;       // K*Nfq + ghost slots (records of the A_U / B trace buffers)
   int64_t e_begin, e_count;  // element range a launch covers (tensor / hex kernels; the host sets 0, K for full launches)
   const double* geo;       // [K][GEO_STRIDE]
   const int32_t* mapP;     // [K][Nfq]  local face-node index, or ghost slot >= K*Nfq

@@ -43,8 +43,39 @@ __device__ __forceinline__ double log_pos(double x) {
   return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
 }
 
+// sqrt for x >= 0 where one ulp does not matter (the LF wavespeed): v_rsq_f64 + two coupled Newton steps, ~9 instructions
+// instead of the ~20 of the correctly rounded library sqrt; 0 stays 0
+__device__ __forceinline__ double sqrt_fast(double x) {
+  const double xs = fmax(x, 1e-300);
+  const double y = __builtin_amdgcn_rsq(xs);
+  double g = xs * y, h = .5 * y;
+  const double r = __builtin_fma(-h, g, .5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  g = __builtin_fma(__builtin_fma(-g, g, xs), h, g);
+  return x > 0.0 ? g : 0.0;
+}
+
+// What the tensor kernels rebuild from a face-trace record q[0..3] = (rho, u, v, beta) instead of reading it (round 3: the
+// record is 32 B, not 64): q[4..5] = log rho, log beta (the logs of exactly the stored doubles, as phase 0 used to take
+// them), q[7] = E, q[6] = the reference's interface wavespeed (euler_variables.jl:7-10 with rhoU_n, cavity :507: the
+// pressure of the NORMAL kinetic energy only, sqrt(|u_n|) quirk Q1) for the face normal (nx, ny) / sJ.  gm1 = gamma - 1.
+__device__ __forceinline__ void trace_rest(double* q, double nx, double ny, double isJ, double gm1);
+
 __device__ __forceinline__ void lds_add(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ void trace_rest(double* q, double nx, double ny, double isJ, double gm1) {
+  q[4] = log_pos(q[0]);
+  q[5] = log_pos(q[3]);
+  const double R = rcp_refined(q[0] * q[3]);
+  const double ib = R * q[0], ir = R * q[3];                                 // 1/beta, 1/rho
+  const double E = __builtin_fma(.5 * q[0], __builtin_fma(q[1], q[1], q[2] * q[2]), q[0] * ib * (.5 / gm1));
+  const double un = __builtin_fma(q[2], ny, q[1] * nx) * isJ;
+  const double pn = gm1 * __builtin_fma(-.5 * q[0], un * un, E);
+  q[6] = fabs(sqrt_fast(fabs(un)) + sqrt_fast(1.4 * pn * ir));
+  q[7] = E;
 }
 
 }  // namespace devmath

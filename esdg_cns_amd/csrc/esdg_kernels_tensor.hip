@@ -487,9 +487,10 @@ __global__ __launch_bounds__(WgP<N1>::TPB) void kt_project(TensorTables TT, Mesh
   const bool vactive = ln.tid < nE * Nq, factive = ln.tid < nE * Nfq;
   const int64_t e0s = min(e0, M.e_begin + M.e_count - 1);   // in-range base for the reads of idle lanes / idle groups
 
-  // All global loads of the kernel are issued here, unconditionally and before anything is waited for: tables, state,
-  // and the face lanes' normals (used only after the projection; loaded at the point of use they cost the wave a third
-  // serial memory round trip after tables -> barrier -> state).  Idle lanes read node 0 / face 0 of an in-range element.
+  // All global loads of the kernel are issued here, unconditionally and before anything is waited for: tables and state
+  // (the strided table copy -> barrier -> state sequence cost the wave two serial memory round trips; until round 3 a third
+  // one for the face normals of the wavespeed, which the consumer of the trace now rebuilds).  Idle lanes read node 0 of an
+  // in-range element.
   TableRegs<N1, W::TPB> tr;
   tr.load(TT);
   double x[4];
@@ -501,13 +502,6 @@ __global__ __launch_bounds__(WgP<N1>::TPB) void kt_project(TensorTables TT, Mesh
     const int tq = va ? ta : 0;
 #pragma unroll
     for (int f = 0; f < 4; ++f) x[f] = Q[(int64_t)f * M.K * Nq + eb * Nq + tq];
-  }
-  double gnf[3];
-  {
-    // (the face means of the record: the wavespeed only scales the LF term, itself a small jump -- the 1e-13 by which a node's
-    // own normal differs from the mean is not amplified there, unlike in the central flux of the last phase)
-    const double* g = M.geo + ESDG_EW(factive ? e0 + ln.ef : e0s) * GEO_STRIDE + 5 + 3 * ((factive ? ln.fn : 0) / N1);
-    gnf[0] = g[0]; gnf[1] = g[1]; gnf[2] = g[2];
   }
   __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise moves the state loads below the barrier, next to their first use)
   tr.store(sTab, sInt);
@@ -536,8 +530,7 @@ __global__ __launch_bounds__(WgP<N1>::TPB) void kt_project(TensorTables TT, Mesh
     }
     double Uf[4], qf[6];
     u_of_v<MODAL>(Vf, Uf);
-#ifdef ESDG_EXP_HALF1   // experiment: phase 0 writes the first trace half only (no logs, wavespeed, energy)
-    {
+    {   // (rho, u, v, beta) of the projected state: the whole record (its logs, energy and wavespeed are rebuilt by the consumer)
       constexpr double GM1e = Gas<MODAL>::GM1;
       const double m2 = Uf[1] * Uf[1] + Uf[2] * Uf[2];
       const double rre = Uf[0] * Uf[3] - .5 * m2;
@@ -545,25 +538,11 @@ __global__ __launch_bounds__(WgP<N1>::TPB) void kt_project(TensorTables TT, Mesh
       const double ir = R * rre;
       qf[0] = Uf[0]; qf[1] = Uf[1] * ir; qf[2] = Uf[2] * ir;
       qf[3] = (Uf[0] * Uf[0]) * (Uf[0] * R) * (1.0 / (2 * GM1e));
-      qf[4] = 0.0; qf[5] = 0.0;
     }
-    const double lam = 0.0;
-    (void)gnf;
-#else
-    prim_logs<MODAL>(Uf, qf);
-    const double lam = lf_lambda<MODAL>(Uf, gnf[0], gnf[1], gnf[2]);
-#endif
     const int64_t n = (ESDG_EW(e0) + ln.ef) * Nfq + ln.fn;
     double2* a = reinterpret_cast<double2*>(A_U + n * FAU_NC);
-    double2* a2 = reinterpret_cast<double2*>(A_U + (M.trace_nodes + n) * FAU_NC);
     a[0] = make_double2(qf[0], qf[1]);
     a[1] = make_double2(qf[2], qf[3]);
-#ifndef ESDG_EXP_HALF1
-    a2[0] = make_double2(qf[4], qf[5]);
-    a2[1] = make_double2(lam, Uf[3]);
-#else
-    (void)a2; (void)lam;
-#endif
   }
   (void)A_v;
 }
@@ -931,17 +910,19 @@ __global__ __launch_bounds__((WgR<N1, VISC>::TPB)) void kt_rhs(TensorTables TT, 
     if (WALLS && bcf == 2 && M.vlid) vlid = M.vlid[n];
     const double2* aM = reinterpret_cast<const double2*>(A_U + n * FAU_NC);
     const double2* aP = reinterpret_cast<const double2*>(A_U + mp * FAU_NC);
-    const double2* aM2 = reinterpret_cast<const double2*>(A_U + (M.trace_nodes + n) * FAU_NC);
-    const double2* aP2 = reinterpret_cast<const double2*>(A_U + (M.trace_nodes + mp) * FAU_NC);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const double2 m = aM[c], p = aP[c], m2 = aM2[c], p2 = aP2[c];
+      const double2 m = aM[c], p = aP[c];
       qM[2 * c] = m.x; qM[2 * c + 1] = m.y;
       qP[2 * c] = p.x; qP[2 * c + 1] = p.y;
-      qM[4 + 2 * c] = m2.x; qM[5 + 2 * c] = m2.y;
-      qP[4 + 2 * c] = p2.x; qP[5 + 2 * c] = p2.y;
     }
     mpk = mp;
+    // logs, energy and wavespeed of the two trace states (devmath::trace_rest), with the face means of the geometry record
+    // as phase 0 used to: the wavespeed only scales the LF term, itself a small jump
+    const double* gmn = M.geo + (e0 + ln.ef) * GEO_STRIDE + 5 + 3 * (ln.fn / N1);
+    const double isJm = rcp_refined(gmn[2]);
+    trace_rest(qM, gmn[0], gmn[1], isJm, Gas<MODAL>::GM1);
+    trace_rest(qP, gmn[0], gmn[1], isJm, Gas<MODAL>::GM1);
   }
 
   // ---- state at the Gauss node -> primitives + logs in registers and LDS ---------------------

@@ -788,30 +788,16 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
 #ifdef ESDG_EXP_SMALLTRACE   // experiment: all trace reads from a cache-resident window (wrong results, same instruction stream)
     const int64_t nfx = nf & ESDG_EXP_SMALLTRACE; const size_t mpx = mp & ESDG_EXP_SMALLTRACE;
     const d2* aM = reinterpret_cast<const d2*>(A_U + nfx * FAU_NC);
-    const d2* aM2 = reinterpret_cast<const d2*>(A_U + (M.trace_nodes + nfx) * FAU_NC);
     const d2* aP = reinterpret_cast<const d2*>(A_U + mpx * FAU_NC);
-    const d2* aP2 = reinterpret_cast<const d2*>(A_U + (M.trace_nodes + mpx) * FAU_NC);
 #else
     const d2* aM = reinterpret_cast<const d2*>(A_U + nf * FAU_NC);
-    const d2* aM2 = reinterpret_cast<const d2*>(A_U + (M.trace_nodes + nf) * FAU_NC);
     const d2* aP = reinterpret_cast<const d2*>(A_U + (size_t)ms * FAU_NC);
-    const d2* aP2 = reinterpret_cast<const d2*>(A_U + (M.trace_nodes + (size_t)ms) * FAU_NC);
 #endif
-#ifdef ESDG_EXP_HALF1   // experiment: only the first trace half is read; logs, wavespeed and energy are rebuilt below
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < 2; ++c) {   // (rho, u, v, beta) of both sides; their logs, energy and wavespeed are rebuilt at first use
       const d2 m = aM[c], p = aP[c];
       qM[2 * c] = m.x; qM[2 * c + 1] = m.y; qP[2 * c] = p.x; qP[2 * c + 1] = p.y;
     }
-    (void)aM2; (void)aP2;
-#else
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const d2 m = aM[c], p = aP[c], m2 = aM2[c], p2 = aP2[c];
-      qM[2 * c] = m.x; qM[2 * c + 1] = m.y; qP[2 * c] = p.x; qP[2 * c + 1] = p.y;
-      qM[4 + 2 * c] = m2.x; qM[5 + 2 * c] = m2.y; qP[4 + 2 * c] = p2.x; qP[5 + 2 * c] = p2.y;
-    }
-#endif
 
   {
     // ---- state and geometry to LDS ----------------------------------------------------------------------------------------
@@ -893,11 +879,10 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
 #ifndef ESDG_EXP_SMALLTRACE
     if (mp != ms) {   // the guess was wrong for this lane: the neighbour's trace from the index mapP holds
       const d2* bP = reinterpret_cast<const d2*>(A_U + (size_t)mp * FAU_NC);
-      const d2* bP2 = reinterpret_cast<const d2*>(A_U + (M.trace_nodes + (size_t)mp) * FAU_NC);
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const d2 p = bP[c], p2 = bP2[c];
-        qP[2 * c] = p.x; qP[2 * c + 1] = p.y; qP[4 + 2 * c] = p2.x; qP[5 + 2 * c] = p2.y;
+        const d2 p = bP[c];
+        qP[2 * c] = p.x; qP[2 * c + 1] = p.y;
       }
     }
 #endif
@@ -912,22 +897,11 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
       const double* gm = gf + gfo;
       // (sJ: the face mean unless a wall closure turns it into a unit normal -- it only scales the LF term, a small jump)
       const double gn[3] = {gm[0] + (double)nd.x, gm[1] + (double)nd.y, WALLS ? gm[2] + (double)sd : gm[2]};
-#ifdef ESDG_EXP_HALF1
-      {
-        const double isJ = rcp_refined(gm[2]);
-#pragma unroll
-        for (int sd2 = 0; sd2 < 2; ++sd2) {
-          double* qq = sd2 ? qP : qM;
-          qq[4] = log_pos(qq[0]);
-          qq[5] = log_pos(qq[3]);
-          const double E = __builtin_fma(.5 * qq[0], __builtin_fma(qq[1], qq[1], qq[2] * qq[2]), qq[0] * rcp_refined(qq[3]) * (1.0 / (2 * Gas2<MODAL>::GM1)));
-          const double un = __builtin_fma(qq[2], gm[1], qq[1] * gm[0]) * isJ;
-          const double pn = Gas2<MODAL>::GM1 * __builtin_fma(-.5 * qq[0], un * un, E);
-          qq[6] = fabs(sqrt(fabs(un)) + sqrt(1.4 * pn * rcp_refined(qq[0])));
-          qq[7] = E;
-        }
+      {   // logs, energy and wavespeed of the two trace states, with the face means of the record as phase 0 used to take them
+        const double isJm = rcp_refined(gm[2]);
+        trace_rest(qM, gm[0], gm[1], isJm, Gas2<MODAL>::GM1);
+        trace_rest(qP, gm[0], gm[1], isJm, Gas2<MODAL>::GM1);
       }
-#endif
       if (VISC) {   // penalty tau*[[v]] (:817-837): the projected entropy variables are those OF the trace states
         const double bM = 2 * Gas2<MODAL>::GM1 * qM[3], bP = 2 * Gas2<MODAL>::GM1 * qP[3];
         const double tau = ph.viscous_dissp ? -rcp_refined(-bM) * ph.inv_Re : 0.0;

@@ -267,8 +267,8 @@ int esdg_error_boundary_velocity(esdg_ctx* ctx, const double* Q, double Jf, doub
 /* The reference's three x[mapP] gathers (QM/Uf+lam :496-511, VUf :776, sigma_f :813-814) become face-trace
  * exchanges: A_U (entropy-projected face state + lam) and B (normal viscous stress); the tensor kernels rebuild the
  * neighbour's projected entropy variables VUf[mapP] from its A_U record, the generic kernels exchange them as a
- * third buffer A_v.  The tensor kernels keep A_U as two arrays of 4-number records, (rho,u,v,beta) and
- * (log rho, log beta, lam, E), exchanged separately: the viscous gradient phase waits for the first only.
+ * third buffer A_v.  The tensor kernels' A_U record is (rho,u,v,beta); its logs, energy and wavespeed are rebuilt by
+ * the consumer.
  * esdg_num_exchanges / esdg_exchange_info enumerate them: exchange x is produced (and packed) by
  * phase `after_phase` and must have landed before phase `before_phase` starts. */
 int esdg_halo_num_neighbors(const esdg_ctx* ctx);
