@@ -407,13 +407,17 @@ def run(args):
     Nfq_ = eng.Nfq if hasattr(eng, "Nfq") else (6 * (N + 1) ** 2 if hexw else 4 * (N + 1))
     if hexw:
         design_k = 80.0 * Np + 80.0 * Nfq_                        # Q r + rhs w, own + neighbour trace (5 doubles per node)
+        if args.hex_geometry == "per-node" and not args.hex_curve:
+            design_k += 12.0 * Np + 8.0 * Nfq_                    # 10-bit geometry differences: 3 words per volume node, 2 per face node
         design_whole = design_k + 40.0 * Np + 40.0 * Nfq_         # + phase 0: Q r, trace w
     elif args.formulation == "cns":
-        design_k = 64.0 * Np + 128.0 * Nfq_ + 24.0 * Np + 48.0 * Nfq_   # Q, rhs | A_U own+nbr | SG | B own+nbr
-        design_whole = design_k + (32.0 * Np + 64.0 * Nfq_) + (32.0 * Np + 32.0 * Nfq_ + 24.0 * Np + 24.0 * Nfq_)
+        # Q, rhs | A_U own+nbr (32-B records) | SG | B own+nbr | per-node normal differences
+        design_k = 64.0 * Np + 64.0 * Nfq_ + 24.0 * Np + 48.0 * Nfq_ + 8.0 * Nfq_
+        # + phase 0 (Q r, A_U w) + phase 1 (Q r, A_U nbr r, SG w, B w, normal differences)
+        design_whole = design_k + (32.0 * Np + 32.0 * Nfq_) + (32.0 * Np + 32.0 * Nfq_ + 24.0 * Np + 24.0 * Nfq_ + 8.0 * Nfq_)
     else:
-        design_k = 64.0 * Np + 128.0 * Nfq_
-        design_whole = design_k + 32.0 * Np + 64.0 * Nfq_
+        design_k = 64.0 * Np + 64.0 * Nfq_ + 8.0 * Nfq_
+        design_whole = design_k + 32.0 * Np + 32.0 * Nfq_
     bytes_k = traffic if traffic else design_k * K_local
     bytes_whole = whole_traffic if whole_traffic else design_whole * K_local
     whole_flops = rec.get("whole_rhs_fp64_flops") if (rec and not pmc_stale) else None
