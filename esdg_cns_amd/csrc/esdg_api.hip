@@ -652,58 +652,6 @@ static void set_interior(esdg_ctx* c, const std::vector<int32_t>& mapP, int64_t 
   }
 }
 
-// Structured-neighbour guess for the last-phase kernels (MeshDev::spec_*): per face one element offset, partner face and
-// node orientation, taken from sample elements and kept when it reproduces mapP on more than half of all face nodes.
-// ESDG_NO_SPEC=1 switches it off (A/B).
-static void detect_structured(MeshDev& M, const std::vector<int32_t>& mapP, int64_t K, int nfaces, int N1, bool hex) {
-  M.spec_code = 0;
-  for (int f = 0; f < 6; ++f) M.spec_eoff[f] = 0;
-  if (getenv("ESDG_NO_SPEC") || K < 1 || nfaces > 6) return;
-  const int npf = hex ? N1 * N1 : N1, Nfq = nfaces * npf;
-  const int64_t first_ghost = K * Nfq;
-  int64_t best = -1;
-  uint64_t best_code = 0;
-  int32_t best_off[6] = {0, 0, 0, 0, 0, 0};
-  const int64_t samples[6] = {K / 2, K / 3, (2 * K) / 3, K / 5, (4 * K) / 5, 0};
-  for (int64_t es : samples) {
-    uint64_t code = 0;
-    int32_t off[6] = {0, 0, 0, 0, 0, 0};
-    bool ok = true;
-    for (int f = 0; f < nfaces && ok; ++f) {
-      const int32_t* row = &mapP[(size_t)es * Nfq + (size_t)f * npf];
-      if (row[0] >= first_ghost) { ok = false; break; }
-      const int64_t pe = row[0] / Nfq;
-      const unsigned of = (unsigned)((row[0] % Nfq) / npf);
-      bool found = false;
-      for (unsigned o = 0; o < (hex ? 8u : 2u) && !found; ++o) {
-        const unsigned c = of | (o << 3);
-        bool all = true;
-        for (int n = 0; n < npf && all; ++n)
-          all = row[n] == (int32_t)(pe * Nfq + of * npf + spec_partner_node_rt(N1, hex, c, (unsigned)n));
-        if (all) { code |= (uint64_t)c << (8 * f); off[f] = (int32_t)(pe - es); found = true; }
-      }
-      ok = found;
-    }
-    if (!ok) continue;
-    int64_t hits = 0;
-    for (int64_t e = 0; e < K; ++e)
-      for (int f = 0; f < nfaces; ++f) {
-        const unsigned c = (unsigned)(code >> (8 * f)) & 255u;
-        const int64_t pe = e + off[f];
-        if (pe < 0 || pe >= K) continue;
-        const int32_t* row = &mapP[(size_t)e * Nfq + (size_t)f * npf];
-        const int64_t base = pe * Nfq + (int64_t)(c & 7u) * npf;
-        for (int n = 0; n < npf; ++n) hits += row[n] == (int32_t)(base + spec_partner_node_rt(N1, hex, c, (unsigned)n));
-      }
-    if (hits > best) { best = hits; best_code = code; for (int f = 0; f < 6; ++f) best_off[f] = off[f]; }
-    if (2 * hits > K * Nfq) break;   // good enough: the first sample that explains most of the mesh
-  }
-  if (best >= 0 && 2 * best > K * Nfq) {
-    M.spec_code = best_code | ((uint64_t)1 << 63);
-    for (int f = 0; f < 6; ++f) M.spec_eoff[f] = best_off[f];
-  }
-}
-
 extern "C" {
 
 const char* esdg_last_error(void) { return g_err.c_str(); }
@@ -1070,7 +1018,6 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   c->M.fnrm = c->d_fnrm.as<double>(); c->M.fnd = c->d_fnd.as<float>(); c->M.fsd = c->d_fsd.as<float>();
   c->M.vlid = vlid.empty() ? nullptr : c->d_vlid.as<double>();
   set_interior(c, pl.mapP, K, Nfq);
-  if (use_fast) detect_structured(c->M, pl.mapP, K, 4, N1, false);
   c->M.wJq = mesh->wJq ? c->d_wJq.as<double>() : nullptr;
 
   // ---- workspace layout ---------------------------------------------------------------------
@@ -1290,7 +1237,6 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
   c->M.hdf = hdv.empty() ? nullptr : c->d_hdf.as<uint32_t>();
   c->M.hdn = hdv.empty() ? nullptr : c->d_hdn.as<uint32_t>();
   set_interior(c, pl.mapP, K, Nfq);
-  detect_structured(c->M, pl.mapP, K, 6, N1, true);
   c->M.wJq = mesh->wJq ? c->d_wJq.as<double>() : nullptr;
 
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };

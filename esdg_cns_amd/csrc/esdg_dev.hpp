@@ -97,39 +97,11 @@ struct MeshDev {
   const uint32_t* hdv;
   const uint32_t* hdf;
   const uint32_t* hdn;
-  // Structured-neighbour guess (esdg_api.hip: detect_structured): on most faces of a structured mesh the partner of face
-  // node (e, f, i) is (e + spec_eoff[f], face of, node i or its mirror) -- one byte per face in spec_code (bits 0-2: of,
-  // bit 3: first index reversed, bit 4: second index reversed, bit 5: indices swapped (hex faces only)), bit 63: valid.
-  // The last-phase kernels issue their neighbour-trace loads from this guess at entry, beside the mapP load instead of
-  // behind it, and reload from mapP where the guess was wrong (wrap-around rows, ghosts, walls, irregular meshes): mapP
-  // stays the only source of truth.
-  int32_t spec_eoff[6];
-  uint64_t spec_code;
   // Role of a ranged launch in the overlapped sharded schedule (set by rhs_sharded_impl only; 0 everywhere else, incl.
   // esdg_rhs_phase_range): 1 = the interior beside which boundary strips run, 2 = a boundary strip.  The persistent
   // kt2_sigma leaves a few workgroup slots free in role 1 and asks for no more than those in role 2 (ESDG_T2_RESERVE).
   int32_t launch_role;
 };
-
-// node of the partner face that the structured-neighbour guess pairs with node n of a face (c: the face's byte of
-// MeshDev::spec_code; faces of quads hold N1 nodes, faces of hexahedra N1 x N1, first index fastest)
-template <int N1, bool HEX>
-__host__ __device__ inline unsigned spec_partner_node(unsigned c, unsigned n) {
-  if (!HEX) return (c & 8u) ? (unsigned)(N1 - 1) - n : n;
-  unsigned i = n % N1, j = n / N1;
-  if (c & 32u) { const unsigned t = i; i = j; j = t; }
-  if (c & 8u) i = (unsigned)(N1 - 1) - i;
-  if (c & 16u) j = (unsigned)(N1 - 1) - j;
-  return i + N1 * j;
-}
-inline unsigned spec_partner_node_rt(int N1, bool hex, unsigned c, unsigned n) {   // host, runtime degree
-  if (!hex) return (c & 8u) ? (unsigned)(N1 - 1) - n : n;
-  unsigned i = n % N1, j = n / N1;
-  if (c & 32u) { const unsigned t = i; i = j; j = t; }
-  if (c & 8u) i = (unsigned)(N1 - 1) - i;
-  if (c & 16u) j = (unsigned)(N1 - 1) - j;
-  return i + N1 * j;
-}
 
 // Attribution builds (-DESDG_EXP_WINDOW=mask, mask = 2^k - 1; tools/session_r03b.sh): every global address a kernel of the
 // tensor path forms -- state, geometry, neighbour index, traces, outputs -- is folded into the first mask+1 elements, which

@@ -711,24 +711,9 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
   const unsigned tvl = tv < (unsigned)(nE * Nq) ? tv : 0u, tfl = tf < (unsigned)(nE * Nfq) ? tf : 0u, tvg = tv;
   const int64_t nf = e0 * Nfq + tfl;
   const unsigned mp = ESDG_EWN((unsigned)M.mapP[nf], Nfq);
-  // Structured-neighbour guess ms of mp (-DESDG_T2_SPEC; MeshDev::spec_*, scalar kernel arguments): the neighbour-trace loads
-  // are issued from the guess at entry, beside the mapP load instead of behind it, mp is compared with it where the trace is
-  // first used, and lanes whose guess was wrong reload from mp.  MEASURED SLOWER and therefore off (round 3, same box:
-  // kt2_rhs 0.3745 ms with the guess, 0.3598 without, 0.3658 for the round-2 build): the traces are not needed until after
-  // the volume-volume rounds, and issuing their 2.5 KB per element at entry only puts them in the memory queues ahead of the
-  // next workgroups' state loads, which ARE needed at once.
-#ifndef ESDG_T2_SPEC
-  const unsigned ms = mp;
-#else
-  unsigned ms = (unsigned)nf;
-  if (M.spec_code >> 63) {   // uniform
-    const unsigned efl = tfl / Nfq, fnl = tfl - efl * Nfq, f = fnl / N1, i = fnl - f * N1;
-    const unsigned c = (unsigned)(M.spec_code >> (8 * f)) & 255u;
-    const int eo = f == 0 ? M.spec_eoff[0] : f == 1 ? M.spec_eoff[1] : f == 2 ? M.spec_eoff[2] : M.spec_eoff[3];
-    const int64_t es = min(max(e0 + (int64_t)efl + eo, (int64_t)0), M.K - 1);
-    ms = (unsigned)(es * Nfq) + (c & 7u) * N1 + spec_partner_node<N1, false>(c, i);
-  }
-#endif
+  // (Measured and removed in round 3 -- a structured-neighbour guess of mp from kernel arguments, the neighbour-trace loads
+  // issued from it at entry and mp verified at first use: 4 % slower.  The traces are not needed until after the volume-volume
+  // rounds; one round trip earlier they only queue ahead of the next workgroups' state loads.  profiles/experiments/README.md)
   int bcf = 0;
   double vlid = 1.0;
   if (WALLS) {   // boundary flag (1 wall, 2 lid, 3 inflow, 4 copy) and lid velocity of this lane's face node
@@ -791,7 +776,7 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
     const d2* aP = reinterpret_cast<const d2*>(A_U + mpx * FAU_NC);
 #else
     const d2* aM = reinterpret_cast<const d2*>(A_U + nf * FAU_NC);
-    const d2* aP = reinterpret_cast<const d2*>(A_U + (size_t)ms * FAU_NC);
+    const d2* aP = reinterpret_cast<const d2*>(A_U + (size_t)mp * FAU_NC);
 #endif
 #pragma unroll
     for (int c = 0; c < 2; ++c) {   // (rho, u, v, beta) of both sides; their logs, energy and wavespeed are rebuilt at first use
@@ -876,16 +861,6 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
       }
     }
     T2_STAMP(4);   // volume-volume rounds
-#ifndef ESDG_EXP_SMALLTRACE
-    if (mp != ms) {   // the guess was wrong for this lane: the neighbour's trace from the index mapP holds
-      const d2* bP = reinterpret_cast<const d2*>(A_U + (size_t)mp * FAU_NC);
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const d2 p = bP[c];
-        qP[2 * c] = p.x; qP[2 * c + 1] = p.y;
-      }
-    }
-#endif
     if (VISC) {   // needed after the volume-face pairs: issued here, their destinations are not live during the rounds above
 #pragma unroll
       for (int c = 0; c < 3; ++c) { bPn[c] = B[(size_t)mp * B_NC + c]; bOwn[c] = B[nf * B_NC + c]; dvs[c] = SG[c * KN + e0 * Nq + tvl]; }
