@@ -62,12 +62,12 @@ def test_hex_rhstest_entropy_conservation(eng_mod, oracle_lib):
     assert abs(rt1 - rto) < 1e-10 * max(1.0, abs(rto))
 
 
-def test_hex_invariants_shards_and_fused_rk(eng_mod):
+@pytest.mark.parametrize("N,K3", [(3, (6, 4, 4)), (4, (3, 2, 4))])   # N = 4: the degree-generic kernels kh_*_g
+def test_hex_invariants_shards_and_fused_rk(eng_mod, N, K3):
     """Free-stream preservation, conservation, two shards on one GPU == one engine bit for bit, bitwise
     reproducibility, host drop-in entry point, fused LSRK stage == unfused."""
     import torch
     from esdg_cns_amd import setup_dg as sd
-    N, K3 = 3, (6, 4, 4)
     rd, md, ops, Q = product_hex_problem(N, *K3)
     eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.EULER_HEX_COLLOCATED, lf_scale=0.25)
     # free stream
@@ -113,7 +113,13 @@ def test_hex_invariants_shards_and_fused_rk(eng_mod):
                     engs[rk].ws[ro:ro + rb].copy_(src.ws[seg[1]:seg[1] + seg[2]])
             torch.cuda.synchronize()
     full = torch.cat(outs, dim=1)
-    assert torch.equal(full, rd_)
+    if N <= 3:
+        assert torch.equal(full, rd_)
+    else:
+        # (at N = 4 the product set-up's own arrays differ in the last bit between the full mesh and an element range --
+        # numpy matmul blocks differently for 24 and 12 columns: tzJ 6e-16, nxJ 4e-16 -- so the shards are fed different
+        # geometry; the kernels themselves are order-deterministic, see the reproducibility check above)
+        assert float((full - rd_).abs().max()) <= 1e-11 * float(rd_.abs().max())
     # fused low-storage RK stage
     a, b, dt = -0.4178904745, 0.3792103130, 1e-3
     Q1, res1 = Qd.clone(), torch.full_like(Qd, 0.01)
@@ -183,7 +189,7 @@ def test_hex_graded_mesh_every_element_its_own_geometry(eng_mod, oracle_lib):
         truth_gate(f"graded hex mesh lf={lf}", _gpu_rhs(eng, Q), ho.rhs(Q)[0], hq.rhs(Q)[0])
 
 
-@pytest.mark.parametrize("N,K3", [(3, (4, 4, 4)), (2, (3, 3, 4))])
+@pytest.mark.parametrize("N,K3", [(3, (4, 4, 4)), (2, (3, 3, 4)), (4, (2, 2, 3)), (5, (2, 2, 2))])   # N >= 4: kh_rhs_g<N1, 1>
 def test_hex_curved_mesh_matches_oracle(eng_mod, oracle_lib, N, K3):
     """The script's curved mapping x,y,z += a (x^2-1)(y^2-1)(z^2-1) (dg3D_euler_hex.jl:67-73; a = 0 in the script
     itself): per-node metric terms at the hybrid nodes, per-pair metric averages (:145-151), per-node normals and J.
