@@ -118,3 +118,24 @@ def test_julia_shim_mirrors_the_header():
     unbound = declared - called
     assert unbound <= not_needed, sorted(unbound - not_needed)
     assert not (not_needed & called), sorted(not_needed & called)
+
+
+def test_julia_setupdg_stand_in_uses_what_exists():
+    """julia/SetupDG.jl (the reference's module / function names over the library's host-only set-up; un-runnable here):
+    it exports the names of /root/reference/src/SetupDG.jl:33-36, imports only functions julia/ESDGHip.jl defines, and asks
+    esdg_setup_array / esdg_setup_map only for names csrc/esdg_setup.cpp serves."""
+    jl = open(os.path.join(ROOT, "julia", "SetupDG.jl")).read()
+    shim = open(os.path.join(ROOT, "julia", "ESDGHip.jl")).read()
+    exported = set(re.findall(r"[A-Za-z_!0-9]+", re.search(r"^export (.*)$", jl, flags=re.M).group(1)))
+    assert {"init_reference_quad", "init_reference_hex", "init_mesh", "MeshData", "RefElemData"} <= exported
+    for line in re.findall(r"^using \.\.ESDGHip: (.*)$", jl, flags=re.M):
+        for name in [n.strip() for n in line.split(",")]:
+            if name in ("ESDGHip",):
+                continue
+            assert re.search(r"^\s*(function |mutable struct |struct |const [^=\n]*\b)?" + re.escape(name) + r"\b", shim, flags=re.M), name
+    src = open(os.path.join(ROOT, "esdg_cns_amd", "csrc", "esdg_setup.cpp")).read()
+    served = set(re.findall(r'"([A-Za-z0-9_]+)"', src))
+    asked = set(re.findall(r":([A-Za-z0-9]+)[,)]", re.search(r"function init_mesh.*?^end", jl, flags=re.S | re.M).group(0)))
+    asked |= set(re.findall(r'setup_(?:array|map)\(s, "([A-Za-z0-9_]+)"\)', jl))
+    missing = {a for a in asked if a not in served and a not in ("VX", "VY", "VZ")}
+    assert not missing, missing
