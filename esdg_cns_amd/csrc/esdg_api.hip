@@ -739,7 +739,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   c->ph.parts = 3;
   c->ph.dbg = 0;
   if (const char* env = getenv("ESDG_DBG")) c->ph.dbg = atoi(env);
-  if (const char* env = getenv("ESDG_V1")) c->v1 = env[0] == '1' ? 3 : env[0] == 's' ? 1 : env[0] == 'r' ? 2 : env[0] == 'w' ? 8 : 0;
+  if (const char* env = getenv("ESDG_V1")) c->v1 = env[0] == '1' ? 7 : env[0] == 's' ? 1 : env[0] == 'r' ? 2 : env[0] == 'p' ? 4 : env[0] == 'w' ? 8 : 0;
 
   // ---- collocated sparse operators -------------------------------------------------------
   Mat EfD, PhC, LfC, DrC, DsC, Vq, Pq;
@@ -1310,8 +1310,12 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
       rc = launch_rhs_hex(ctx->T.N1, ctx->HT, ctx->M, ctx->ph, Q, A_U, rhs, lf, s);
     }
   } else if (phase == 0) {
-    rc = ctx->use_fast ? launch_project_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, A_v, s)
-                       : launch_project(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, s);
+    rc = -1;
+    if (ctx->use_fast && !(ctx->v1 & 4))   // v2 kernel (ESDG_V1=1 / ESDG_V1=project: the round-1 kt_project, A/B)
+      rc = launch_project_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, s);
+    if (rc == -1)
+      rc = ctx->use_fast ? launch_project_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, A_v, s)
+                         : launch_project(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, s);
   } else if (visc && phase == 1) {
     // v2 kernel (the visc_test reduction stays with kt_sigma); ESDG_V1=1: A/B.  On meshes with walls the two viscous phases
     // must come from the same set (kt_sigma stores sigma for kt_rhs, kt2_sigma the volume divergence and, at boundary

@@ -635,6 +635,106 @@ __device__ __forceinline__ void prim_logs(const double* U, double* q) {
   q[5] = log_pos(q[3]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// phase 0: entropy projection to the faces -> the (rho, u, v, beta) trace records A_U
+// (euler_quad.jl:141-157 / rhs_inviscid! :447-495: VU = v(Vq u), Uf = u(Vf Pq VU); see kt_project in esdg_kernels_tensor.hip)
+// One workgroup per group of E elements (one-shot), pair planes, per-node table rows.  The round-1 kernel kept its LDS
+// arrays as [element][component][node] planes of doubles: a wave waited 38 % of its life on LDS instructions, a third of its
+// LDS cycles were bank conflicts (profiles/r03u_sq_counters.txt).
+// ---------------------------------------------------------------------------------------------------------------------
+// entropy variables from primitives + logs (identities of euler_variables.jl:79-92)
+template <bool MODAL>
+__device__ __forceinline__ void v_of_prim2(const double* q, double* V) {
+  constexpr double GM1 = Gas2<MODAL>::GM1;
+  const double s = -GM1 * q[4] - q[5] - 0.6931471805599453;
+  const double b2 = 2 * GM1 * q[3];
+  V[0] = 1.4 - s - .5 * b2 * (q[1] * q[1] + q[2] * q[2]);
+  V[1] = b2 * q[1];
+  V[2] = b2 * q[2];
+  V[3] = -b2;
+}
+// (rho, u, v, beta) of entropy variables: u_vfun (euler_variables.jl:95-120 / cavity :473-478, no pow) followed by the
+// primitive conversion of the conservative state it returns
+template <bool MODAL>
+__device__ __forceinline__ void prim_of_v2(const double* V, double* q) {
+  constexpr double GM1 = Gas2<MODAL>::GM1;
+  const double vUnorm = V[1] * V[1] + V[2] * V[2];
+  const double h = vUnorm * .5 * rcp_refined(V[3]);
+  const double s = 1.4 - V[0] + h;
+  const double rhoeV = exp((log(GM1) - 1.4 * log_pos(-V[3]) - s) * (1.0 / GM1));
+  const double U[4] = {rhoeV * (-V[3]), rhoeV * V[1], rhoeV * V[2], rhoeV * (1 - h)};
+  const double m2 = U[1] * U[1] + U[2] * U[2];
+  const double rre = U[0] * U[3] - .5 * m2;
+  const double R = rcp_refined(U[0] * rre);
+  const double ir = R * rre;
+  q[0] = U[0]; q[1] = U[1] * ir; q[2] = U[2] * ir;
+  q[3] = (U[0] * U[0]) * (U[0] * R) * (1.0 / (2 * GM1));
+}
+
+template <int N1, bool MODAL>
+__global__ __launch_bounds__(Geo<N1>::GT) void kt2_project(TensorTables TT, MeshDev M, const double* __restrict__ Q, double* __restrict__ A_U) {
+  using G = Geo<N1>;
+  constexpr int Nq = G::Nq, Nfq = G::Nfq, E = G::E, NV = G::NV, NF = G::NF;
+  constexpr NodeLayout NL(N1);
+  constexpr FaceLayout FL(N1);
+  __shared__ __align__(16) double lds[8 * NV];   // Vq scratch A | B0 | B1 (pair planes), then the entropy variables (2 pair planes)
+  d2* sA = reinterpret_cast<d2*>(lds);
+  d2* sB0 = reinterpret_cast<d2*>(lds + 4 * NV);
+  d2* sB1 = reinterpret_cast<d2*>(lds + 6 * NV);
+  const unsigned tid = threadIdx.x;
+  const unsigned tv = tid < (unsigned)NV ? tid : tid - NV;              // (lanes beyond the slots duplicate a slot, see kt2_sigma)
+  const unsigned tf = tid < (unsigned)NF ? tid : tid % NF;
+  const unsigned ev = tv / Nq, q = tv - ev * Nq, a = q % N1, b = q / N1;
+  const unsigned ef = tf / Nfq, fn = tf - ef * Nfq;
+  const unsigned rowb = ev * Nq + N1 * b, colq = ev * Nq + b;
+  const int64_t KN = M.K * Nq;
+  const int64_t e0 = M.e_begin + (int64_t)blockIdx.x * E;
+  const int nE = (int)min((int64_t)E, M.e_begin + M.e_count - e0);
+  const unsigned tvl = tv < (unsigned)(nE * Nq) ? tv : 0u;
+  const bool fact = tid < (unsigned)(nE * Nfq);
+  // every global load at entry, unconditionally (state; per-node / per-face-node table rows)
+  double x[4], cq[N1], ee[N1];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) x[f] = Q[f * KN + ESDG_EW(e0) * Nq + tvl];
+  const double* nd_ = TT.node_d + q;
+  const double* fd_ = TT.face_d + fn;
+  const int* fi_ = TT.face_i + fn;
+#pragma unroll
+  for (int i = 0; i < N1; ++i) { cq[i] = MODAL ? nd_[(NL.IQ + i) * Nq] : 0.0; ee[i] = fd_[(FL.EE + i) * Nfq]; }
+  const unsigned fnode0 = ef * Nq + fi_[(FL.NODE0) * Nfq], fstride = fi_[(FL.STRIDE) * Nfq];
+
+  double U[4];
+  if (MODAL) {
+    vq_apply<N1, NV>(cq, sA, sB0, sB1, tv, rowb, colq, x, U);
+    __syncthreads();   // every lane is past its reads of the scratch planes, which take the entropy variables below
+  } else {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) U[f] = x[f];
+  }
+  double qh[6], V[4];
+  prim_logs<MODAL>(U, qh);
+  v_of_prim2<MODAL>(qh, V);
+  sA[tv] = make_double2(V[0], V[1]);
+  sA[NV + tv] = make_double2(V[2], V[3]);
+  __syncthreads();
+  // face lanes: Vf = Ef * V along the node's line, then the primitive state of u(Vf)
+  d2 p0 = sA[fnode0], p1 = sA[NV + fnode0];
+  double Vf[4] = {ee[0] * p0.x, ee[0] * p0.y, ee[0] * p1.x, ee[0] * p1.y};
+#pragma unroll
+  for (int j = 1; j < N1; ++j) {
+    p0 = sA[fnode0 + j * fstride]; p1 = sA[NV + fnode0 + j * fstride];
+    Vf[0] = __builtin_fma(ee[j], p0.x, Vf[0]); Vf[1] = __builtin_fma(ee[j], p0.y, Vf[1]);
+    Vf[2] = __builtin_fma(ee[j], p1.x, Vf[2]); Vf[3] = __builtin_fma(ee[j], p1.y, Vf[3]);
+  }
+  double qf[4];
+  prim_of_v2<MODAL>(Vf, qf);
+  if (fact) {
+    d2* rec = reinterpret_cast<d2*>(A_U + (ESDG_EW(e0) * Nfq + tf) * FAU_NC);
+    rec[0] = make_double2(qf[0], qf[1]);
+    rec[1] = make_double2(qf[2], qf[3]);
+  }
+}
+
 template <int N1, bool MODAL, bool VISC> struct RhsLds2 {
   using G = GeoR<N1>;
   static constexpr NodeLayout NL = NodeLayout(N1);
@@ -1136,6 +1236,20 @@ int launch_rhs_tensor2(int N1v, const TensorTables& TT, const MeshDev& M, const 
       else if (visc) (launch_rhs2<N1, true, true>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
       else (launch_rhs2<N1, true, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
     }
+  });
+  return (int)hipGetLastError();
+}
+
+// phase 0 with the v2 kernel; returns -1 where it does not cover the degree (caller falls back to kt_project)
+int launch_project_tensor2(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, double* A_U, hipStream_t s) {
+  if (M.e_count <= 0) return 0;
+  if (N1v < 2 || N1v > 8) return -1;
+  const bool modal = ph.formulation != 0;
+  ESDG_T2_DISPATCH(N1v, {
+    using G = t2::Geo<N1>;
+    const int nb = (int)((M.e_count + G::E - 1) / G::E);
+    if (modal) hipLaunchKernelGGL((t2::kt2_project<N1, true>), dim3(nb), dim3(G::GT), 0, s, TT, M, Q, A_U);
+    else hipLaunchKernelGGL((t2::kt2_project<N1, false>), dim3(nb), dim3(G::GT), 0, s, TT, M, Q, A_U);
   });
   return (int)hipGetLastError();
 }
