@@ -64,7 +64,7 @@ for k in out:
 rhs_name = [k for k in out if "_rhs<" in k]
 sys.path.insert(0, root)
 import bench  # noqa: E402
-main = {k: v for k, v in out.items() if any(t in k for t in ("kt_project", "kt_sigma", "kt_rhs", "kt2_sigma", "kt2_rhs", "kh_project", "kh_rhs"))}
+main = {k: v for k, v in out.items() if any(t in k for t in ("kt_project", "kt2_project", "kt_sigma", "kt_rhs", "kt2_sigma", "kt2_rhs", "kh_project", "kh_rhs"))}
 # the hash recorded on the GPU box when the passes ran (tools/profile_round.sh); never the hash of whatever the sources are now
 sha_file = os.path.join(src, "kernel_src_sha.txt")
 measured_sha = open(sha_file).read().strip() if os.path.exists(sha_file) else None
