@@ -178,3 +178,43 @@ def test_truth_evaluator_is_the_same_statements_in_binary128(oracle_lib):
     d_cns = rel_l2(c64.rhsRK(pc.Q, False)[0], c128.rhsRK(pc.Q, False)[0])
     print(f"cns N=3 4x4: |f64 - f128| {d_cns:.2e}")
     assert 1e-14 < d_cns < 1e-9
+
+
+def test_viscous_operators_read_their_geometry_node_by_node(oracle_lib):
+    """dg_grad! / dg_div! scale nodal coefficients by rows 1:Np of the metric arrays and by J[i,e] node by node
+    (dg2D_CNS_cavity_optimized.jl:549-611); on an affine element those arrays are a constant plus the set-up's round-off.
+    With adiabatic no-slip walls the lifted wall jump dominates the momentum rows of the boundary elements and the Float64
+    evaluation is almost exact there (e_orc ~ 1e-15), so that round-off is visible: the same oracle fed with ELEMENT MEANS of
+    those arrays -- what the device kernels hold, one record per element -- moves `rhs_viscous!` by tens of e_orc in exactly
+    those rows, and by nothing measurable in the interior.  This pins the explanation of the two recorded exceptions of the
+    GPU gate (tests/test_gpu_parity.py: VISC_FACTOR_NOSLIP; tools/cavity_visc_attribution.py)."""
+    import copy
+
+    from common import as_oracle_problem, product_cavity_problem
+    N, Kx, Ky = 4, 8, 8
+    rd, md, ops, Q = product_cavity_problem(N, Kx, Ky)
+    phys = dict(Re=1000.0, mu=1e-3, lam=-2e-3 / 3, Pr=.71, BCTYPE=1)
+    p = as_oracle_problem(rd, md, ops, Q, **phys)
+    tv = orc.CnsOracle(p, quad=True).rhs_viscous(Q)[0]
+    ov = orc.CnsOracle(p).rhs_viscous(Q)[0]
+    Np = rd.Pq.shape[0]
+    md2 = copy.copy(md)
+    for nm in ("J", "rxJ", "sxJ", "ryJ", "syJ"):
+        a = getattr(md, nm).copy()
+        if nm == "J":
+            a[:] = a.mean(axis=0)
+        else:
+            a[:Np] = a[:Np].mean(axis=0)
+        setattr(md2, nm, a)
+    mv = orc.CnsOracle(as_oracle_problem(rd, md2, ops, Q, **phys)).rhs_viscous(Q)[0]
+    K = Kx * Ky
+    ex, ey = np.arange(K) % Kx, np.arange(K) // Kx
+    bnd = (ex == 0) | (ex == Kx - 1) | (ey == 0) | (ey == Ky - 1)
+    ring = ((ex == 1) | (ex == Kx - 2) | (ey == 1) | (ey == Ky - 2)) & ~bnd
+    inner = ~(bnd | ring)
+    err = lambda a, f, m: np.linalg.norm((a[f] - tv[f])[:, m]) / np.linalg.norm(tv[f][:, m])
+    for f in (1, 2):                                   # the momentum rows
+        assert err(ov, f, bnd) < 2e-14                 # the reference's own statements: almost exact on the boundary elements
+        assert err(mv, f, bnd) > 10 * err(ov, f, bnd)  # element means: 69 x / 25 x of that
+        assert err(mv, f, inner) < 1.5 * err(ov, f, inner)   # invisible in the interior (1.1 x)
+    assert rel_l2(mv[1:], tv[1:]) > 1.5 * rel_l2(ov[1:], tv[1:])    # and enough to leave the 2 x gate as a whole (1.9e-13 vs 9.5e-14)
