@@ -1273,7 +1273,7 @@ int esdg_num_phases(const esdg_ctx* ctx) { return ctx ? ctx->nphases : 0; }
 int esdg_uses_tensor_kernels(const esdg_ctx* ctx) { return ctx ? (int)ctx->use_fast : 0; }
 
 static bool v2_on_walls(const esdg_ctx* ctx) {
-  return ctx->v1 == 0 && !ctx->ph.dbg && ctx->T.N1 >= 2 && ctx->T.N1 <= 8;
+  return (ctx->v1 & ~4) == 0 && !ctx->ph.dbg && ctx->T.N1 >= 2 && ctx->T.N1 <= 8;   // (bit 4 = phase 0 only)
 }
 
 static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs, const LsrkFuse& lf, void* stream,
