@@ -566,7 +566,7 @@ struct esdg_ctx {
   int Np = 0, Nq = 0, Nfq = 0;
   // device storage
   DevBuf d_pair_ij, d_pair_c, d_inc_ptr, d_inc, d_Ef_i, d_Ef_v, d_Ph_i, d_Ph_v, d_Lf_i, d_Lf_v, d_Dr_i, d_Dr_v, d_Ds_i,
-      d_Ds_v, d_Vq, d_Pq, d_geo, d_fnrm, d_fnd, d_fsd, d_mapP, d_bc, d_vlid, d_wJq, d_sendlist, d_partial;
+      d_Ds_v, d_Vq, d_Pq, d_geo, d_fnrm, d_fnd, d_fsd, d_wgeo, d_mapP, d_bc, d_vlid, d_wJq, d_sendlist, d_partial;
   DevBuf t_dbl, t_int, d_G9, d_Jq, d_nrm, d_hdv, d_hdf, d_hdn;
   DevBuf t_nd, t_ni, t_fd, t_fi;   // per-node rows of the v2 tensor kernels
   DevBuf t_rvd, t_rvi, t_rfd, t_rfi;   // packed rows of kt2_rhs (RhsRows)
@@ -940,6 +940,20 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
     UP(d_bc, bcflag);
     if (!vlid.empty()) UP(d_vlid, vlid);
   }
+  // what the reference's viscous operators read node by node (MeshDev::wgeo): CNS on a mesh with walls whose driver
+  // passed at least the Np nodal rows of the metric arrays.  ESDG_WALL_GEOMETRY=element: off (A/B).
+  bool wall_nodal = visc && modal && use_fast && mesh->NmapB > 0 && ld >= Np && Np == Nq;
+  if (const char* env = getenv("ESDG_WALL_GEOMETRY"))
+    if (env[0] == 'e') wall_nodal = false;
+  if (wall_nodal) {
+    std::vector<double> wg((size_t)K * 5 * Np);
+    for (int64_t e = 0; e < K; ++e) {
+      const double* src[5] = {mesh->rxJ + e * ld, mesh->sxJ + e * ld, mesh->ryJ + e * ld, mesh->syJ + e * ld, mesh->J + e * Np};
+      for (int m = 0; m < 5; ++m)
+        for (int i = 0; i < Np; ++i) wg[((size_t)e * 5 + m) * Np + i] = src[m][i];
+    }
+    UP(d_wgeo, wg);
+  }
   if (use_fast) {
     UP(t_dbl, th.dbl); UP(t_int, th.ints);
     c->TT.dbl = c->t_dbl.as<double>();
@@ -1016,6 +1030,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   c->M.K = K; c->M.e_begin = 0; c->M.e_count = K;
   c->M.geo = c->d_geo.as<double>(); c->M.mapP = c->d_mapP.as<int32_t>(); c->M.bc = bcflag.empty() ? nullptr : c->d_bc.as<uint8_t>();
   c->M.fnrm = c->d_fnrm.as<double>(); c->M.fnd = c->d_fnd.as<float>(); c->M.fsd = c->d_fsd.as<float>();
+  c->M.wgeo = wall_nodal ? c->d_wgeo.as<double>() : nullptr;
   c->M.vlid = vlid.empty() ? nullptr : c->d_vlid.as<double>();
   set_interior(c, pl.mapP, K, Nfq);
   c->M.wJq = mesh->wJq ? c->d_wJq.as<double>() : nullptr;

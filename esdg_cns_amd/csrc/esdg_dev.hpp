@@ -85,6 +85,19 @@ struct MeshDev {
   // scaled by the normal (LF wavespeed and penalty: sJ, lambda) the kernels use the mean.
   const float* fnd;
   const float* fsd;
+  // Meshes with walls, CNS, v2 tensor kernels; null otherwise.  dg_grad! / dg_div! (cavity_optimized.jl:549-611) scale NODAL
+  // coefficients by rows 1:Np of the metric arrays and divide them by J[i,e], node by node; on an affine element those arrays
+  // are a constant plus the round-off of the driver's set-up.  In the elements that touch a wall the lifted wall jump dominates
+  // the momentum rows and the reference evaluates it almost exactly, so there that round-off shows (round 3: rhs_viscous! alone
+  // 2.6 ... 8.9 x e_orc with one record per element).  kt2_sigma therefore scales gradient and volume divergence of THOSE
+  // elements in the nodal basis with these arrays: wgeo[K][5][Np] = rxJ, sxJ, ryJ, syJ (rows 1:Np as passed), J.
+  const double* wgeo;
+  // ... those elements cost a multiple of the others and sit at regular distances in the element numbering (every Kx-th
+  // element on the side walls), which resonates with the persistent kernel's stride of one grid per round: the same few
+  // workgroups would take all of them.  With wgeo set, workgroup w takes group k G + ((w + k wall_rot) mod G) in round k
+  // (G = grid size): neighbouring workgroups still work on neighbouring groups, and the costly ones move on by wall_rot
+  // workgroups per round.  0: the plain stride.
+  int32_t wall_rot;
   const double* wJq;       // [K][Nq] (diagnostics) may be null
   // curved (non-affine) hexahedra only, null otherwise: per-node metric terms [K][9][Nh] (row m9 = comp*3 + operator:
   // rxJ sxJ txJ ryJ syJ tyJ rzJ szJ tzJ), J at the quadrature nodes [K][Nq], normals [K][4][Nfq] = nxJ nyJ nzJ sJ

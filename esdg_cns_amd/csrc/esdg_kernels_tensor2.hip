@@ -216,6 +216,49 @@ __device__ __forceinline__ void wall_stress_jump(const double* sn, const double*
   }
 }
 
+// ---- meshes with walls: gradient and volume divergence of the elements that touch a wall, in the NODAL basis --------------
+// dg_grad! / dg_div! (cavity_optimized.jl:549-611) act on nodal coefficients: Dr, Ds, LIFT, then rows 1:Np of the metric
+// arrays and 1/J[i,e] node by node, then Vq.  Everywhere else the kernel works at the Gauss nodes with one geometry record
+// per element (Vq Dr Pq as a 1D operator along the lines) -- the same up to the round-off of the driver's set-up in those
+// arrays (5e-14 relative at 8x8 elements, 5e-13 at 64x64), which shows only where the lifted wall jump dominates and the
+// reference is almost exact: the elements with a boundary node (MeshDev::wgeo).  For those, kt2_sigma takes its Gauss-node
+// pieces -- the two line derivatives and the lift, Vq (Dr VU), Vq (Ds VU), Vq (LIFT ...) -- back to nodal coefficients (Pq),
+// scales them node by node as the reference does, and returns to the Gauss nodes (Vq); the same for the volume part of the
+// divergence.  Pq = IP (x) IP and Vq = IQ (x) IQ by sum factorisation, the 1D operators in LDS (staged at kernel entry).
+//
+// One such product for NP pair planes: stage 1 reads `in` at o1 + k s1 with the weights w1[k], writes `mid` at the lane's own
+// slot; stage 2 reads `mid` at o2 + k s2 with w2[k].  The caller's barrier precedes the call (in complete); one barrier inside.
+template <int N1, int NV, int NP>
+__device__ __forceinline__ void tp_apply(const double* w1, const double* w2, const d2* in, d2* mid, unsigned tv, unsigned o1, unsigned s1,
+                                         unsigned o2, unsigned s2, double* out) {
+  double t[2 * NP];
+#pragma unroll
+  for (int c = 0; c < 2 * NP; ++c) t[c] = 0.0;
+#pragma unroll
+  for (int k = 0; k < N1; ++k) {
+    const double m = w1[k];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const d2 v = in[p * NV + o1 + k * s1];
+      t[2 * p] = __builtin_fma(m, v.x, t[2 * p]); t[2 * p + 1] = __builtin_fma(m, v.y, t[2 * p + 1]);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) mid[p * NV + tv] = make_double2(t[2 * p], t[2 * p + 1]);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 2 * NP; ++c) out[c] = 0.0;
+#pragma unroll
+  for (int k = 0; k < N1; ++k) {
+    const double m = w2[k];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const d2 v = mid[p * NV + o2 + k * s2];
+      out[2 * p] = __builtin_fma(m, v.x, out[2 * p]); out[2 * p + 1] = __builtin_fma(m, v.y, out[2 * p + 1]);
+    }
+  }
+}
+
 #ifndef ESDG_T2_SIGMA_WPE
 #define ESDG_T2_SIGMA_WPE 1   // minimum waves per SIMD asked of the register allocator (A/B hook)
 #endif
@@ -239,8 +282,11 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
   constexpr int NVP = NV + (NV & 1), NFP = NF + (NF & 1);   // single planes padded to an even length: pair planes stay 16-B aligned
   constexpr int NGEO = E * GEO_STRIDE, GPT = (NGEO + G::GT - 1) / G::GT;   // geometry doubles of a group / per thread
   constexpr int R0 = 0, R1 = 8 * NV, RV = R1 + 2 * NV + 2 * NVP, RD = RV + 2 * NV + NVP, RG = RD + 6 * NF,
-                NLDS = RG + GPT * G::GT;
+                RE = RG + GPT * G::GT, RW = RE + (WALLS ? (E + 2) / 2 : 0), NLDS = RW + (WALLS ? 2 * N1 * N1 : 0);
   __shared__ __align__(16) double lds[NLDS];
+  int* sEb = reinterpret_cast<int*>(lds + RE);        // [E] WALLS: element has a boundary node (see wall_dense above)
+  double* sW = lds + RW;                              // WALLS: the 1D operators IQ | IP, row-major (for tp_apply above)
+  static_assert(R0 + 18 * NV <= RG, "scratch of the nodal-basis divergence ends before the geometry records");
   d2* sSg = reinterpret_cast<d2*>(lds + R0);          // [3][NV] sigma pairs
   d2* sS0 = reinterpret_cast<d2*>(lds + R0 + 6 * NV); // [NV] (S^0_0, S^0_1)
   d2* sS1 = reinterpret_cast<d2*>(lds + R1);          // [NV] (S^1_0, S^1_1)
@@ -294,7 +340,11 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
   // Prefetch without a second register set: the loads of the NEXT group go into the registers of the current one right
   // after their last use (x and the geometry are written to LDS first thing; the neighbour traces are consumed by the
   // face-jump stage), so that every load has most of an iteration to land and no copy ever waits for one.
-  int64_t grp = FULL ? (int64_t)blockIdx.x : nfull;
+  // group of this workgroup in round k: k G + w, or (MeshDev::wall_rot) k G + ((w + k rot) mod G)
+  const int64_t rot = (WALLS && FULL) ? (int64_t)M.wall_rot : 0;
+  auto group_of = [&](int64_t k) -> int64_t { return k * (int64_t)gridDim.x + ((int64_t)blockIdx.x + k * rot) % (int64_t)gridDim.x; };
+  int64_t rnd = 0;
+  int64_t grp = FULL ? group_of(0) : nfull;
   double x[4], geo[GPT];
   float2 ndn;        // this lane's face-node normal (nxJ, nyJ) minus the face mean (MeshDev::fnd), prefetched like the rest
   float sdn = 0.f;   // the same for sJ (wall closures only)
@@ -323,18 +373,23 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
 #ifndef ESDG_T2_SIGMA_DEFER_STORES
 #define ESDG_T2_SIGMA_DEFER_STORES 1
 #endif
+  if (WALLS && M.wgeo) {   // IQ | IP for the nodal-basis path (read many barriers further down)
+    constexpr TensorLayout TL(N1);
+    static_assert(TL.IP == TL.IQ + N1 * N1, "IQ and IP are adjacent in the 1D tables");
+    for (int i = tid; i < 2 * N1 * N1; i += G::GT) sW[i] = TT.dbl[TL.IQ + i];
+  }
   double cdv[3] = {0, 0, 0}, csn[3] = {0, 0, 0};
   int64_t ce0 = 0;
   bool cva = false, cfa = false;
   T2_STAMP_INIT;
 #pragma unroll 1
-  for (; grp < ngrp; grp += gridDim.x) {
+  for (; grp < ngrp; grp = FULL ? group_of(++rnd) : ngrp) {
     T2_STAMP(0);
     const int64_t e0 = FULL ? min(M.e_begin + grp * E, e_last) : M.e_begin;
     const int nE = FULL ? E : (int)(e_end - e0);
     const bool vact = FULL || tid < (unsigned)(nE * Nq), fact = FULL || tid < (unsigned)(nE * Nfq);
     // next group, clamped to the last one (harmless re-loads at the end)
-    const int64_t gnx = min(grp + (int64_t)gridDim.x, ngrp - 1);
+    const int64_t gnx = min(FULL ? group_of(rnd + 1) : ngrp, ngrp - 1);
     const int64_t e0n = FULL ? min(M.e_begin + gnx * E, e_last) : M.e_begin;
     const int nEn = FULL ? E : (int)(e_end - e0n);
     const unsigned tvn = tv < (unsigned)(nEn * Nq) ? tv : 0u, tfn = tf < (unsigned)(nEn * Nfq) ? tf : 0u;
@@ -348,6 +403,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
 
     // ---- this group's state and geometry to LDS; their registers take the next group's loads ---------------------------
     d2* sA = reinterpret_cast<d2*>(lds + R0);
+    if (WALLS && tid < (unsigned)E) sEb[tid] = 0;   // (set by the face lanes two barriers further down)
 #pragma unroll
     for (int i = 0; i < GPT; ++i) sGeo[tid + i * G::GT] = geo[i];
     sA[tv] = make_double2(x[0], x[1]);
@@ -415,6 +471,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
       if (WALLS && bcf) {
         const double vfo[3] = {vf0, vf1, vf2};
         wall_exterior_v(vfo, bcf, vlid, nr, ph, vP);
+        sEb[ef] = 1;
       }
       const double h0 = .5 * (vP[0] - vf0), h1 = .5 * (vP[1] - vf1), h2 = .5 * (vP[2] - vf2);
       sDx[tf] = make_double2(nr[0] * h0, nr[0] * h1);     // (duplicate lanes: duplicate writes)
@@ -425,6 +482,8 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
     T2_STAMP(4);
 
     // ---- volume lanes: BR1 gradient, sigma = K(v) grad v --------------------------------------------------------------
+    bool gb = false;   // WALLS: some element of the group has a boundary node (uniform)
+    double wgm[5] = {0, 0, 0, 0, 1};   // ... and then this lane's nodal metric terms and J (MeshDev::wgeo)
     const double* g = sGeo + ev * GEO_STRIDE;     // elements beyond the mesh read the (clamped) staged values: finite, unused
     const double gx0 = g[TT.op0], gy0 = g[2 + TT.op0], gx1 = g[TT.op1], gy1 = g[2 + TT.op1];
     double sgx[3], sgy[3];
@@ -448,16 +507,69 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
         tx[c] = __builtin_fma(gx1, d1[c], gx0 * d0[c]);
         ty[c] = __builtin_fma(gy1, d1[c], gy0 * d0[c]);
       }
+      double lxs[3] = {0, 0, 0}, lys[3] = {0, 0, 0};   // WALLS: the lift on its own (the nodal-basis path below needs it)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {   // lift of the (normal x half jump)s on the four faces at the ends of this node's lines
         const d2 jx = sDx[fq[k]], j4 = sD4[fq[k]], jy = sDy[fq[k]];
-        tx[0] = __builtin_fma(lw[k], jx.x, tx[0]); ty[0] = __builtin_fma(lw[k], jy.x, ty[0]);
-        tx[1] = __builtin_fma(lw[k], jx.y, tx[1]); ty[1] = __builtin_fma(lw[k], jy.y, ty[1]);
-        tx[2] = __builtin_fma(lw[k], j4.x, tx[2]); ty[2] = __builtin_fma(lw[k], j4.y, ty[2]);
+        if (WALLS) {
+          lxs[0] = __builtin_fma(lw[k], jx.x, lxs[0]); lys[0] = __builtin_fma(lw[k], jy.x, lys[0]);
+          lxs[1] = __builtin_fma(lw[k], jx.y, lxs[1]); lys[1] = __builtin_fma(lw[k], jy.y, lys[1]);
+          lxs[2] = __builtin_fma(lw[k], j4.x, lxs[2]); lys[2] = __builtin_fma(lw[k], j4.y, lys[2]);
+        } else {
+          tx[0] = __builtin_fma(lw[k], jx.x, tx[0]); ty[0] = __builtin_fma(lw[k], jy.x, ty[0]);
+          tx[1] = __builtin_fma(lw[k], jx.y, tx[1]); ty[1] = __builtin_fma(lw[k], jy.y, ty[1]);
+          tx[2] = __builtin_fma(lw[k], j4.x, tx[2]); ty[2] = __builtin_fma(lw[k], j4.y, ty[2]);
+        }
+      }
+      if (WALLS) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { tx[c] += lxs[c]; ty[c] += lys[c]; }
       }
       const double iJ = rcp_refined(g[4]);
 #pragma unroll
       for (int c = 0; c < 3; ++c) { tx[c] *= iJ; ty[c] *= iJ; }
+      if (WALLS && M.wgeo) {   // (uniform) elements with a boundary node: the gradient as dg_grad! forms it, in the nodal basis
+        gb = __syncthreads_or(bcf != 0) != 0;
+        if (gb) {
+          // this lane's NODE: metric terms of tensor direction 0 / 1 (x, y parts) and 1/J as the driver holds them; requested
+          // here, needed after the first product below (and once more by the divergence)
+          const double* wg = M.wgeo + (ESDG_EW(e0) + (ev < (unsigned)nE ? ev : 0u)) * 5 * Nq + q;
+          wgm[0] = wg[TT.op0 * Nq]; wgm[1] = wg[(2 + TT.op0) * Nq]; wgm[2] = wg[TT.op1 * Nq]; wgm[3] = wg[(2 + TT.op1) * Nq];
+          wgm[4] = wg[4 * Nq];
+          d2* sc = reinterpret_cast<d2*>(lds + R0);   // 3 + 3 pair planes: the Vq scratch and what will hold S^0, S^1 (all free here)
+          d2* sm = sc + 3 * NV;
+          const double* ipa = sW + N1 * N1 + a * N1;   // IP[a][:], IP[b][:], IQ[a][:]
+          const double* ipb = sW + N1 * N1 + b * N1;
+          const double* iqa = sW + a * N1;
+          const unsigned colq = ev * Nq + b;
+          double o[12];   // derivative of VU along tensor direction 0 [3], direction 1 [3] (Dr / Ds VU), LIFT (.5 (vP - vf) nxJ) [3],
+                          // LIFT (... nyJ) [3], all at this lane's NODE
+          sc[tv] = make_double2(d0[0], d0[1]); sc[NV + tv] = make_double2(d0[2], d1[0]); sc[2 * NV + tv] = make_double2(d1[1], d1[2]);
+          __syncthreads();
+          tp_apply<N1, NV, 3>(ipa, ipb, sc, sm, tv, colq, N1, colb, N1, o);
+          __syncthreads();
+          sc[tv] = make_double2(lxs[0], lxs[1]); sc[NV + tv] = make_double2(lxs[2], lys[0]); sc[2 * NV + tv] = make_double2(lys[1], lys[2]);
+          __syncthreads();
+          tp_apply<N1, NV, 3>(ipa, ipb, sc, sm, tv, colq, N1, colb, N1, o + 6);
+          const double iJn = rcp_refined(wgm[4]);
+          double th[6];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {   // (rxj*ur + sxj*us + surf) / J  (:559-566)
+            th[c] = (__builtin_fma(wgm[2], o[3 + c], wgm[0] * o[c]) + o[6 + c]) * iJn;
+            th[3 + c] = (__builtin_fma(wgm[3], o[3 + c], wgm[1] * o[c]) + o[9 + c]) * iJn;
+          }
+          __syncthreads();
+          sc[tv] = make_double2(th[0], th[1]); sc[NV + tv] = make_double2(th[2], th[3]); sc[2 * NV + tv] = make_double2(th[4], th[5]);
+          __syncthreads();
+          double tn[6];   // VUx = Vq * VUx (:779-780)
+          tp_apply<N1, NV, 3>(iqa, iqa, sc, sm, tv, rowb, 1, colq, N1, tn);
+          if (sEb[ev]) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { tx[c] = tn[c]; ty[c] = tn[3 + c]; }
+          }
+          __syncthreads();   // the scratch planes take sigma below
+        }
+      }
       viscous_stress(V, tx, ty, -ph.lambda, ph.mu, ph.kappa, sgx, sgy);
     }
     {
@@ -488,6 +600,54 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
         p = sS1[colb + N1 * j];
         dv0 = __builtin_fma(dg1[j], p.x, dv0); dv1 = __builtin_fma(dg1[j], p.y, dv1);
         dv2 = __builtin_fma(dg1[j], sS12[colb + N1 * j], dv2);
+      }
+      if (WALLS && gb) {   // (uniform) the same for the volume part of dg_div! (:604-609)
+        double ax[3], bx[3], ay[3], by[3];   // line derivatives of sigma_x, sigma_y at the Gauss nodes: Vq (Dr sigma), Vq (Ds sigma)
+        {
+          d2 p0 = sSg[rowb], p1 = sSg[NV + rowb], p2 = sSg[2 * NV + rowb];
+          ax[0] = dg0[0] * p0.x; ax[1] = dg0[0] * p0.y; ax[2] = dg0[0] * p1.x;
+          ay[0] = dg0[0] * p1.y; ay[1] = dg0[0] * p2.x; ay[2] = dg0[0] * p2.y;
+          d2 r0 = sSg[colb], r1 = sSg[NV + colb], r2 = sSg[2 * NV + colb];
+          bx[0] = dg1[0] * r0.x; bx[1] = dg1[0] * r0.y; bx[2] = dg1[0] * r1.x;
+          by[0] = dg1[0] * r1.y; by[1] = dg1[0] * r2.x; by[2] = dg1[0] * r2.y;
+#pragma unroll
+          for (int j = 1; j < N1; ++j) {
+            p0 = sSg[rowb + j]; p1 = sSg[NV + rowb + j]; p2 = sSg[2 * NV + rowb + j];
+            ax[0] = __builtin_fma(dg0[j], p0.x, ax[0]); ax[1] = __builtin_fma(dg0[j], p0.y, ax[1]); ax[2] = __builtin_fma(dg0[j], p1.x, ax[2]);
+            ay[0] = __builtin_fma(dg0[j], p1.y, ay[0]); ay[1] = __builtin_fma(dg0[j], p2.x, ay[1]); ay[2] = __builtin_fma(dg0[j], p2.y, ay[2]);
+            r0 = sSg[colb + N1 * j]; r1 = sSg[NV + colb + N1 * j]; r2 = sSg[2 * NV + colb + N1 * j];
+            bx[0] = __builtin_fma(dg1[j], r0.x, bx[0]); bx[1] = __builtin_fma(dg1[j], r0.y, bx[1]); bx[2] = __builtin_fma(dg1[j], r1.x, bx[2]);
+            by[0] = __builtin_fma(dg1[j], r1.y, by[0]); by[1] = __builtin_fma(dg1[j], r2.x, by[1]); by[2] = __builtin_fma(dg1[j], r2.y, by[2]);
+          }
+        }
+        __syncthreads();   // every lane is past its reads of the contravariant planes
+        d2* sc = reinterpret_cast<d2*>(lds + R0 + 6 * NV);   // 3 + 3 pair planes behind sigma (S^0, S^1, V, half jumps: all dead here)
+        d2* sm = sc + 3 * NV;
+        const double* ipa = sW + N1 * N1 + a * N1;
+        const double* ipb = sW + N1 * N1 + b * N1;
+        const double* iqa = sW + a * N1;
+        const unsigned colq = ev * Nq + b;
+        double o[12];   // derivatives of sigma_x along direction 0 [3], 1 [3], of sigma_y [3], [3] at this lane's NODE
+        sc[tv] = make_double2(ax[0], ax[1]); sc[NV + tv] = make_double2(ax[2], bx[0]); sc[2 * NV + tv] = make_double2(bx[1], bx[2]);
+        __syncthreads();
+        tp_apply<N1, NV, 3>(ipa, ipb, sc, sm, tv, colq, N1, colb, N1, o);
+        __syncthreads();
+        sc[tv] = make_double2(ay[0], ay[1]); sc[NV + tv] = make_double2(ay[2], by[0]); sc[2 * NV + tv] = make_double2(by[1], by[2]);
+        __syncthreads();
+        tp_apply<N1, NV, 3>(ipa, ipb, sc, sm, tv, colq, N1, colb, N1, o + 6);
+        const double iJn = rcp_refined(wgm[4]);
+        double w[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)   // (rxj*uxr + sxj*uxs + ryj*uyr + syj*uys) / J
+          w[c] = __builtin_fma(wgm[3], o[9 + c], __builtin_fma(wgm[1], o[6 + c], __builtin_fma(wgm[2], o[3 + c], wgm[0] * o[c]))) * iJn;
+        __syncthreads();
+        sc[tv] = make_double2(w[0], w[1]); sc[NV + tv] = make_double2(w[2], 0.0);
+        __syncthreads();
+        double dn[4];
+        tp_apply<N1, NV, 2>(iqa, iqa, sc, sm, tv, rowb, 1, colq, N1, dn);
+        if (sEb[ev]) {   // times the record's J: the last phase multiplies by its reciprocal before Pq
+          dv0 = g[4] * dn[0]; dv1 = g[4] * dn[1]; dv2 = g[4] * dn[2];
+        }
       }
       if (ESDG_T2_SIGMA_DEFER_STORES) {
         cdv[0] = dv0; cdv[1] = dv1; cdv[2] = dv2; cva = vact;
@@ -1196,7 +1356,9 @@ static void launch_sigma2w(const TensorTables& TT, const MeshDev& M, const Phys&
         else if (nb > reserve) nb = reserve;                                                            // strip
       }
     }
-    hipLaunchKernelGGL((t2::kt2_sigma<N1, true, WALLS>), dim3(nb), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);
+    MeshDev Ml = M;
+    Ml.wall_rot = (WALLS && M.wgeo) ? 1 : 0;   // spread the costly wall groups over the workgroups (MeshDev::wall_rot)
+    hipLaunchKernelGGL((t2::kt2_sigma<N1, true, WALLS>), dim3(nb), dim3(G::GT), 0, s, TT, Ml, ph, Q, A_U, B, SG);
   }
   else hipLaunchKernelGGL((t2::kt2_sigma<N1, false, WALLS>), dim3(1), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);   // fewer than E elements
 }

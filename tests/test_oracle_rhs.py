@@ -186,8 +186,9 @@ def test_viscous_operators_read_their_geometry_node_by_node(oracle_lib):
     With adiabatic no-slip walls the lifted wall jump dominates the momentum rows of the boundary elements and the Float64
     evaluation is almost exact there (e_orc ~ 1e-15), so that round-off is visible: the same oracle fed with ELEMENT MEANS of
     those arrays -- what the device kernels hold, one record per element -- moves `rhs_viscous!` by tens of e_orc in exactly
-    those rows, and by nothing measurable in the interior.  This pins the explanation of the two recorded exceptions of the
-    GPU gate (tests/test_gpu_parity.py: VISC_FACTOR_NOSLIP; tools/cavity_visc_attribution.py)."""
+    those rows, and by nothing measurable in the interior.  This pins why kt2_sigma repeats gradient and volume divergence of
+    the elements with a boundary node in the nodal basis with the per-node arrays (MeshDev::wgeo; tests/test_gpu_parity.py:
+    VISC_FACTOR; tools/cavity_visc_attribution.py)."""
     import copy
 
     from common import as_oracle_problem, product_cavity_problem

@@ -1,6 +1,7 @@
 """rhs_viscous! ALONE (esdg_set_parts(2)) on the lid-driven cavity: where does the GPU's error against the binary128 truth sit?
 Per field: relative L2 errors of the GPU and of the Float64 oracle, the share of the squared GPU error carried by elements that
-touch a wall / the lid / a corner, and the worst elements.  Kernel sets: v2 (default), round-1 (ESDG_V1=walls).
+touch a wall / the lid / a corner, and the worst elements.  Kernel sets: v2 (default: nodal-basis viscous operators in the elements with a boundary node), v2 with one geometry record
+per element everywhere (ESDG_WALL_GEOMETRY=element), round-1 (ESDG_V1=walls).
   python tools/cavity_visc_probe.py [N Kx Ky [BCTYPE [nopen] [vlid0]]]     nopen: viscous_dissp = false; vlid0: lid velocity 0"""
 import os
 import sys
@@ -33,15 +34,15 @@ lid = ey == Ky - 1
 kinds = dict(interior=~(wall | lid), wall=wall & ~lid, lid=lid)
 print(f"cavity N={N} {Kx}x{Ky} BCTYPE={BCTYPE} penalty={PEN} vlid={'0' if VL0 else '1'}: rhs_viscous! alone, fields 2..4")
 print("oracle  :", " ".join("%.2e" % (np.linalg.norm(a - t) / np.linalg.norm(t)) for a, t in zip(ov[1:], tv[1:])))
-for tag, env in (("v2", {}), ("round-1", {"ESDG_V1": "walls"})):
-    for k in ("ESDG_V1", "ESDG_FORCE_GENERIC"):
+for tag, env in (("v2", {}), ("v2, one record per element", {"ESDG_WALL_GEOMETRY": "element"}), ("round-1", {"ESDG_V1": "walls"})):
+    for k in ("ESDG_V1", "ESDG_FORCE_GENERIC", "ESDG_WALL_GEOMETRY"):
         os.environ.pop(k, None)
     os.environ.update(env)
     eng = engine.RhsEngine(rd, md, ops, engine.CNS_MODAL, Re=p.Re, mu=p.mu, lam=p.lam, Pr=p.Pr, BCTYPE=BCTYPE, viscous_dissp=PEN,
                            **(dict(vlid=lambda x: 0.0 * x) if VL0 else {}))
     eng.set_parts(2)
     gv = eng.download(eng.rhs(eng.upload(Q)))
-    print(f"{tag:8s}:", " ".join("%.2e" % (np.linalg.norm(a - t) / np.linalg.norm(t)) for a, t in zip(gv[1:], tv[1:])),
+    print(f"{tag:26s}:", " ".join("%.2e" % (np.linalg.norm(a - t) / np.linalg.norm(t)) for a, t in zip(gv[1:], tv[1:])),
           "| gpu - oracle:", " ".join("%.2e" % (np.linalg.norm(a - b) / np.linalg.norm(t)) for a, b, t in zip(gv[1:], ov[1:], tv[1:])))
     for f in range(1, 4):
         eg = ((gv[f] - tv[f]) ** 2).sum(axis=0)          # per element
