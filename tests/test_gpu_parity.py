@@ -132,7 +132,7 @@ VISC_FACTOR = 2.0
 
 
 @pytest.mark.parametrize("BCTYPE", [1, 2, 3])
-@pytest.mark.parametrize("N,Kx,Ky", [(3, 6, 5), (4, 8, 8), (5, 4, 3)])
+@pytest.mark.parametrize("N,Kx,Ky", [(3, 6, 5), (4, 8, 8), (5, 4, 3), (4, 2, 2)])   # (2x2: fewer elements than one group holds)
 def test_cns_wall_boundary_conditions_match_oracle(eng_mod, oracle_lib, BCTYPE, N, Kx, Ky):
     """Lid-driven cavity walls (init_BC_funs, dg2D_CNS_cavity_optimized.jl:135-265): adiabatic no-slip (1),
     isothermal (2), slip (3), lid on y=+1."""
