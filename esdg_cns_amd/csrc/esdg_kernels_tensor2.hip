@@ -939,6 +939,8 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
   constexpr TensorLayout TL(N1);
   static_assert(TL.IP == TL.IQ + N1 * N1, "IQ and IP are adjacent in the 1D tables");
   __shared__ __align__(16) double lds[LD::NLDS];
+  __shared__ int sEbR[WALLS ? GeoR<N1>::E : 1];   // WALLS: element has a boundary node (set by its face lanes; see the end of the kernel)
+  if (WALLS && threadIdx.x < (unsigned)GeoR<N1>::E) sEbR[threadIdx.x] = 0;
   d2* sRec = reinterpret_cast<d2*>(lds + LD::REC);
   d2* sAcc = reinterpret_cast<d2*>(lds + LD::ACC);
   d2* sGf = reinterpret_cast<d2*>(lds + LD::SGF);
@@ -1127,7 +1129,7 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
     }
     // ---- face lanes: interface flux and penalty from the two trace states (registers only) -----------------------------------
     const double* gf = sGeo + ef * GEO_STRIDE;     // (slots of elements beyond the mesh hold the clamped loads: finite, unused)
-    double Gf[4], pnr[3] = {0, 0, 0};
+    double Gf[4], pnr[3] = {0, 0, 0}, gpen[3] = {0, 0, 0};   // (gpen: WALLS, the penalty's share of the face total)
     {
       const double* gm = gf + gfo;
       // (sJ: the face mean unless a wall closure turns it into a unit normal -- it only scales the LF term, a small jump)
@@ -1140,6 +1142,7 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
       if (VISC) {   // penalty tau*[[v]] (:817-837): the projected entropy variables are those OF the trace states
         const double bM = 2 * Gas2<MODAL>::GM1 * qM[3], bP = 2 * Gas2<MODAL>::GM1 * qP[3];
         const double tau = ph.viscous_dissp ? -rcp_refined(-bM) * ph.inv_Re : 0.0;
+        if (WALLS && bcf) sEbR[ef] = 1;
         if (WALLS && bcf) {   // exterior values by the wall closure; third component overridden as in :827-837
           const double vf[3] = {bM * qM[1], bM * qM[2], -bM};
           double vP[3];
@@ -1211,13 +1214,26 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
       const double Jf = gf[4], ws = viscous ? wfac : 0.0;
 #pragma unroll
       for (int c = 0; c < 3; ++c) Gf[c + 1] = __builtin_fma(-ws, __builtin_fma(Jf, pnr[c], .5 * (-bPn[c] - bOwn[c])), Gf[c + 1]);
+      if (WALLS) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gpen[c] = ws * Jf * pnr[c];
+      }
     }
     sGf[tf] = make_double2(Gf[0], Gf[1]);
     sGf[NF + tf] = make_double2(Gf[2], Gf[3]);
-    __syncthreads();
+    // Meshes with walls: the reference divides the nodal coefficients of everything but the penalty by J[i,e] NODE BY NODE
+    // (rhs_inviscid! :518, dg_div! :609); the kernel divides by the record's J at the Gauss nodes.  In the elements with a boundary
+    // node the lifted stress jump of the energy row is large and that difference shows (like the gradient's, see kt2_sigma); there
+    // the result is corrected after Pq: out_i (1 + g_i) - g_i (Pq X)_i, g_i = J/J[i,e] - 1, X = the part that must not be rescaled
+    // (penalty, lifted without 1/J; volume divergence, which kt2_sigma already divided by J[i,e]).
+    bool gb = false;
+    if (WALLS && VISC && MODAL && M.wgeo) gb = __syncthreads_or(bcf != 0) != 0;
+    else __syncthreads();
+    double Jn = 1.0;
+    if (WALLS && gb) Jn = M.wgeo[((e0 + (ev < (unsigned)nE ? ev : 0u)) * 5 + 4) * Nq + q];
 
     // ---- collocated rhs: -(Ph*QF + Lf*flux)/J  (+ viscous divergence and penalty) ---------------------------------------------
-    double R[4];
+    double R[4], RX[4] = {0, 0, 0, 0}, gJ = 1.0;
     {
       const double* g = sGeo + ev * GEO_STRIDE;
       const double iJ = rcp_refined(g[4]);
@@ -1241,6 +1257,22 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
         const double vs = viscous ? iJ : 0.0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) R[c + 1] = __builtin_fma(dvs[c], vs, R[c + 1]);
+        if (WALLS && gb) {   // (uniform) X = lift of the penalty + volume divergence, at the Gauss nodes
+          __syncthreads();   // every lane is past its gather of the accumulator planes, whose space takes the penalty's face values
+          d2* sP = sAcc + 2 * NV;   // (behind the two pair planes Pq uses below)
+          sP[tf] = make_double2(gpen[0], gpen[1]);
+          sP[NF + tf] = make_double2(gpen[2], 0.0);
+          __syncthreads();
+          double lp[3] = {0, 0, 0};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const d2 g0 = sP[fq[k]], g1 = sP[NF + fq[k]];
+            lp[0] = __builtin_fma(pw[k], g0.x, lp[0]); lp[1] = __builtin_fma(pw[k], g0.y, lp[1]); lp[2] = __builtin_fma(pw[k], g1.x, lp[2]);
+          }
+#pragma unroll
+          for (int c = 0; c < 3; ++c) RX[c + 1] = __builtin_fma(dvs[c], vs, lp[c] * iJ);
+          gJ = g[4];
+        }
       }
     }
     T2_STAMP(6);     // barrier + gather + lift
@@ -1249,40 +1281,52 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
     if (MODAL) {
       d2* sA = sRec;                       // records are dead (all lanes are past the barrier after the flux rounds)
       d2* sB = sAcc;                       // accumulators: read above, rewritten only after the next barrier
-      sA[tv] = make_double2(R[0], R[1]);
-      sA[NV + tv] = make_double2(R[2], R[3]);
       lds[LD::TABP + tabo] = tabp;   // IP into the (dead) third record plane
-      __syncthreads();
-      double ipl[N1P], iph[N1P];
-      {
-        const d2* rl = reinterpret_cast<const d2*>(lds + LD::TABP + a * N1P);
-        const d2* rh = reinterpret_cast<const d2*>(lds + LD::TABP + b * N1P);
+      auto pq_apply = [&](const double* Rin, double* o) {
+        sA[tv] = make_double2(Rin[0], Rin[1]);
+        sA[NV + tv] = make_double2(Rin[2], Rin[3]);
+        __syncthreads();
+        double ipl[N1P], iph[N1P];
+        {
+          const d2* rl = reinterpret_cast<const d2*>(lds + LD::TABP + a * N1P);
+          const d2* rh = reinterpret_cast<const d2*>(lds + LD::TABP + b * N1P);
 #pragma unroll
-        for (int i = 0; i < N1P / 2; ++i) { const d2 t = rl[i], u = rh[i]; ipl[2 * i] = t.x; ipl[2 * i + 1] = t.y; iph[2 * i] = u.x; iph[2 * i + 1] = u.y; }
-      }
-      {   // stage 1: W[a + N1 b] = sum_j IP[a,j] R[b + N1 j]   (this lane: column b of R)
-        const d2* rr = sA + colq;
-        d2 p = rr[0], t = rr[NV];
-        double w0 = ipl[0] * p.x, w1 = ipl[0] * p.y, w2 = ipl[0] * t.x, w3 = ipl[0] * t.y;
-#pragma unroll
-        for (int j = 1; j < N1; ++j) {
-          p = rr[N1 * j]; t = rr[NV + N1 * j];
-          w0 = __builtin_fma(ipl[j], p.x, w0); w1 = __builtin_fma(ipl[j], p.y, w1);
-          w2 = __builtin_fma(ipl[j], t.x, w2); w3 = __builtin_fma(ipl[j], t.y, w3);
+          for (int i = 0; i < N1P / 2; ++i) { const d2 t = rl[i], u = rh[i]; ipl[2 * i] = t.x; ipl[2 * i + 1] = t.y; iph[2 * i] = u.x; iph[2 * i + 1] = u.y; }
         }
-        sB[tv] = make_double2(w0, w1);
-        sB[NV + tv] = make_double2(w2, w3);
-      }
-      __syncthreads();
-      {   // stage 2: out[a + N1 b] = sum_i IP[b,i] W[a + N1 i]   (this lane: column a of W)
-        const d2* rr = sB + colb;
-        d2 p = rr[0], t = rr[NV];
-        out[0] = iph[0] * p.x; out[1] = iph[0] * p.y; out[2] = iph[0] * t.x; out[3] = iph[0] * t.y;
+        {   // stage 1: W[a + N1 b] = sum_j IP[a,j] R[b + N1 j]   (this lane: column b of R)
+          const d2* rr = sA + colq;
+          d2 p = rr[0], t = rr[NV];
+          double w0 = ipl[0] * p.x, w1 = ipl[0] * p.y, w2 = ipl[0] * t.x, w3 = ipl[0] * t.y;
 #pragma unroll
-        for (int i = 1; i < N1; ++i) {
-          p = rr[N1 * i]; t = rr[NV + N1 * i];
-          out[0] = __builtin_fma(iph[i], p.x, out[0]); out[1] = __builtin_fma(iph[i], p.y, out[1]);
-          out[2] = __builtin_fma(iph[i], t.x, out[2]); out[3] = __builtin_fma(iph[i], t.y, out[3]);
+          for (int j = 1; j < N1; ++j) {
+            p = rr[N1 * j]; t = rr[NV + N1 * j];
+            w0 = __builtin_fma(ipl[j], p.x, w0); w1 = __builtin_fma(ipl[j], p.y, w1);
+            w2 = __builtin_fma(ipl[j], t.x, w2); w3 = __builtin_fma(ipl[j], t.y, w3);
+          }
+          sB[tv] = make_double2(w0, w1);
+          sB[NV + tv] = make_double2(w2, w3);
+        }
+        __syncthreads();
+        {   // stage 2: out[a + N1 b] = sum_i IP[b,i] W[a + N1 i]   (this lane: column a of W)
+          const d2* rr = sB + colb;
+          d2 p = rr[0], t = rr[NV];
+          o[0] = iph[0] * p.x; o[1] = iph[0] * p.y; o[2] = iph[0] * t.x; o[3] = iph[0] * t.y;
+#pragma unroll
+          for (int i = 1; i < N1; ++i) {
+            p = rr[N1 * i]; t = rr[NV + N1 * i];
+            o[0] = __builtin_fma(iph[i], p.x, o[0]); o[1] = __builtin_fma(iph[i], p.y, o[1]);
+            o[2] = __builtin_fma(iph[i], t.x, o[2]); o[3] = __builtin_fma(iph[i], t.y, o[3]);
+          }
+        }
+      };
+      pq_apply(R, out);
+      if (WALLS && gb) {   // (uniform) second product for the part that keeps the record's J; correction per element and node
+        double ox[4];
+        pq_apply(RX, ox);
+        if (sEbR[ev]) {
+          const double gam = __builtin_fma(gJ, rcp_refined(Jn), -1.0);
+#pragma unroll
+          for (int f = 0; f < 4; ++f) out[f] = __builtin_fma(gam, out[f] - ox[f], out[f]);
         }
       }
     } else {
