@@ -127,7 +127,7 @@ def test_modal_euler_matches_oracle_inviscid(eng_mod, oracle_lib):
 # 64x64), and the kernels held one geometry record per element.  With BCTYPE=1 the lifted wall jump dominates those rows and the
 # reference evaluates it almost exactly (e_orc 8e-16 / 8e-15 in fields 2 / 3), so the geometry round-off showed.  kt2_sigma now
 # repeats gradient and volume divergence of the elements with a boundary node in the nodal basis with the driver's per-node
-# arrays (MeshDev::wgeo): 1.3 x at 8x8 and 16x16.  ESDG_WALL_GEOMETRY=element switches that off (A/B; the old figures come back).
+# arrays (MeshDev::wgeo), kt2_rhs divides their result by the per-node J: 1.2-1.3 x from 8x8 to 128x128.  ESDG_WALL_GEOMETRY=element switches that off (A/B; the old figures come back).
 VISC_FACTOR = 2.0
 
 
