@@ -147,6 +147,31 @@ def test_ranged_launches_match_the_full_launch(E, form, N, Kx, Ky):
         E.check(eng.L.esdg_rhs_phase_range(eng.ctx, 0, K - 1, 2, C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr()), None))
 
 
+@pytest.mark.parametrize("N,Kx,Ky,BCTYPE", [(4, 12, 9, 1), (3, 10, 7, 3), (2, 9, 8, 2)])
+def test_ranged_launches_match_the_full_launch_on_wall_meshes(E, N, Kx, Ky, BCTYPE):
+    """The same on the lid-driven cavity: the wall instantiations repeat the viscous operators of the elements with a boundary
+    node in the nodal basis (MeshDev::wgeo) -- a decision taken per ELEMENT inside a branch taken per GROUP, so the result of an
+    element must not depend on which other elements share its group."""
+    from common import product_cavity_problem
+    rd, md, ops, Q = product_cavity_problem(N, Kx, Ky)
+    eng = E.RhsEngine(rd, md, ops, E.CNS_MODAL, BCTYPE=BCTYPE)
+    Qd = eng.upload(Q)
+    ref = eng.rhs(Qd).clone()
+    K = Kx * Ky
+    rng = np.random.default_rng(K + N)
+    cuts = sorted(set([0, K] + [int(c) for c in rng.integers(1, K, size=5)]))
+    pieces = [(a, b - a) for a, b in zip(cuts[:-1], cuts[1:])]
+    out = torch.full_like(Qd, float("nan"))
+    for ph in range(eng.nphases):
+        for i in rng.permutation(len(pieces)):
+            e0, n = pieces[i]
+            E.check(eng.L.esdg_rhs_phase_range(eng.ctx, ph, e0, n, C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    rel = float((out - ref).abs().max() / ref.abs().max())
+    print(f"ranged cavity N={N} BCTYPE={BCTYPE}: pieces {pieces}, max rel diff {rel:.2e}")
+    assert torch.equal(out, ref), rel
+
+
 def test_trailing_idle_waves_read_no_geometry_past_the_mesh(E):
     """N=2 at 512x512: 262144 elements are not a multiple of the 20 elements a workgroup takes, so the last workgroup
     has waves without elements.  Their lanes used to form geometry addresses from an element index past the mesh
