@@ -139,3 +139,23 @@ def test_julia_setupdg_stand_in_uses_what_exists():
     asked |= set(re.findall(r'setup_(?:array|map)\(s, "([A-Za-z0-9_]+)"\)', jl))
     missing = {a for a in asked if a not in served and a not in ("VX", "VY", "VZ")}
     assert not missing, missing
+
+
+def test_julia_commonutils_stand_in_exports_what_the_drivers_call():
+    """julia/CommonUtils.jl (un-runnable here): the names the reference's drivers import from CommonUtils
+    (/root/reference/src/CommonUtils.jl:14-24; uses at dg2D_euler_quad.jl:42, 76, 94, dg3D_euler_hex.jl:64, 81, 115) are exported and
+    defined, and the LSRK45 coefficients are the ones the Python host uses."""
+    from esdg_cns_amd import setup_dg as sd
+    jl = open(os.path.join(ROOT, "julia", "CommonUtils.jl")).read()
+    exported = set(re.findall(r"[A-Za-z_!0-9]+", re.search(r"^export (.*)$", jl, flags=re.M).group(1)))
+    need = {"meshgrid", "geometric_factors", "build_periodic_boundary_maps", "rk45_coeffs", "unzip", "eye", "speye"}
+    assert need <= exported
+    for name in need:
+        assert re.search(r"^(function )?" + re.escape(name) + r"\(", jl, flags=re.M), name
+    body = re.search(r"function rk45_coeffs\(\).*?^end", jl, flags=re.S | re.M).group(0)
+    fracs = [float(a) / float(b) for a, b in re.findall(r"(-?[0-9]+\.0) / ([0-9]+\.0)", body)]
+    a, b, c = sd.rk45_coeffs()
+    want = list(a[1:]) + list(b) + list(c[1:5])
+    assert len(fracs) == len(want) and all(abs(x - y) <= 1e-16 * abs(y) for x, y in zip(fracs, want))
+    assert jl.count("(") == jl.count(")") and jl.count("[") == jl.count("]")
+    assert len(re.findall(r"^function ", jl, flags=re.M)) + len(re.findall(r"^module ", jl, flags=re.M)) == len(re.findall(r"^end", jl, flags=re.M))
