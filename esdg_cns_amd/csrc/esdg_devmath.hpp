@@ -62,6 +62,24 @@ __device__ __forceinline__ double sqrt_fast(double x) {
 // pressure of the NORMAL kinetic energy only, sqrt(|u_n|) quirk Q1) for the face normal (nx, ny) / sJ.  gm1 = gamma - 1.
 __device__ __forceinline__ void trace_rest(double* q, double nx, double ny, double isJ, double gm1);
 
+// Wave issue priority (s_setprio, 0 = default ... 3) at the two ends of a one-shot workgroup's life: PRIO_ENTRY while a new
+// workgroup computes its addresses and issues its global loads, PRIO_EXIT from the gather / projection / store stage on.  0 = no
+// instruction.  Measured in round 3 (profiles/experiments/r03_prio_ab.log): entry priority 3 takes 6 % off the hex phase-0 kernel
+// kh_project (default on there, ESDG_PRIO_KH_PROJECT) and ADDS 11 % to the 2D phase-0 kernel kt2_project, 1-2 % to kh_rhs, nothing
+// to kt2_rhs; exit priority moves nothing anywhere -- so the generic hooks stay off (A/B: -DESDG_PRIO_ENTRY=n -DESDG_PRIO_EXIT=n).
+#ifndef ESDG_PRIO_ENTRY
+#define ESDG_PRIO_ENTRY 0
+#endif
+#ifndef ESDG_PRIO_EXIT
+#define ESDG_PRIO_EXIT 0
+#endif
+#ifndef ESDG_PRIO_KH_PROJECT
+#define ESDG_PRIO_KH_PROJECT 3
+#endif
+template <int P = ESDG_PRIO_ENTRY> __device__ __forceinline__ void prio_entry_begin() { if (P > 0) __builtin_amdgcn_s_setprio(P); }
+template <int P = ESDG_PRIO_ENTRY> __device__ __forceinline__ void prio_entry_end() { if (P > 0) __builtin_amdgcn_s_setprio(0); }
+__device__ __forceinline__ void prio_exit() { if (ESDG_PRIO_EXIT > 0) __builtin_amdgcn_s_setprio(ESDG_PRIO_EXIT); }
+
 __device__ __forceinline__ void lds_add(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }

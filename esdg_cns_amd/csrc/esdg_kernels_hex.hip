@@ -200,6 +200,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_project(HexTables HT, MeshDev M,
   const int64_t ec = active ? e : M.e_begin + M.e_count - 1;
   const bool vin = lane < Nq;
   double U[HEX_NFLD];
+  prio_entry_begin<ESDG_PRIO_KH_PROJECT>();
   TableRegs<N1> tr;
   tr.load(HT);
   {
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_project(HexTables HT, MeshDev M,
 #pragma unroll
     for (int c = 0; c < HEX_NFLD; ++c) U[c] = Q[(int64_t)c * M.K * Nq + ec * Nq + lu];
   }
+  prio_entry_end<ESDG_PRIO_KH_PROJECT>();
   tr.store(sTab, sInt);
   double q[7], V[HEX_NFLD];
   prim_logs3(U, q);
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
   double rm[HEX_AU_NC], rp[HEX_AU_NC];
   const int fc0 = lane < Nfq ? lane : Nfq - 1;
   const int64_t nm0 = ec * Nfq + fc0;
+  prio_entry_begin();
   const int64_t np0 = M.mapP[nm0];
   TableRegs<N1> tr;
   tr.load(HT);
@@ -327,6 +330,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
     kf0 = M.hdf[nm0];
     kn0 = M.hdn[nm0];
   }
+  prio_entry_end();
   sGeo[wv][gl] = geo_r;
   tr.store(sTab, sInt);
 #pragma unroll
@@ -572,6 +576,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
     }
   }
   __syncthreads();
+  prio_exit();
 
   // ---- Ph*QF + Lf*flux, -(.)/J (:198-212) -------------------------------------------------------------
   if (vin) {

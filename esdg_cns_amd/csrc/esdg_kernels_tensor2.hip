@@ -262,6 +262,16 @@ __device__ __forceinline__ void tp_apply(const double* w1, const double* w2, con
 #ifndef ESDG_T2_SIGMA_WPE
 #define ESDG_T2_SIGMA_WPE 1   // minimum waves per SIMD asked of the register allocator (A/B hook)
 #endif
+// kt2_sigma at N1 = 5 without walls: the per-lane rows of IQ and of the face extrapolation (20 VGPRs held across the persistent
+// loop) live in LDS and are read at the point of use, which brings the kernel from 184 to <= 168 VGPRs = three waves per SIMD
+// (ESDG_T2_SIGMA_ROWS_LDS=0: rows in registers, two waves per SIMD, the form of every other instantiation).
+#ifndef ESDG_T2_SIGMA_ROWS_LDS
+#define ESDG_T2_SIGMA_ROWS_LDS 0
+#endif
+template <int N1, bool WALLS> struct SigmaCfg {
+  static constexpr bool ROWS_LDS = ESDG_T2_SIGMA_ROWS_LDS && N1 == 5 && !WALLS;
+  static constexpr int WPE = ROWS_LDS ? 3 : ESDG_T2_SIGMA_WPE;
+};
 // FULL = true: persistent over the complete groups of the launch's element range; every lane holds valid data (lanes
 // beyond a group's slots duplicate slot tid - NV / tid % NF), so nothing is masked -- duplicate lanes store the same
 // value to the same address -- and no branch hides the outstanding-store count from the compiler's s_waitcnt placement.
@@ -269,7 +279,7 @@ __device__ __forceinline__ void tp_apply(const double* w1, const double* w2, con
 // WALLS: boundary nodes (M.bc): exterior entropy variables by the wall closure; at a boundary node B holds MINUS the
 // prescribed stress jump, so that the last phase's .5*(-B[mapP] - B[own]) with mapP = own gives the jump unchanged.
 template <int N1, bool FULL, bool WALLS>
-__global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
+__global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_sigma(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                         const double* __restrict__ A_U, double* __restrict__ B,
                                                         double* __restrict__ SG) {
   using G = Geo<N1>;
@@ -282,7 +292,10 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
   constexpr int NVP = NV + (NV & 1), NFP = NF + (NF & 1);   // single planes padded to an even length: pair planes stay 16-B aligned
   constexpr int NGEO = E * GEO_STRIDE, GPT = (NGEO + G::GT - 1) / G::GT;   // geometry doubles of a group / per thread
   constexpr int R0 = 0, R1 = 8 * NV, RV = R1 + 2 * NV + 2 * NVP, RD = RV + 2 * NV + NVP, RG = RD + 6 * NF,
-                RE = RG + GPT * G::GT, RW = RE + (WALLS ? (E + 2) / 2 : 0), NLDS = RW + (WALLS ? 2 * N1 * N1 : 0);
+                RE = RG + GPT * G::GT, RW = RE + (WALLS ? (E + 2) / 2 : 0), RT = RW + (WALLS ? 2 * N1 * N1 : 0);
+  constexpr bool ROWS_LDS = SigmaCfg<N1, WALLS>::ROWS_LDS;
+  constexpr int N1P = N1 + (N1 & 1);                   // rows padded to an even length: N1P / 2 ds_read_b128 per row
+  constexpr int RTQ = RT + (RT & 1), RTE = RTQ + Nq * N1P, NLDS = ROWS_LDS ? RTE + Nfq * N1P : RT;
   __shared__ __align__(16) double lds[NLDS];
   int* sEb = reinterpret_cast<int*>(lds + RE);        // [E] WALLS: element has a boundary node (see wall_dense above)
   double* sW = lds + RW;                              // WALLS: the 1D operators IQ | IP, row-major (for tp_apply above)
@@ -321,9 +334,25 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
   const int* ni_ = TT.node_i + q;
   const double* fd_ = TT.face_d + fn;
   const int* fi_ = TT.face_i + fn;
-  double cq[N1], dg0[N1], dg1[N1], ee[N1], lw[4];
+  double cq_r[N1], dg0[N1], dg1[N1], ee_r[N1], lw[4];
 #pragma unroll
-  for (int i = 0; i < N1; ++i) { cq[i] = nd_[(NL.IQ + i) * Nq]; dg0[i] = nd_[(NL.DG0 + i) * Nq]; dg1[i] = nd_[(NL.DG1 + i) * Nq]; ee[i] = fd_[(FL.EE + i) * Nfq]; }
+  for (int i = 0; i < N1; ++i) { cq_r[i] = nd_[(NL.IQ + i) * Nq]; dg0[i] = nd_[(NL.DG0 + i) * Nq]; dg1[i] = nd_[(NL.DG1 + i) * Nq]; ee_r[i] = fd_[(FL.EE + i) * Nfq]; }
+  if (ROWS_LDS) {   // row q of IQ's per-node table and row fn of the face extrapolation, by every lane that holds one (same values)
+#pragma unroll
+    for (int i = 0; i < N1; ++i) { lds[RTQ + q * N1P + i] = cq_r[i]; lds[RTE + fn * N1P + i] = ee_r[i]; }
+    if (N1P > N1) { lds[RTQ + q * N1P + N1] = 0.0; lds[RTE + fn * N1P + N1] = 0.0; }
+  }
+  // (rows in registers: the arrays themselves; rows in LDS: re-read where they are used, first after the loop's first barrier)
+  auto row_of = [&](const double* reg, int base, double* out) {
+    if (ROWS_LDS) {
+      const d2* r = reinterpret_cast<const d2*>(lds + base);
+#pragma unroll
+      for (int i = 0; i < N1P / 2; ++i) { const d2 t = r[i]; out[2 * i] = t.x; if (2 * i + 1 < N1) out[2 * i + 1] = t.y; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < N1; ++i) out[i] = reg[i];
+    }
+  };
   unsigned fq[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) { lw[k] = nd_[(NL.LW + k) * Nq]; fq[k] = ev * Nfq + ni_[(NL.FQ + k) * Nq]; }
@@ -431,7 +460,11 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
 
     // ---- state at the Gauss node, entropy variables 2..4 --------------------------------------------------------------
     double U[4];
-    vq_apply<N1, NV>(cq, sA, reinterpret_cast<d2*>(lds + R0 + 4 * NV), reinterpret_cast<d2*>(lds + R0 + 6 * NV), tv, rowb, ev * Nq + b, nullptr, U);
+    {   // (a lane reads the row it staged itself -- other lanes' copies of it hold the same values: no barrier needed)
+      double cq[N1];
+      row_of(cq_r, RTQ + q * N1P, cq);
+      vq_apply<N1, NV>(cq, sA, reinterpret_cast<d2*>(lds + R0 + 4 * NV), reinterpret_cast<d2*>(lds + R0 + 6 * NV), tv, rowb, ev * Nq + b, nullptr, U);
+    }
     T2_STAMP(2);
     double V[3];
     {
@@ -458,6 +491,8 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
         up0 = upn[0]; up1 = upn[1];
         __builtin_amdgcn_sched_barrier(0);
       }
+      double ee[N1];
+      row_of(ee_r, RTE + fn * N1P, ee);
       d2 p = sVp[fnode0];
       double vf0 = ee[0] * p.x, vf1 = ee[0] * p.y, vf2 = ee[0] * sV4[fnode0];
 #pragma unroll
@@ -661,6 +696,8 @@ __global__ __launch_bounds__(Geo<N1>::GT, ESDG_T2_SIGMA_WPE) void kt2_sigma(Tens
     {
       const double* gn = nr;
       const double nx = gn[0], ny = gn[1];
+      double ee[N1];
+      row_of(ee_r, RTE + fn * N1P, ee);
       d2 p0 = sSg[fnode0], p1 = sSg[NV + fnode0], p2 = sSg[2 * NV + fnode0];
       double fx0 = ee[0] * p0.x, fx1 = ee[0] * p0.y, fx2 = ee[0] * p1.x, fy0 = ee[0] * p1.y, fy1 = ee[0] * p2.x, fy2 = ee[0] * p2.y;
 #pragma unroll
@@ -838,6 +875,7 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_project(TensorTables TT, Mesh
   constexpr NodeLayout NL(N1);
   constexpr FaceLayout FL(N1);
   __shared__ __align__(16) double lds[8 * NV];   // Vq scratch A | B0 | B1 (pair planes), then the entropy variables (2 pair planes)
+  prio_entry_begin();
   d2* sA = reinterpret_cast<d2*>(lds);
   d2* sB0 = reinterpret_cast<d2*>(lds + 4 * NV);
   d2* sB1 = reinterpret_cast<d2*>(lds + 6 * NV);
@@ -862,6 +900,7 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_project(TensorTables TT, Mesh
 #pragma unroll
   for (int i = 0; i < N1; ++i) { cq[i] = MODAL ? nd_[(NL.IQ + i) * Nq] : 0.0; ee[i] = fd_[(FL.EE + i) * Nfq]; }
   const unsigned fnode0 = ef * Nq + fi_[(FL.NODE0) * Nfq], fstride = fi_[(FL.STRIDE) * Nfq];
+  prio_entry_end();
 
   double U[4];
   if (MODAL) {
@@ -877,6 +916,7 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_project(TensorTables TT, Mesh
   sA[tv] = make_double2(V[0], V[1]);
   sA[NV + tv] = make_double2(V[2], V[3]);
   __syncthreads();
+  prio_exit();
   // face lanes: Vf = Ef * V along the node's line, then the primitive state of u(Vf)
   d2 p0 = sA[fnode0], p1 = sA[NV + fnode0];
   double Vf[4] = {ee[0] * p0.x, ee[0] * p0.y, ee[0] * p1.x, ee[0] * p1.y};
@@ -961,6 +1001,7 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
   const int64_t e0 = ESDG_EW(e0r);
   const bool vact = tid < (unsigned)(nE * Nq);
   constexpr RhsRows RR(N1);
+  prio_entry_begin();
   T2_STAMP_INIT;
 #ifdef ESDG_T2_POISON   // diagnostic build: LDS starts as NaN, so a read of a slot nobody wrote shows in the result
   for (int i = tid; i < LD::NLDS; i += G::GT) lds[i] = __builtin_nan("");
@@ -1045,6 +1086,7 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
       const d2 m = aM[c], p = aP[c];
       qM[2 * c] = m.x; qM[2 * c + 1] = m.y; qP[2 * c] = p.x; qP[2 * c + 1] = p.y;
     }
+  prio_entry_end();
 
   {
     // ---- state and geometry to LDS ----------------------------------------------------------------------------------------
@@ -1229,6 +1271,7 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
     bool gb = false;
     if (WALLS && VISC && MODAL && M.wgeo) gb = __syncthreads_or(bcf != 0) != 0;
     else __syncthreads();
+    prio_exit();
     double Jn = 1.0;
     if (WALLS && gb) Jn = M.wgeo[((e0 + (ev < (unsigned)nE ? ev : 0u)) * 5 + 4) * Nq + q];
 
