@@ -935,6 +935,13 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_project(TensorTables TT, Mesh
   }
 }
 
+// kt2_rhs: partner records read one flux round ahead (A/B hook, off).  Measured in round 3 (profiles/experiments/
+// r03_rhs_prefetch_ab.log): N = 4 nothing (0.392-0.397 vs 0.396-0.398 ms), N = 2, 3 -1.5 % of the kernel, N = 6 +15 % (its 12
+// registers push the N1 = 7 instantiation from 166 to 178 VGPRs = from three waves per SIMD to two; N1 = 6 would spill).
+#ifndef ESDG_T2_PREFETCH_REC
+#define ESDG_T2_PREFETCH_REC 0
+#endif
+template <int N1> struct RhsPrefetch { static constexpr bool ON = ESDG_T2_PREFETCH_REC && N1 <= 5; };
 template <int N1, bool MODAL, bool VISC> struct RhsLds2 {
   using G = GeoR<N1>;
   static constexpr NodeLayout NL = NodeLayout(N1);
@@ -970,6 +977,7 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
   constexpr NodeLayout NL(N1);
   constexpr FaceLayout FL(N1);
   constexpr int NFULL = NL.NFULL, NRND = NL.NRND, NVV = LD::NVV;
+  constexpr bool PFR = RhsPrefetch<N1>::ON;
   constexpr int NGEO = E * GEO_STRIDE, GPT = (NGEO + G::GT - 1) / G::GT;
   // 1D operators IQ (Gauss nodes from nodal values) and IP (back), rows padded to an even length: a lane reads row a / b
   // as N1P / 2 ds_read_b128 at the point of use instead of holding per-lane copies in registers across the flux rounds.
@@ -1133,11 +1141,20 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
       const double* g = sGeo + ev * GEO_STRIDE;
       const double gx0 = 2 * g[TT.op0], gy0 = 2 * g[2 + TT.op0], gx1 = 2 * g[TT.op1], gy1 = 2 * g[2 + TT.op1];
       // volume-volume rounds: pair (pos, pos + i + 1 mod N1) of direction d; share of the partner -> plane set d * NVV + i / 2
+      // (ESDG_T2_PREFETCH_REC: the partner record of round r + 1 is read before round r's flux is evaluated -- the wave-uniform
+      // variants of ec_flux_dir are branches, across which hipcc does not move the next round's ds_reads up by itself, so every
+      // round started with an exposed LDS round trip)
+      d2 nx0, nx1, nx2;
+      if (PFR && NFULL > 0) { nx0 = sRec[pid[0]]; nx1 = sRec[NV + pid[0]]; nx2 = sRec[2 * NV + pid[0]]; }
 #pragma unroll
       for (int r = 0; r < 2 * NFULL; ++r) {
         constexpr int NFD = NFULL > 0 ? NFULL : 1;     // (N1 = 2 has no full round: the loop is empty)
         const int d = r / NFD, i = r % NFD;
-        const d2 p0 = sRec[pid[r]], p1 = sRec[NV + pid[r]], p2 = sRec[2 * NV + pid[r]];
+        d2 p0, p1, p2;
+        if (PFR) {
+          p0 = nx0; p1 = nx1; p2 = nx2;
+          if (r + 1 < 2 * NFULL + (N1 % 2 == 0 ? 1 : 0)) { nx0 = sRec[pid[r + 1]]; nx1 = sRec[NV + pid[r + 1]]; nx2 = sRec[2 * NV + pid[r + 1]]; }
+        } else { p0 = sRec[pid[r]]; p1 = sRec[NV + pid[r]]; p2 = sRec[2 * NV + pid[r]]; }
         const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
         double Fd[4];
         ec_flux_dir<MODAL>(qh, qj, svv[r] * (d ? gx1 : gx0), svv[r] * (d ? gy1 : gy0), Fd);
@@ -1151,7 +1168,9 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
       }
       if (N1 % 2 == 0) {   // antipodal pairs: a node serves direction `ad` (one endpoint of every such pair does)
         constexpr int r = 2 * NFULL;
-        const d2 p0 = sRec[pid[r]], p1 = sRec[NV + pid[r]], p2 = sRec[2 * NV + pid[r]];
+        d2 p0, p1, p2;
+        if (PFR && NFULL > 0) { p0 = nx0; p1 = nx1; p2 = nx2; }
+        else { p0 = sRec[pid[r]]; p1 = sRec[NV + pid[r]]; p2 = sRec[2 * NV + pid[r]]; }
         const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
         double Fd[4];
         ec_flux_dir<MODAL>(qh, qj, svv[r] * (ad ? gx1 : gx0), svv[r] * (ad ? gy1 : gy0), Fd);
@@ -1232,10 +1251,16 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
       {
         const double gxf = 2 * gf[opf], gyf = 2 * gf[2 + opf];
         const d2* accf = sAcc + (LD::NACC - 2 + fdir) * 2 * NV;
+        d2 nx0, nx1, nx2;
+        if (PFR) { nx0 = sRec[fnode0]; nx1 = sRec[NV + fnode0]; nx2 = sRec[2 * NV + fnode0]; }
 #pragma unroll
         for (int j = 0; j < N1; ++j) {
           const unsigned n = fnode0 + j * fstride;
-          const d2 p0 = sRec[n], p1 = sRec[NV + n], p2 = sRec[2 * NV + n];
+          d2 p0, p1, p2;
+          if (PFR) {
+            p0 = nx0; p1 = nx1; p2 = nx2;
+            if (j + 1 < N1) { const unsigned nn = n + fstride; nx0 = sRec[nn]; nx1 = sRec[NV + nn]; nx2 = sRec[2 * NV + nn]; }
+          } else { p0 = sRec[n]; p1 = sRec[NV + n]; p2 = sRec[2 * NV + n]; }
           const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
           double vv[4];
           ec_flux_dir<MODAL>(qj, qM, svf[j] * gxf, svf[j] * gyf, vv);
