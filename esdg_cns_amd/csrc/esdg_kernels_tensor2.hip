@@ -75,6 +75,22 @@ __device__ __forceinline__ void viscous_stress(const double* v, const double* tx
 // 16 B = conflict-free ds_read_b128 / ds_write_b128) plus a plane of doubles for an odd component.
 typedef double2 d2;
 
+// Workgroup -> element group, XCD-contiguous (ESDG_T2_XCD_REMAP, A/B hook): the dispatcher deals consecutive workgroups to the 8
+// XCDs in turn, so with group = blockIdx the five elements next door (and the row above, 102 groups away at cfg3) are always
+// another XCD's and their traces another L2's.  With the remap the workgroups of XCD x = blockIdx % 8 walk the x-th contiguous
+// eighth of the groups (a bijection for every grid size: XCD x holds q + (x < r) workgroups, q = n / 8, r = n % 8).
+// Measured in round 3 (profiles/experiments/r03_xcd_remap_ab.log): cfg3 kt2_rhs -1.5 %, kt2_sigma +3 %, RHS +-0; N = 6: kt2_sigma
+// +38 %; N = 2: RHS -3.6 %, N = 3: +1.5 % -- no consistent gain, off.
+#ifndef ESDG_T2_XCD_REMAP
+#define ESDG_T2_XCD_REMAP 0
+#endif
+constexpr int T2_NXCD = 8;
+__device__ __forceinline__ int64_t xcd_group(int64_t b, int64_t n) {
+  if (!ESDG_T2_XCD_REMAP || n < 8 * T2_NXCD) return b;
+  const int64_t x = b % T2_NXCD, q = n / T2_NXCD, r = n % T2_NXCD;
+  return x * q + (x < r ? x : r) + b / T2_NXCD;
+}
+
 // Uq = Vq Qn by sum factorisation through the pair planes sA, sB ([2][NV] each).  Nodal values are r-fastest, Gauss
 // nodes s-fastest (SetupDG.jl:244): Vq[(a + N1 b), (i + N1 j)] = IQ[b,i] IQ[a,j].  c = IQ[a][:]; rowb = first slot of
 // row b, colq = slot b of row 0 (both of this lane's element).
@@ -371,7 +387,17 @@ __global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_s
   // face-jump stage), so that every load has most of an iteration to land and no copy ever waits for one.
   // group of this workgroup in round k: k G + w, or (MeshDev::wall_rot) k G + ((w + k rot) mod G)
   const int64_t rot = (WALLS && FULL) ? (int64_t)M.wall_rot : 0;
-  auto group_of = [&](int64_t k) -> int64_t { return k * (int64_t)gridDim.x + ((int64_t)blockIdx.x + k * rot) % (int64_t)gridDim.x; };
+  // (ESDG_T2_XCD_REMAP, meshes without walls: the workgroups of XCD x = blockIdx % 8 share the x-th contiguous eighth of the groups,
+  // workgroup i of the XCD's nx takes its groups i, i + nx, ...; exhausted -> ngrp, which ends the loop)
+  const bool xr = ESDG_T2_XCD_REMAP && FULL && !WALLS && nfull >= 8 * T2_NXCD && gridDim.x >= (unsigned)T2_NXCD;
+  const int64_t xx = blockIdx.x % T2_NXCD, xi = blockIdx.x / T2_NXCD;
+  const int64_t xnw = gridDim.x / T2_NXCD + (xx < (int64_t)(gridDim.x % T2_NXCD) ? 1 : 0);           // workgroups on this XCD
+  const int64_t xq = nfull / T2_NXCD, xrm = nfull % T2_NXCD;
+  const int64_t xs = xx * xq + (xx < xrm ? xx : xrm), xc = xq + (xx < xrm ? 1 : 0);                     // this XCD's groups: start, count
+  auto group_of = [&](int64_t k) -> int64_t {
+    if (xr) { const int64_t j = xi + k * xnw; return j < xc ? xs + j : ngrp; }
+    return k * (int64_t)gridDim.x + ((int64_t)blockIdx.x + k * rot) % (int64_t)gridDim.x;
+  };
   int64_t rnd = 0;
   int64_t grp = FULL ? group_of(0) : nfull;
   double x[4], geo[GPT];
@@ -886,7 +912,7 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_project(TensorTables TT, Mesh
   const unsigned ef = tf / Nfq, fn = tf - ef * Nfq;
   const unsigned rowb = ev * Nq + N1 * b, colq = ev * Nq + b;
   const int64_t KN = M.K * Nq;
-  const int64_t e0 = M.e_begin + (int64_t)blockIdx.x * E;
+  const int64_t e0 = M.e_begin + xcd_group(blockIdx.x, gridDim.x) * E;
   const int nE = (int)min((int64_t)E, M.e_begin + M.e_count - e0);
   const unsigned tvl = tv < (unsigned)(nE * Nq) ? tv : 0u;
   const bool fact = tid < (unsigned)(nE * Nfq);
@@ -1004,7 +1030,7 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
   const bool inviscid = (ph.parts & 1) != 0, viscous = VISC && (ph.parts & 2) != 0;
   const bool vown = NV == G::GT || tid < (unsigned)NV, fown = NF == G::GT || tid < (unsigned)NF;   // not a duplicate lane
 
-  const int64_t e0r = M.e_begin + (int64_t)blockIdx.x * E;
+  const int64_t e0r = M.e_begin + xcd_group(blockIdx.x, gridDim.x) * E;
   const int nE = (int)min((int64_t)E, M.e_begin + M.e_count - e0r);
   const int64_t e0 = ESDG_EW(e0r);
   const bool vact = tid < (unsigned)(nE * Nq);
