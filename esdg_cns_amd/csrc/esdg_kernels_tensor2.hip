@@ -964,6 +964,9 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_project(TensorTables TT, Mesh
 // kt2_rhs: partner records read one flux round ahead (A/B hook, off).  Measured in round 3 (profiles/experiments/
 // r03_rhs_prefetch_ab.log): N = 4 nothing (0.392-0.397 vs 0.396-0.398 ms), N = 2, 3 -1.5 % of the kernel, N = 6 +15 % (its 12
 // registers push the N1 = 7 instantiation from 166 to 178 VGPRs = from three waves per SIMD to two; N1 = 6 would spill).
+#ifndef ESDG_T2_ACC_REUSE
+#define ESDG_T2_ACC_REUSE 1
+#endif
 #ifndef ESDG_T2_PREFETCH_REC
 #define ESDG_T2_PREFETCH_REC 0
 #endif
@@ -973,7 +976,14 @@ template <int N1, bool MODAL, bool VISC> struct RhsLds2 {
   static constexpr NodeLayout NL = NodeLayout(N1);
   static constexpr int NV = G::NV, NF = G::NF;
   static constexpr int NVV = (NL.NFULL + 1) / 2;                      // accumulator plane sets per direction, volume-volume
-  static constexpr int NACC = 2 * NVV + (N1 % 2 == 0 ? 1 : 0) + 2;    // + antipodal + the two volume-face sets
+  // REUSE (the collocated Euler instantiation at N1 = 5, ESDG_T2_ACC_REUSE): the volume-face shares go to the plane sets of the volume-volume
+  // shares, which every lane has gathered and zeroed again between two barriers -- the same sequence of additions per node, so
+  // the same bits, two sets instead of four: 26.2 -> 18.2 KB of LDS = eight workgroups per CU, and with the collocated kernel's
+  // 122 VGPRs four waves per SIMD.  (The CNS instantiation needs ~150 VGPRs: three waves either way; measured there in round 2.)
+  static constexpr bool REUSE = ESDG_T2_ACC_REUSE && !VISC && !MODAL && N1 == 5;
+  static constexpr int NACCV = 2 * NVV + (N1 % 2 == 0 ? 1 : 0);       // volume-volume sets (+ antipodal)
+  static constexpr int NACC = REUSE ? (NACCV > 2 ? NACCV : 2) : NACCV + 2;   // + the two volume-face sets
+  static constexpr int FSET = REUSE ? 0 : NACCV;                      // first volume-face set
   static constexpr int REC = 0;                                       // 3 pair planes [NV]: (rho,u) (v,beta) (lrho,lbeta)
   // Before they are zeroed the accumulator planes hold Vq's second buffer (2 pair planes) and the 1D operator IQ (rows
   // padded to even length); after the flux rounds the (dead) third record plane holds IP.
@@ -994,7 +1004,7 @@ template <int N1, bool MODAL, bool VISC> struct RhsLds2 {
 //     spill, and resident workgroups that start together stay in step, so their load and compute phases do not overlap
 //     the way consecutive one-shot workgroups' do.
 template <int N1, bool MODAL, bool VISC, bool WALLS>
-__global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
+__global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? (RhsLds2<N1, MODAL, VISC>::REUSE ? 4 : 3) : 2)) void kt2_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                                        const double* __restrict__ A_U, const double* __restrict__ SG,
                                                                        const double* __restrict__ B, double* __restrict__ rhs, LsrkFuse lf) {
   using G = GeoR<N1>;
@@ -1209,6 +1219,18 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
         }
       }
     }
+    if (LD::REUSE) {   // gather the volume-volume shares and hand the zeroed planes to the volume-face shares
+      __syncthreads();
+      if (vown) {   // (a duplicate lane would zero its owner's cells before the owner has read them; its own sums are never stored)
+#pragma unroll
+        for (int p = 0; p < LD::NACCV; ++p) {
+          const d2 s0 = sAcc[(2 * p) * NV + tv], s1 = sAcc[(2 * p + 1) * NV + tv];
+          acc[0] += s0.x; acc[1] += s0.y; acc[2] += s1.x; acc[3] += s1.y;
+          sAcc[(2 * p) * NV + tv] = make_double2(0.0, 0.0); sAcc[(2 * p + 1) * NV + tv] = make_double2(0.0, 0.0);
+        }
+      }
+      __syncthreads();
+    }
     T2_STAMP(4);   // volume-volume rounds
     if (VISC) {   // needed after the volume-face pairs: issued here, their destinations are not live during the rounds above
 #pragma unroll
@@ -1276,7 +1298,7 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
       // volume-face pairs by the face lanes: share of the volume node -> plane set of the face's direction
       {
         const double gxf = 2 * gf[opf], gyf = 2 * gf[2 + opf];
-        const d2* accf = sAcc + (LD::NACC - 2 + fdir) * 2 * NV;
+        const d2* accf = sAcc + (LD::FSET + fdir) * 2 * NV;
         d2 nx0, nx1, nx2;
         if (PFR) { nx0 = sRec[fnode0]; nx1 = sRec[NV + fnode0]; nx2 = sRec[2 * NV + fnode0]; }
 #pragma unroll
@@ -1332,7 +1354,7 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? 3 : 2)) void kt2_rhs(Tenso
       const double* g = sGeo + ev * GEO_STRIDE;
       const double iJ = rcp_refined(g[4]);
 #pragma unroll
-      for (int p = 0; p < LD::NACC; ++p) {
+      for (int p = LD::REUSE ? LD::FSET : 0; p < (LD::REUSE ? LD::FSET + 2 : LD::NACC); ++p) {
         const d2 s0 = sAcc[(2 * p) * NV + tv], s1 = sAcc[(2 * p + 1) * NV + tv];
         acc[0] += s0.x; acc[1] += s0.y; acc[2] += s1.x; acc[3] += s1.y;
       }
