@@ -965,7 +965,7 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_project(TensorTables TT, Mesh
 // r03_rhs_prefetch_ab.log): N = 4 nothing (0.392-0.397 vs 0.396-0.398 ms), N = 2, 3 -1.5 % of the kernel, N = 6 +15 % (its 12
 // registers push the N1 = 7 instantiation from 166 to 178 VGPRs = from three waves per SIMD to two; N1 = 6 would spill).
 #ifndef ESDG_T2_ACC_REUSE
-#define ESDG_T2_ACC_REUSE 1
+#define ESDG_T2_ACC_REUSE 3   // bit 0: collocated Euler at N1 = 5; bit 1: every instantiation at N1 = 4
 #endif
 #ifndef ESDG_T2_PREFETCH_REC
 #define ESDG_T2_PREFETCH_REC 0
@@ -980,7 +980,8 @@ template <int N1, bool MODAL, bool VISC> struct RhsLds2 {
   // shares, which every lane has gathered and zeroed again between two barriers -- the same sequence of additions per node, so
   // the same bits, two sets instead of four: 26.2 -> 18.2 KB of LDS = eight workgroups per CU, and with the collocated kernel's
   // 122 VGPRs four waves per SIMD.  (The CNS instantiation needs ~150 VGPRs: three waves either way; measured there in round 2.)
-  static constexpr bool REUSE = ESDG_T2_ACC_REUSE && !VISC && !MODAL && N1 == 5;
+  static constexpr bool REUSE = ESDG_T2_ACC_REUSE && ((N1 == 5 && !VISC && !MODAL) || (N1 == 4 && (ESDG_T2_ACC_REUSE & 2)));
+  static constexpr int WPE = N1 <= 6 ? ((REUSE && N1 == 5) ? 4 : 3) : 2;   // waves per SIMD asked of the register allocator
   static constexpr int NACCV = 2 * NVV + (N1 % 2 == 0 ? 1 : 0);       // volume-volume sets (+ antipodal)
   static constexpr int NACC = REUSE ? (NACCV > 2 ? NACCV : 2) : NACCV + 2;   // + the two volume-face sets
   static constexpr int FSET = REUSE ? 0 : NACCV;                      // first volume-face set
@@ -1004,7 +1005,7 @@ template <int N1, bool MODAL, bool VISC> struct RhsLds2 {
 //     spill, and resident workgroups that start together stay in step, so their load and compute phases do not overlap
 //     the way consecutive one-shot workgroups' do.
 template <int N1, bool MODAL, bool VISC, bool WALLS>
-__global__ __launch_bounds__(GeoR<N1>::GT, (N1 <= 6 ? (RhsLds2<N1, MODAL, VISC>::REUSE ? 4 : 3) : 2)) void kt2_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
+__global__ __launch_bounds__(GeoR<N1>::GT, (RhsLds2<N1, MODAL, VISC>::WPE)) void kt2_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                                        const double* __restrict__ A_U, const double* __restrict__ SG,
                                                                        const double* __restrict__ B, double* __restrict__ rhs, LsrkFuse lf) {
   using G = GeoR<N1>;
