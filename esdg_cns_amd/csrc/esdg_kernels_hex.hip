@@ -34,6 +34,9 @@ constexpr double GM1 = 1.4 - 1;   // gamma - 1 with the package's gamma (Entropy
 constexpr int HW = 64;            // wave
 constexpr int HNWV = 4;           // waves (= elements) per workgroup
 constexpr int NXCD = 8;
+#ifndef ESDG_KH_COALESCE
+#define ESDG_KH_COALESCE 1
+#endif
 
 template <int N1> struct HCfg {
   static constexpr int Nq = N1 * N1 * N1, Nfq = 6 * N1 * N1, NIT = (Nfq + HW - 1) / HW;
@@ -191,6 +194,9 @@ __global__ __launch_bounds__(HW * HNWV) void kh_project(HexTables HT, MeshDev M,
   __shared__ double sTab[L.NDBL];
   __shared__ int sInt[L.NINT];
   __shared__ double sV[HNWV][HEX_NFLD * HW];
+  // ESDG_KH_COALESCE: an element's 5 Nfq trace doubles leave through a wave-private LDS block, so that every store instruction
+  // writes 512 contiguous bytes instead of 64 x 8 B at a stride of 40 B (20 cache lines per instruction)
+  __shared__ double sOut[ESDG_KH_COALESCE ? HNWV : 1][ESDG_KH_COALESCE ? HEX_AU_NC * Nfq : 1];
   const int64_t nblk = (M.e_count + HNWV - 1) / HNWV;
   const int64_t blk = block_of(nblk, remap != 0);
   if (blk < 0) return;
@@ -235,9 +241,26 @@ __global__ __launch_bounds__(HW * HNWV) void kh_project(HexTables HT, MeshDev M,
       }
       double qf[HEX_NFLD];
       prim_of_v3(Vf, qf);
-      if (active) {
+      if (ESDG_KH_COALESCE) {
+#pragma unroll
+        for (int c = 0; c < HEX_NFLD; ++c) sOut[wv][f * HEX_AU_NC + c] = qf[c];
+      } else if (active) {
 #pragma unroll
         for (int c = 0; c < HEX_NFLD; ++c) A_U[(e * Nfq + f) * HEX_AU_NC + c] = qf[c];
+      }
+    }
+  }
+  if (ESDG_KH_COALESCE) {
+    // (one wave = one element: its LDS instructions execute in order, a later read sees every lane's earlier write)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (active) {
+      constexpr int NT = HEX_AU_NC * Nfq;
+#pragma unroll
+      for (int k = 0; k < (NT + HW - 1) / HW; ++k) {
+        const int idx = k * HW + lane;
+        if (idx < NT) A_U[e * NT + idx] = sOut[wv][idx];
       }
     }
   }
