@@ -281,6 +281,12 @@ __device__ __forceinline__ void tp_apply(const double* w1, const double* w2, con
 // kt2_sigma at N1 = 5 without walls: the per-lane rows of IQ and of the face extrapolation (20 VGPRs held across the persistent
 // loop) live in LDS and are read at the point of use, which brings the kernel from 184 to <= 168 VGPRs = three waves per SIMD
 // (ESDG_T2_SIGMA_ROWS_LDS=0: rows in registers, two waves per SIMD, the form of every other instantiation).
+#ifndef ESDG_T2_SIGMA_DEFER_STORES
+#define ESDG_T2_SIGMA_DEFER_STORES 1   // (see the comment at the kernel's store stage)
+#endif
+#ifndef ESDG_T2_SIGMA_COALESCE
+#define ESDG_T2_SIGMA_COALESCE 0   // (measured late in round 3: phase 1 +2 % at N=4, -2 ... -5 % at N=2, 3, 6: hook, off)
+#endif
 #ifndef ESDG_T2_SIGMA_ROWS_LDS
 #define ESDG_T2_SIGMA_ROWS_LDS 0
 #endif
@@ -311,7 +317,11 @@ __global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_s
                 RE = RG + GPT * G::GT, RW = RE + (WALLS ? (E + 2) / 2 : 0), RT = RW + (WALLS ? 2 * N1 * N1 : 0);
   constexpr bool ROWS_LDS = SigmaCfg<N1, WALLS>::ROWS_LDS;
   constexpr int N1P = N1 + (N1 & 1);                   // rows padded to an even length: N1P / 2 ds_read_b128 per row
-  constexpr int RTQ = RT + (RT & 1), RTE = RTQ + Nq * N1P, NLDS = ROWS_LDS ? RTE + Nfq * N1P : RT;
+  constexpr int RTQ = RT + (RT & 1), RTE = RTQ + Nq * N1P, RBS = ROWS_LDS ? RTE + Nfq * N1P : RT;
+  // COAL (ESDG_T2_SIGMA_COALESCE, with the deferred stores): a group's normal-stress records [NF][3] leave through an LDS block, so
+  // that a store instruction writes 1 KB of consecutive doubles instead of 8 B per lane at a stride of 24 B
+  constexpr bool COAL = ESDG_T2_SIGMA_COALESCE && ESDG_T2_SIGMA_DEFER_STORES;
+  constexpr int NBS = B_NC * NF, BPT = (NBS + G::GT - 1) / G::GT, NLDS = RBS + (COAL ? NBS : 0);
   __shared__ __align__(16) double lds[NLDS];
   int* sEb = reinterpret_cast<int*>(lds + RE);        // [E] WALLS: element has a boundary node (see wall_dense above)
   double* sW = lds + RW;                              // WALLS: the 1D operators IQ | IP, row-major (for tp_apply above)
@@ -436,6 +446,8 @@ __global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_s
   double cdv[3] = {0, 0, 0}, csn[3] = {0, 0, 0};
   int64_t ce0 = 0;
   bool cva = false, cfa = false;
+  int cnb = 0;                      // COAL: doubles of the stored group's B block (uniform)
+  double* sBs = lds + RBS;
   T2_STAMP_INIT;
 #pragma unroll 1
   for (; grp < ngrp; grp = FULL ? group_of(++rnd) : ngrp) {
@@ -459,6 +471,11 @@ __global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_s
     // ---- this group's state and geometry to LDS; their registers take the next group's loads ---------------------------
     d2* sA = reinterpret_cast<d2*>(lds + R0);
     if (WALLS && tid < (unsigned)E) sEb[tid] = 0;   // (set by the face lanes two barriers further down)
+    double bt[BPT];
+    if (COAL) {   // the previous group's B block, consecutive doubles per lane (read before the staging writes below are queued)
+#pragma unroll
+      for (int r = 0; r < BPT; ++r) bt[r] = sBs[min((int)tid + r * G::GT, NBS - 1)];
+    }
 #pragma unroll
     for (int i = 0; i < GPT; ++i) sGeo[tid + i * G::GT] = geo[i];
     sA[tv] = make_double2(x[0], x[1]);
@@ -466,7 +483,11 @@ __global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_s
     __builtin_amdgcn_sched_barrier(0);
     if (ESDG_T2_SIGMA_DEFER_STORES) {   // the previous group's results (none in the first iteration: cva = cfa = false)
       if (cva) { double* o = SG + ESDG_EW(ce0) * Nq + tv; o[0] = cdv[0]; o[KN] = cdv[1]; o[2 * KN] = cdv[2]; }
-      if (cfa) { double* bb = B + (ESDG_EW(ce0) * Nfq + tf) * B_NC; bb[0] = csn[0]; bb[1] = csn[1]; bb[2] = csn[2]; }
+      if (COAL) {
+        double* bb = B + ESDG_EW(ce0) * Nfq * B_NC;
+#pragma unroll
+        for (int r = 0; r < BPT; ++r) { const int idx = (int)tid + r * G::GT; if (idx < cnb) bb[idx] = bt[r]; }
+      } else if (cfa) { double* bb = B + (ESDG_EW(ce0) * Nfq + tf) * B_NC; bb[0] = csn[0]; bb[1] = csn[1]; bb[2] = csn[2]; }
       __builtin_amdgcn_sched_barrier(0);
     }
     // mapP first: it is waited for first (vmcnt counts in issue order), the others may then still be in flight.
@@ -740,7 +761,10 @@ __global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_s
         wall_stress_jump(sn, fx, fy, bcf, vlid, gn, ph, sj);
         sn[0] = -sj[0]; sn[1] = -sj[1]; sn[2] = -sj[2];
       }
-      if (ESDG_T2_SIGMA_DEFER_STORES) {
+      if (COAL) {   // (duplicate lanes write duplicates; slots of elements beyond the mesh are never stored)
+        sBs[tf * B_NC] = sn[0]; sBs[tf * B_NC + 1] = sn[1]; sBs[tf * B_NC + 2] = sn[2];
+        cnb = (FULL ? E : nE) * Nfq * B_NC; ce0 = e0;
+      } else if (ESDG_T2_SIGMA_DEFER_STORES) {
         csn[0] = sn[0]; csn[1] = sn[1]; csn[2] = sn[2]; cfa = fact; ce0 = e0;
       } else if (fact) {
         double* bb = B + (ESDG_EW(e0) * Nfq + tf) * B_NC;
@@ -753,7 +777,11 @@ __global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_s
   }
   if (ESDG_T2_SIGMA_DEFER_STORES) {   // the last group's results
     if (cva) { double* o = SG + ESDG_EW(ce0) * Nq + tv; o[0] = cdv[0]; o[KN] = cdv[1]; o[2 * KN] = cdv[2]; }
-    if (cfa) { double* bb = B + (ESDG_EW(ce0) * Nfq + tf) * B_NC; bb[0] = csn[0]; bb[1] = csn[1]; bb[2] = csn[2]; }
+    if (COAL) {
+      double* bb = B + ESDG_EW(ce0) * Nfq * B_NC;
+#pragma unroll
+      for (int r = 0; r < BPT; ++r) { const int idx = (int)tid + r * G::GT; if (idx < cnb) bb[idx] = sBs[idx]; }
+    } else if (cfa) { double* bb = B + (ESDG_EW(ce0) * Nfq + tf) * B_NC; bb[0] = csn[0]; bb[1] = csn[1]; bb[2] = csn[2]; }
   }
   T2_STAMP_FLUSH;
 }
