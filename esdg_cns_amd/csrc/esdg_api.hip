@@ -554,6 +554,8 @@ struct esdg_ctx {
   Tables T{};
   TensorTables TT{};
   bool use_fast = false;
+  int v2 = 0;              // ESDG_V2=1 | rhs | sigma in the environment: the v2 kernel where a v3 kernel exists (A/B; bit 0: phase 1,
+                           // bit 1: last phase)
   int v1 = 0;              // ESDG_V1=1 in the environment: round-1 tensor kernels only (A/B against esdg_kernels_tensor2.hip);
                            // ESDG_V1=sigma / ESDG_V1=rhs: for that phase only (bit 0: phase 1, bit 1: last phase)
   int dim = 2, nfld = 4;   // 3 / 5 on the hexahedral path
@@ -739,6 +741,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   c->ph.parts = 3;
   c->ph.dbg = 0;
   if (const char* env = getenv("ESDG_DBG")) c->ph.dbg = atoi(env);
+  if (const char* env = getenv("ESDG_V2")) c->v2 = env[0] == '1' ? 7 : env[0] == 'r' ? 2 : env[0] == 's' ? 1 : 0;
   if (const char* env = getenv("ESDG_V1")) c->v1 = env[0] == '1' ? 7 : env[0] == 's' ? 1 : env[0] == 'r' ? 2 : env[0] == 'p' ? 4 : env[0] == 'w' ? 8 : 0;
 
   // ---- collocated sparse operators -------------------------------------------------------
@@ -1344,7 +1347,10 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
     if (!rhs && !lf.Qw) return fail(ESDG_ERR_ARG, "rhs output is null");
     if (lf.Qw && !ctx->use_fast) return fail(ESDG_ERR_STATE, "the fused RK update needs the tensor kernels");
     rc = -1;
-    if (ctx->use_fast && !ctx->ph.dbg && (ctx->M.bc ? v2_on_walls(ctx) : !(ctx->v1 & 2)))      // v2 kernel: N1 = N + 1 = 2 ... 8
+    // v3 kernel (line-per-lane flux stage, esdg_kernels_tensor3.hip): meshes without walls; ESDG_V2=rhs: the v2 kernel (A/B)
+    if (ctx->use_fast && !ctx->ph.dbg && !ctx->M.bc && !(ctx->v1 & 2) && !(ctx->v2 & 2))
+      rc = launch_rhs_tensor3(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s);
+    if (rc == -1 && ctx->use_fast && !ctx->ph.dbg && (ctx->M.bc ? v2_on_walls(ctx) : !(ctx->v1 & 2)))      // v2 kernel: N1 = N + 1 = 2 ... 8
       rc = launch_rhs_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s);
     if (rc == -1)
       rc = ctx->use_fast ? launch_rhs_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s)

@@ -60,6 +60,9 @@ int launch_rhs_tensor2(int N1, const TensorTables& TT, const MeshDev& M, const P
 int launch_sigma_tensor2(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
                          double* B, double* SG, hipStream_t s);
 int launch_project_tensor2(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, double* A_U, hipStream_t s);
+// v3 last-phase kernel (esdg_kernels_tensor3.hip); -1 where it does not apply
+int launch_rhs_tensor3(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
+                       const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s);
 struct LsrkFuse;
 int launch_rhs_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
                       const double* A_U, const double* SG, const double* B, double* rhs, const LsrkFuse& lf,

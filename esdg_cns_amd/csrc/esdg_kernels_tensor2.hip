@@ -16,6 +16,7 @@
 #include "esdg_dev.hpp"
 #include "esdg_tensor_tables.hpp"
 #include "esdg_devmath.hpp"
+#include "esdg_t2_physics.hpp"
 
 namespace esdg {
 namespace t2 {
@@ -45,35 +46,10 @@ template <int N1, int GWv = Cfg<N1>::GW> struct Geo {
 
 template <int N1> using GeoR = Geo<N1, CfgRhs<N1>::GW>;   // group geometry of kt2_rhs
 
-constexpr double GM1 = 0.4;   // the CNS drivers' literal (cavity_optimized.jl:463)
-
-// viscous_matrices! + sigma rows 2..4 (cavity :613-645, 786-801); lam already sign-flipped (quirk Q4); gk = gamma*mu/Pr
-__device__ __forceinline__ void viscous_stress(const double* v, const double* tx, const double* ty, double lam, double mu,
-                                               double gk, double* sx, double* sy) {
-  const double v2 = v[0], v3 = v[1], v4 = v[2];
-  const double i1 = rcp_refined(v4);
-  const double i2 = i1 * i1, i3 = i2 * i1;
-  const double l2m = lam + 2.0 * mu;
-  const double a24 = v2 * i2, a34 = v3 * i2;
-  const double Kxx22 = -l2m * i1, Kxx24 = l2m * a24, Kxx33 = -mu * i1, Kxx34 = mu * a34,
-               Kxx44 = -i3 * (l2m * (v2 * v2) + mu * (v3 * v3) - gk * v4);
-  const double Kxy23 = -lam * i1, Kxy24 = lam * a34, Kxy32 = Kxx33, Kxy34 = mu * a24, Kxy42 = Kxx34, Kxy43 = lam * a24,
-               Kxy44 = i3 * (lam + mu) * (-v2 * v3);
-  const double Kyy22 = Kxx33, Kyy24 = Kxy34, Kyy33 = Kxx22, Kyy34 = l2m * a34,
-               Kyy44 = -i3 * (l2m * (v3 * v3) + mu * (v2 * v2) - gk * v4);
-  sx[0] = Kxx22 * tx[0] + Kxx24 * tx[2] + Kxy23 * ty[1] + Kxy24 * ty[2];
-  sx[1] = Kxx33 * tx[1] + Kxx34 * tx[2] + Kxy32 * ty[0] + Kxy34 * ty[2];
-  sx[2] = Kxx24 * tx[0] + Kxx34 * tx[1] + Kxx44 * tx[2] + Kxy42 * ty[0] + Kxy43 * ty[1] + Kxy44 * ty[2];
-  sy[0] = Kxy32 * tx[1] + Kxy42 * tx[2] + Kyy22 * ty[0] + Kyy24 * ty[2];
-  sy[1] = Kxy23 * tx[0] + Kxy43 * tx[2] + Kyy33 * ty[1] + Kyy34 * ty[2];
-  sy[2] = Kxy24 * tx[0] + Kxy34 * tx[1] + Kxy44 * tx[2] + Kyy24 * ty[0] + Kyy34 * ty[1] + Kyy44 * ty[2];
-}
-
 // LDS layout.  Measured on MI355X (tools/ubench/lds_read.hip, 2 waves per SIMD): a ds_read_b64 and a ds_read_b128
 // wave-instruction cost the same LDS time (~4.5 cycles; 119 vs 223 B/clk/CU), ds_read2_b64 costs two.  All arrays are
 // therefore planes of double2 ("pair planes": two components of one node side by side, [pairs][E * nodes], lane stride
 // 16 B = conflict-free ds_read_b128 / ds_write_b128) plus a plane of doubles for an odd component.
-typedef double2 d2;
 
 // Workgroup -> element group, XCD-contiguous (ESDG_T2_XCD_REMAP, A/B hook): the dispatcher deals consecutive workgroups to the 8
 // XCDs in turn, so with group = blockIdx the five elements next door (and the row above, 102 groups away at cfg3) are always
@@ -801,91 +777,6 @@ __global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_s
 // the order of the two adds, so the result is bit-for-bit the same wherever the element sits in its group and however
 // the waves of a group are scheduled (elements may straddle two waves) -- no per-wave accumulator copies.
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool MODAL> struct Gas2 { static constexpr double GM1 = MODAL ? 0.4 : (1.4 - 1); };   // literal 0.4 in the CNS drivers
-
-// (gx,gy) . (Fx,Fy) of the entropy-conservative flux (euler_fluxes.jl:23-48 with logmean.jl:14-28) between the states
-// (rho,u,v,beta,lrho,lbeta); one refined reciprocal serves the three quotients.  The reference's |f| < 1e-4 series branch
-// (logmean.jl:23-27) is taken per lane by selection (MODE 0); when EVERY lane of the wave takes the series for both means
-// (MODE 1: smooth regions, e.g. the far field of the vortex) or NO lane takes it for either (MODE 2) the unselected
-// half is not computed at all -- 13-15 of ~64 VALU instructions per flux.  The three variants evaluate the same
-// expressions with explicit FMAs, so a lane's result does not depend on which variant its wave ran (the ranged-launch
-// and shard tests compare bit for bit across different wave compositions).
-__device__ __forceinline__ double logmean_series_rho(double ravg, double vr) {
-  return ravg * __builtin_fma(vr, __builtin_fma(vr, __builtin_fma(vr, 0.026038857142857, -.0512), -.2), 1.0);
-}
-__device__ __forceinline__ double logmean_series_ibeta(double ib, double vb) {
-  return ib * __builtin_fma(vb, __builtin_fma(vb, .0912, .2), 1.0);
-}
-template <bool MODAL, int MODE>
-__device__ __forceinline__ void ec_flux_core(const double* qL, const double* qR, double gx, double gy, double* F, double dr, double ravg,
-                                             double db, double bavg, bool ser_r, bool ser_b) {
-  constexpr double GM1 = Gas2<MODAL>::GM1;
-  double yr, yb;
-  if (MODE == 1) { yr = ravg; yb = bavg; }
-  else {
-    const double A = qL[4] - qR[4];
-    yr = MODE == 2 ? A : (ser_r ? ravg : A);
-    yb = MODE == 2 ? db : (ser_b ? bavg : db);
-  }
-  const double yp = qL[3] + qR[3];
-  const double ybp = yb * yp;
-  const double R = rcp_refined(yr * ybp);
-  const double ir = R * ybp;
-  const double ryr = R * yr;
-  const double ib = ryr * yp;
-  const double ip = ryr * yb;
-  const double fr = dr * ir;
-  const double fb = db * ib;
-  double rholog, ibetalog;
-  if (MODE == 2) {
-    rholog = -fr;
-    ibetalog = -((qL[5] - qR[5]) * ib);
-  } else {
-    const double sr = logmean_series_rho(ravg, fr * fr), sb = logmean_series_ibeta(ib, fb * fb);
-    if (MODE == 1) { rholog = sr; ibetalog = sb; }
-    else { rholog = ser_r ? sr : -fr; ibetalog = ser_b ? sb : -((qL[5] - qR[5]) * ib); }
-  }
-  const double uavg = .5 * (qL[1] + qR[1]), vavg = .5 * (qL[2] + qR[2]);
-  const double unorm = __builtin_fma(qL[2], qR[2], qL[1] * qR[1]);
-  const double pa = ravg * ip;
-  const double f4aux = __builtin_fma(.5 * rholog, unorm, __builtin_fma(rholog * ibetalog, 1.0 / (2 * GM1), pa));
-  const double un = __builtin_fma(gy, vavg, gx * uavg);
-  F[0] = rholog * un;
-  F[1] = __builtin_fma(F[0], uavg, pa * gx);
-  F[2] = __builtin_fma(F[0], vavg, pa * gy);
-  F[3] = f4aux * un;
-}
-template <bool MODAL>
-__device__ __forceinline__ void ec_flux_dir(const double* qL, const double* qR, double gx, double gy, double* F) {
-  const double dr = qR[0] - qL[0], ravg = .5 * (qR[0] + qL[0]);
-  const double db = qR[3] - qL[3], bavg = .5 * (qR[3] + qL[3]);
-  const bool ser_r = fabs(dr) < 1e-4 * ravg, ser_b = fabs(db) < 1e-4 * bavg;
-#ifdef ESDG_T2_NO_UNIFORM_LOGMEAN
-  ec_flux_core<MODAL, 0>(qL, qR, gx, gy, F, dr, ravg, db, bavg, ser_r, ser_b);
-#else
-  const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
-  if (__builtin_amdgcn_ballot_w64(ser_r && ser_b) == active) ec_flux_core<MODAL, 1>(qL, qR, gx, gy, F, dr, ravg, db, bavg, ser_r, ser_b);
-  else if (__builtin_amdgcn_ballot_w64(ser_r || ser_b) == 0) ec_flux_core<MODAL, 2>(qL, qR, gx, gy, F, dr, ravg, db, bavg, ser_r, ser_b);
-  else ec_flux_core<MODAL, 0>(qL, qR, gx, gy, F, dr, ravg, db, bavg, ser_r, ser_b);
-#endif
-}
-
-// conservative -> (rho,u,v,beta,log rho,log beta)
-template <bool MODAL>
-__device__ __forceinline__ void prim_logs(const double* U, double* q) {
-  constexpr double GM1 = Gas2<MODAL>::GM1;
-  const double m2 = U[1] * U[1] + U[2] * U[2];
-  const double rre = U[0] * U[3] - .5 * m2;
-  const double R = rcp_refined(U[0] * rre);
-  const double ir = R * rre;
-  q[0] = U[0];
-  q[1] = U[1] * ir;
-  q[2] = U[2] * ir;
-  q[3] = (U[0] * U[0]) * (U[0] * R) * (1.0 / (2 * GM1));
-  q[4] = log_pos(U[0]);
-  q[5] = log_pos(q[3]);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // phase 0: entropy projection to the faces -> the (rho, u, v, beta) trace records A_U
 // (euler_quad.jl:141-157 / rhs_inviscid! :447-495: VU = v(Vq u), Uf = u(Vf Pq VU); see kt_project in esdg_kernels_tensor.hip)
@@ -893,35 +784,6 @@ __device__ __forceinline__ void prim_logs(const double* U, double* q) {
 // arrays as [element][component][node] planes of doubles: a wave waited 38 % of its life on LDS instructions, a third of its
 // LDS cycles were bank conflicts (profiles/r03u_sq_counters.txt).
 // ---------------------------------------------------------------------------------------------------------------------
-// entropy variables from primitives + logs (identities of euler_variables.jl:79-92)
-template <bool MODAL>
-__device__ __forceinline__ void v_of_prim2(const double* q, double* V) {
-  constexpr double GM1 = Gas2<MODAL>::GM1;
-  const double s = -GM1 * q[4] - q[5] - 0.6931471805599453;
-  const double b2 = 2 * GM1 * q[3];
-  V[0] = 1.4 - s - .5 * b2 * (q[1] * q[1] + q[2] * q[2]);
-  V[1] = b2 * q[1];
-  V[2] = b2 * q[2];
-  V[3] = -b2;
-}
-// (rho, u, v, beta) of entropy variables: u_vfun (euler_variables.jl:95-120 / cavity :473-478, no pow) followed by the
-// primitive conversion of the conservative state it returns
-template <bool MODAL>
-__device__ __forceinline__ void prim_of_v2(const double* V, double* q) {
-  constexpr double GM1 = Gas2<MODAL>::GM1;
-  const double vUnorm = V[1] * V[1] + V[2] * V[2];
-  const double h = vUnorm * .5 * rcp_refined(V[3]);
-  const double s = 1.4 - V[0] + h;
-  const double rhoeV = exp((log(GM1) - 1.4 * log_pos(-V[3]) - s) * (1.0 / GM1));
-  const double U[4] = {rhoeV * (-V[3]), rhoeV * V[1], rhoeV * V[2], rhoeV * (1 - h)};
-  const double m2 = U[1] * U[1] + U[2] * U[2];
-  const double rre = U[0] * U[3] - .5 * m2;
-  const double R = rcp_refined(U[0] * rre);
-  const double ir = R * rre;
-  q[0] = U[0]; q[1] = U[1] * ir; q[2] = U[2] * ir;
-  q[3] = (U[0] * U[0]) * (U[0] * R) * (1.0 / (2 * GM1));
-}
-
 template <int N1, bool MODAL>
 __global__ __launch_bounds__(Geo<N1>::GT) void kt2_project(TensorTables TT, MeshDev M, const double* __restrict__ Q, double* __restrict__ A_U) {
   using G = Geo<N1>;

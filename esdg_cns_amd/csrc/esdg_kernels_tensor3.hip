@@ -1,0 +1,447 @@
+// esdg_kernels_tensor3.hip -- third generation of the last-phase kernel of the 2D tensor path for gfx950 (MI355X / CDNA4).
+//
+// Same formulas, tables and face-trace protocol as kt2_rhs (esdg_kernels_tensor2.hip; reference: euler_quad.jl:141-194 /
+// rhs_inviscid! cavity_optimized.jl:447-528, update_flux! :308-324, flux_differencing! :326-348, dg_div! :590-611), a different
+// mapping of the flux differencing.  kt2_rhs gives every Gauss node a lane and returns the partner's share of each flux through
+// LDS (ds_add_f64 into two-add cells): its LDS is ~80 % busy, a quarter of that in bank conflicts of the 8-byte atomics on the
+// 16-byte pair planes, two waves per group meet at eight barriers, and the VALU sits at 73 % (profiles/r03z_sq_counters.txt).
+// Here
+//   * a workgroup is ONE wave and owns E = 64 / (2 N1) elements: no inter-wave barrier exists, every wave runs through its
+//     load -> Vq -> primitives -> fluxes -> Pq -> store sequence on its own, and the waves of a SIMD are in different stages;
+//   * the flux differencing is LINE PER LANE: lane (element, direction d, line o) owns the N1 Gauss nodes of one tensor line and
+//     the two face nodes at its ends, evaluates all C(N1,2) volume-volume pairs, the 2 N1 volume-face pairs and the two interface
+//     fluxes of its line, and keeps the N1 + 2 accumulators (4 components each) in registers: both shares of a flux are added
+//     in the lane that computed it -- no LDS atomics, no accumulator planes, no face-total planes; the partner records are
+//     streamed from LDS (3 ds_read_b128 per flux, the only LDS traffic of the stage);
+//   * the SBP weight of a pair is folded into the accumulation (acc_i += S_ij F, acc_j -= S_ij F: the flux is linear in the metric
+//     vector, which carries the line's transverse weight), and the lift of the two face totals is applied by the line lane, so a
+//     node's result is the sum of what its two lines hold for it: r = r_0 + r_1, one LDS exchange;
+//   * node-wise work (Vq, primitives + logs, gather, viscous divergence, Pq, store) runs in ceil(E N1^2 / 64) rounds of the same
+//     wave with the node-per-lane layout of kt2_rhs.
+// An element's result depends on nothing but its own data and its neighbours' traces (no cross-lane reduction whose order
+// depends on the slot), so ranged, sharded and full launches agree bit for bit as before.
+// Meshes with walls stay with kt2_rhs (launch_rhs_tensor3 returns -1).
+#include "esdg_dev.hpp"
+#include "esdg_tensor_tables.hpp"
+#include "esdg_devmath.hpp"
+#include "esdg_t2_physics.hpp"
+
+namespace esdg {
+namespace t3 {
+
+using namespace devmath;
+using t2::d2;
+using t2::ec_flux_dir;
+using t2::Gas2;
+using t2::prim_logs;
+
+template <int N1> struct G3 {
+  static constexpr int TW = 64, Nq = N1 * N1, Nfq = 4 * N1, NLN = 2 * N1;
+  static constexpr int E = TW / NLN;                  // elements of a wave
+  static constexpr int NV = E * Nq, NF = E * Nfq, LL = E * NLN;
+  static constexpr int NR = (NV + TW - 1) / TW;       // node rounds
+  static_assert(E >= 1, "a wave holds an element");
+};
+
+// Compiler-only memory fence in front of every record read of the line stage: the records are read-only there, so without it
+// hipcc merges the repeated reads of a node's record (the node is a partner in N1 + 1 pairs) and keeps all N1 records of the
+// line -- 12 VGPRs each -- live across the whole stage on top of the accumulators: 284 registers at N1 = 5, spills under any cap.
+#define T3_FENCE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
+
+// ... and a pin behind every flux: the updated accumulators pass through an empty asm statement, which hipcc cannot move relative
+// to the fences.  Without it the second half of every flux (averages, the four components, the accumulation) is sunk towards
+// the stage's end, where the accumulators are first read, and ten doubles of intermediates per flux stay live until there.
+#define T3_PIN4(a) asm volatile("" : "+v"((a)[0]), "+v"((a)[1]), "+v"((a)[2]), "+v"((a)[3]))
+
+#ifndef ESDG_T3_WPE
+#define ESDG_T3_WPE 3   // waves per SIMD asked of the register allocator (A/B hook)
+#endif
+
+template <int N1, bool MODAL, bool VISC>
+__global__ __launch_bounds__(64, ESDG_T3_WPE) void kt3_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
+                                                          const double* __restrict__ A_U, const double* __restrict__ SG,
+                                                          const double* __restrict__ B, double* __restrict__ rhs, LsrkFuse lf) {
+  using G = G3<N1>;
+  constexpr int TW = G::TW, Nq = G::Nq, Nfq = G::Nfq, NLN = G::NLN, E = G::E, NV = G::NV, LL = G::LL, NR = G::NR;
+  constexpr TensorLayout TL(N1);
+  constexpr int NGEO = E * GEO_STRIDE, GPT = (NGEO + TW - 1) / TW, TPT = (TL.NDBL + TW - 1) / TW;
+  constexpr double GM1 = Gas2<MODAL>::GM1;
+  // LDS: one arena of 8 NV doubles that is, in turn, Vq's two buffers ([2][NV] pair planes each), the node records
+  // ([3][NV] pair planes: (rho,u) (v,beta) (log rho, log beta)), the two lines' results per node ([2 directions][2][NV]) and
+  // Pq's two buffers; the geometry records of the wave's elements; the 1D operator tables (TensorLayout, esdg_tensor_tables.hpp).
+  __shared__ __align__(16) double arena[8 * NV];
+  __shared__ __align__(16) double sGeo[GPT * TW];
+  __shared__ __align__(16) double sTab[TPT * TW];
+  d2* sA = reinterpret_cast<d2*>(arena);                // [2][NV]
+  d2* sB = reinterpret_cast<d2*>(arena + 4 * NV);       // [2][NV]
+  d2* sRec = reinterpret_cast<d2*>(arena);              // [3][NV]
+  d2* sS = reinterpret_cast<d2*>(arena);                // [2][2][NV]
+
+  const unsigned tid = threadIdx.x;
+  const int64_t e0r = M.e_begin + (int64_t)blockIdx.x * E;
+  const int nE = (int)min((int64_t)E, M.e_begin + M.e_count - e0r);
+  const int64_t e0 = ESDG_EW(e0r);
+  const int64_t KN = M.K * Nq;
+  const bool inviscid = (ph.parts & 1) != 0, viscous = VISC && (ph.parts & 2) != 0;
+
+  // ---- this lane's line: element el, direction d, transverse index o; nodes n0 + i st; face nodes fA (end 0), fB (end 1) ----
+  const unsigned ln = tid < (unsigned)LL ? tid : tid - LL;   // (lanes beyond the lines duplicate a line: same LDS writes)
+  const unsigned el = ln / NLN, lr = ln - el * NLN, d = lr / N1, o = lr - d * N1;
+  const unsigned elc = el < (unsigned)nE ? el : 0u;          // (elements beyond the range: the data of the first one)
+  const unsigned n0 = el * Nq + (d ? o : N1 * o), st = d ? N1 : 1;
+  const int fA = TT.ints[TL.FN + (2 * d) * N1 + o], fB = TT.ints[TL.FN + (2 * d + 1) * N1 + o];
+  const int64_t nfA = (e0 + elc) * Nfq + fA, nfB = (e0 + elc) * Nfq + fB;
+  const unsigned mpA = ESDG_EWN((unsigned)M.mapP[nfA], Nfq), mpB = ESDG_EWN((unsigned)M.mapP[nfB], Nfq);
+
+  // ---- every global load of the inputs, unconditionally ------------------------------------------------------------------
+  double x[NR][4], geo[GPT], tab[TPT];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const unsigned n = tid + r * TW, s = n < (unsigned)NV ? n : n - NV, sl = s < (unsigned)(nE * Nq) ? s : 0u;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) x[r][f] = Q[f * KN + e0 * Nq + sl];
+  }
+#pragma unroll
+  for (int i = 0; i < GPT; ++i) { const unsigned n = tid + i * TW; geo[i] = M.geo[e0 * GEO_STRIDE + (n < (unsigned)(nE * GEO_STRIDE) ? n : 0u)]; }
+#pragma unroll
+  for (int i = 0; i < TPT; ++i) { const unsigned n = tid + i * TW; tab[i] = TT.dbl[n < (unsigned)TL.NDBL ? n : 0u]; }
+  // traces of the line's two face nodes, both sides: (rho, u, v, beta); their logs, energy and wavespeed are rebuilt below
+  double qMA[8], qPA[8], qMB[8], qPB[8];
+  {
+    const d2* aMA = reinterpret_cast<const d2*>(A_U + nfA * FAU_NC);
+    const d2* aMB = reinterpret_cast<const d2*>(A_U + nfB * FAU_NC);
+    const d2* aPA = reinterpret_cast<const d2*>(A_U + (size_t)mpA * FAU_NC);
+    const d2* aPB = reinterpret_cast<const d2*>(A_U + (size_t)mpB * FAU_NC);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const d2 ma = aMA[c], mb = aMB[c], pa = aPA[c], pb = aPB[c];
+      qMA[2 * c] = ma.x; qMA[2 * c + 1] = ma.y; qMB[2 * c] = mb.x; qMB[2 * c + 1] = mb.y;
+      qPA[2 * c] = pa.x; qPA[2 * c + 1] = pa.y; qPB[2 * c] = pb.x; qPB[2 * c + 1] = pb.y;
+    }
+  }
+  const float2 ndA = reinterpret_cast<const float2*>(M.fnd)[nfA], ndB = reinterpret_cast<const float2*>(M.fnd)[nfB];
+  double bsA[3] = {0, 0, 0}, bsB[3] = {0, 0, 0};   // central stress jump .5*((sxP-sxf)*nxJ + (syP-syf)*nyJ) of the two face nodes
+  if (VISC) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      bsA[c] = .5 * (-B[(size_t)mpA * B_NC + c] - B[nfA * B_NC + c]);
+      bsB[c] = .5 * (-B[(size_t)mpB * B_NC + c] - B[nfB * B_NC + c]);
+    }
+  }
+
+  // ---- staging: geometry, tables, nodal values ------------------------------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < GPT; ++i) sGeo[tid + i * TW] = geo[i];
+#pragma unroll
+  for (int i = 0; i < TPT; ++i) sTab[tid + i * TW] = tab[i];
+  unsigned slot[NR], nq[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const unsigned n = tid + r * TW;
+    slot[r] = n < (unsigned)NV ? n : n - NV;       // (slots beyond the nodes duplicate one: same values, same LDS writes)
+    nq[r] = slot[r] % Nq;
+  }
+  double U[NR][4];
+  if (MODAL) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      sA[slot[r]] = make_double2(x[r][0], x[r][1]);
+      sA[NV + slot[r]] = make_double2(x[r][2], x[r][3]);
+    }
+    __syncthreads();
+    // Uq = Vq Qn by sum factorisation, exactly as t2::vq_apply: W[a + N1 b] = sum_i IQ[a,i] Qn[i + N1 b], then
+    // Uq[a + N1 b] = sum_j IQ[a,j] W[b + N1 j]
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const unsigned ev = slot[r] / Nq, a = nq[r] % N1, b = nq[r] / N1;
+      const double* c = sTab + TL.IQ + a * N1;
+      const d2* rw = sA + ev * Nq + N1 * b;
+      d2 p = rw[0], t = rw[NV];
+      const double c0 = c[0];
+      double w0 = c0 * p.x, w1 = c0 * p.y, w2 = c0 * t.x, w3 = c0 * t.y;
+#pragma unroll
+      for (int i = 1; i < N1; ++i) {
+        p = rw[i]; t = rw[NV + i];
+        const double ci = c[i];
+        w0 = __builtin_fma(ci, p.x, w0); w1 = __builtin_fma(ci, p.y, w1);
+        w2 = __builtin_fma(ci, t.x, w2); w3 = __builtin_fma(ci, t.y, w3);
+      }
+      sB[slot[r]] = make_double2(w0, w1);
+      sB[NV + slot[r]] = make_double2(w2, w3);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const unsigned ev = slot[r] / Nq, a = nq[r] % N1, b = nq[r] / N1;
+      const double* c = sTab + TL.IQ + a * N1;
+      const d2* rw = sB + ev * Nq + b;
+      d2 p = rw[0], t = rw[NV];
+      const double c0 = c[0];
+      U[r][0] = c0 * p.x; U[r][1] = c0 * p.y; U[r][2] = c0 * t.x; U[r][3] = c0 * t.y;
+#pragma unroll
+      for (int j = 1; j < N1; ++j) {
+        p = rw[N1 * j]; t = rw[NV + N1 * j];
+        const double cj = c[j];
+        U[r][0] = __builtin_fma(cj, p.x, U[r][0]); U[r][1] = __builtin_fma(cj, p.y, U[r][1]);
+        U[r][2] = __builtin_fma(cj, t.x, U[r][2]); U[r][3] = __builtin_fma(cj, t.y, U[r][3]);
+      }
+    }
+    __syncthreads();   // the records below overwrite both buffers
+  } else {
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) U[r][f] = x[r][f];
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    double qh[6];
+    prim_logs<MODAL>(U[r], qh);
+    sRec[slot[r]] = make_double2(qh[0], qh[1]);
+    sRec[NV + slot[r]] = make_double2(qh[2], qh[3]);
+    sRec[2 * NV + slot[r]] = make_double2(qh[4], qh[5]);
+  }
+  __syncthreads();
+
+  // ---- line stage ----------------------------------------------------------------------------------------------------------------
+  double acc[N1][4], GfA[4], GfB[4];
+#pragma unroll
+  for (int i = 0; i < N1; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[i][c] = 0.0;
+  const double* g = sGeo + el * GEO_STRIDE;
+  {
+    const int opd = d ? TT.op1 : TT.op0;
+    const double gxd = 2 * g[opd], gyd = 2 * g[2 + opd];     // metric vector of the line's direction (affine: one per element)
+    // one face turn: interface flux + penalty + stress jump of face node f (end t of the line), then its N1 volume-face pairs
+    auto face_turn = [&](int t, int f, double* qM, double* qP, const float2 nd, const double* bs, double* Gf) {
+      const double* gm = g + 5 + 3 * (f / N1);             // face means of the record; + this node's difference = its own normal
+      const double gn[3] = {gm[0] + (double)nd.x, gm[1] + (double)nd.y, gm[2]};
+      {
+        const double isJm = rcp_refined(gm[2]);
+        trace_rest(qM, gm[0], gm[1], isJm, GM1);
+        trace_rest(qP, gm[0], gm[1], isJm, GM1);
+      }
+      double pnr[3] = {0, 0, 0};
+      if (VISC) {   // penalty tau*[[v]] (:817-837): the projected entropy variables are those OF the trace states
+        const double bM = 2 * GM1 * qM[3], bP = 2 * GM1 * qP[3];
+        const double tau = ph.viscous_dissp ? -rcp_refined(-bM) * ph.inv_Re : 0.0;
+        pnr[0] = tau * (bP * qP[1] - bM * qM[1]);
+        pnr[1] = tau * (bP * qP[2] - bM * qM[2]);
+        pnr[2] = tau * (bM - bP);
+      }
+      double Fn[4];
+      ec_flux_dir<MODAL>(qM, qP, gn[0], gn[1], Fn);
+      const double LFc = ph.inviscid_dissp ? ph.lf_scale * fmax(qM[6], qP[6]) * gn[2] : 0.0;
+      const double dU[4] = {qP[0] - qM[0], qP[0] * qP[1] - qM[0] * qM[1], qP[0] * qP[2] - qM[0] * qM[2], qP[7] - qM[7]};
+      const double wfac = sTab[TL.WFAC + f];
+      const double wf = inviscid ? wfac : 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Gf[c] = wf * (Fn[c] - LFc * dU[c]);
+      if (VISC) {   // stress jump + J * penalty (lifted WITHOUT 1/J, quirk Q3) ride in the face total with the opposite sign
+        const double Jf = g[4], ws = viscous ? wfac : 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Gf[c + 1] = __builtin_fma(-ws, __builtin_fma(Jf, pnr[c], bs[c]), Gf[c + 1]);
+      }
+      if (inviscid) {   // (uniform)
+        const double wt = sTab[TL.WTF + (2 * d + t) * N1 + o];
+        const double gxf = gxd * wt, gyf = gyd * wt;
+        const double* SFk = sTab + TL.SF + (2 * d + t) * N1;
+#pragma unroll
+        for (int j = 0; j < N1; ++j) {
+          const unsigned n = n0 + j * st;
+          T3_FENCE();
+          const d2 p0 = sRec[n], p1 = sRec[NV + n], p2 = sRec[2 * NV + n];
+          const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
+          double F[4];
+          ec_flux_dir<MODAL>(qj, qM, gxf, gyf, F);
+          const double c = SFk[j];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { acc[j][k] = __builtin_fma(c, F[k], acc[j][k]); Gf[k] = __builtin_fma(-c, F[k], Gf[k]); }
+          T3_PIN4(acc[j]); T3_PIN4(Gf);
+        }
+      }
+    };
+    face_turn(0, fA, qMA, qPA, ndA, bsA, GfA);
+    face_turn(1, fB, qMB, qPB, ndB, bsB, GfB);
+    if (inviscid) {   // volume-volume pairs of the line, each once
+      const double wt = sTab[TL.WT + d * N1 + o];
+      const double gxv = gxd * wt, gyv = gyd * wt;
+      const double* Sd = sTab + TL.S + d * N1 * N1;
+#pragma unroll
+      for (int i = 0; i < N1 - 1; ++i) {
+        const unsigned ni = n0 + i * st;
+        T3_FENCE();
+        const d2 a0 = sRec[ni], a1 = sRec[NV + ni], a2 = sRec[2 * NV + ni];
+        const double qi[6] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y};
+#pragma unroll
+        for (int j = i + 1; j < N1; ++j) {
+          const unsigned n = n0 + j * st;
+          T3_FENCE();
+          const d2 p0 = sRec[n], p1 = sRec[NV + n], p2 = sRec[2 * NV + n];
+          const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
+          double F[4];
+          ec_flux_dir<MODAL>(qi, qj, gxv, gyv, F);
+          const double c = Sd[i * N1 + j];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { acc[i][k] = __builtin_fma(c, F[k], acc[i][k]); acc[j][k] = __builtin_fma(-c, F[k], acc[j][k]); }
+          T3_PIN4(acc[i]); T3_PIN4(acc[j]);
+        }
+      }
+    }
+  }
+  // viscous volume divergence of the wave's nodes (phase 1): requested here, consumed after the exchange below
+  double dvs[NR][3];
+  if (VISC) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const unsigned sl = slot[r] < (unsigned)(nE * Nq) ? slot[r] : 0u;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dvs[r][c] = SG[c * KN + e0 * Nq + sl];
+    }
+  }
+  __syncthreads();   // every lane is past its reads of the records, whose space takes the lines' results
+  {   // collocated projection and lift along the line: r_d[node i] = PD[node i] acc_i + PW_A[i] Gf_A + PW_B[i] Gf_B
+    const double ptA = sTab[TL.PTF + (2 * d) * N1 + o], ptB = sTab[TL.PTF + (2 * d + 1) * N1 + o];
+    const double* PFA = sTab + TL.PF + (2 * d) * N1;
+    const double* PFB = sTab + TL.PF + (2 * d + 1) * N1;
+    const unsigned q0 = n0 - el * Nq;
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+      const double pd = sTab[TL.PD + q0 + i * st], pa = PFA[i] * ptA, pb = PFB[i] * ptB;
+      double rr[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) rr[c] = __builtin_fma(pb, GfB[c], __builtin_fma(pa, GfA[c], pd * acc[i][c]));
+      const unsigned n = n0 + i * st;
+      sS[(2 * d) * NV + n] = make_double2(rr[0], rr[1]);
+      sS[(2 * d + 1) * NV + n] = make_double2(rr[2], rr[3]);
+    }
+  }
+  __syncthreads();
+
+  // ---- node rounds: rhs at the Gauss nodes = -(r_0 + r_1)/J (+ viscous volume divergence / J), then Pq -----------------------
+  double R[NR][4];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const unsigned s = slot[r], ev = s / Nq;
+    const double iJ = rcp_refined(sGeo[ev * GEO_STRIDE + 4]);
+    const d2 a0 = sS[s], a1 = sS[NV + s], b0 = sS[2 * NV + s], b1 = sS[3 * NV + s];
+    R[r][0] = -(a0.x + b0.x) * iJ; R[r][1] = -(a0.y + b0.y) * iJ; R[r][2] = -(a1.x + b1.x) * iJ; R[r][3] = -(a1.y + b1.y) * iJ;
+    if (VISC) {
+      const double vs = viscous ? iJ : 0.0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) R[r][c + 1] = __builtin_fma(dvs[r][c], vs, R[r][c + 1]);
+    }
+  }
+  double out[NR][4];
+  if (MODAL) {
+    __syncthreads();   // every lane is past its reads of the lines' results
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      sA[slot[r]] = make_double2(R[r][0], R[r][1]);
+      sA[NV + slot[r]] = make_double2(R[r][2], R[r][3]);
+    }
+    __syncthreads();
+    // out = Pq R as in kt2_rhs: W[a + N1 b] = sum_j IP[a,j] R[b + N1 j], out[a + N1 b] = sum_i IP[b,i] W[a + N1 i]
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const unsigned ev = slot[r] / Nq, a = nq[r] % N1, b = nq[r] / N1;
+      const double* c = sTab + TL.IP + a * N1;
+      const d2* rw = sA + ev * Nq + b;
+      d2 p = rw[0], t = rw[NV];
+      const double c0 = c[0];
+      double w0 = c0 * p.x, w1 = c0 * p.y, w2 = c0 * t.x, w3 = c0 * t.y;
+#pragma unroll
+      for (int j = 1; j < N1; ++j) {
+        p = rw[N1 * j]; t = rw[NV + N1 * j];
+        const double cj = c[j];
+        w0 = __builtin_fma(cj, p.x, w0); w1 = __builtin_fma(cj, p.y, w1);
+        w2 = __builtin_fma(cj, t.x, w2); w3 = __builtin_fma(cj, t.y, w3);
+      }
+      sB[slot[r]] = make_double2(w0, w1);
+      sB[NV + slot[r]] = make_double2(w2, w3);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const unsigned ev = slot[r] / Nq, a = nq[r] % N1, b = nq[r] / N1;
+      const double* c = sTab + TL.IP + b * N1;
+      const d2* rw = sB + ev * Nq + a;
+      d2 p = rw[0], t = rw[NV];
+      const double c0 = c[0];
+      out[r][0] = c0 * p.x; out[r][1] = c0 * p.y; out[r][2] = c0 * t.x; out[r][3] = c0 * t.y;
+#pragma unroll
+      for (int i = 1; i < N1; ++i) {
+        p = rw[N1 * i]; t = rw[NV + N1 * i];
+        const double ci = c[i];
+        out[r][0] = __builtin_fma(ci, p.x, out[r][0]); out[r][1] = __builtin_fma(ci, p.y, out[r][1]);
+        out[r][2] = __builtin_fma(ci, t.x, out[r][2]); out[r][3] = __builtin_fma(ci, t.y, out[r][3]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) out[r][f] = R[r][f];
+  }
+  // ---- store, or fused low-storage RK stage (dg2D_euler_quad.jl:204-205) -------------------------------------------------------
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const unsigned n = tid + r * TW;
+    if (n < (unsigned)(nE * Nq)) {
+      if (lf.Qw) {   // (uniform)
+        double ro[4], qo[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { const int64_t idx = f * KN + e0 * Nq + n; ro[f] = lf.res[idx]; qo[f] = lf.Qw[idx]; }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const int64_t idx = f * KN + e0 * Nq + n;
+          const double rr = __builtin_fma(lf.a, ro[f], lf.dt * out[r][f]);
+          lf.res[idx] = rr;
+          lf.Qw[idx] = __builtin_fma(lf.b, rr, qo[f]);
+        }
+      } else {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) rhs[f * KN + e0 * Nq + n] = out[r][f];
+      }
+    }
+  }
+}
+
+}  // namespace t3
+
+#define ESDG_T3_DISPATCH(N1v, BODY)                  \
+  switch (N1v) {                                     \
+    case 2: { constexpr int N1 = 2; BODY; } break;   \
+    case 3: { constexpr int N1 = 3; BODY; } break;   \
+    case 4: { constexpr int N1 = 4; BODY; } break;   \
+    case 5: { constexpr int N1 = 5; BODY; } break;   \
+    case 6: { constexpr int N1 = 6; BODY; } break;   \
+    case 7: { constexpr int N1 = 7; BODY; } break;   \
+    case 8: { constexpr int N1 = 8; BODY; } break;   \
+    default: return -1;                              \
+  }
+
+template <int N1, bool MODAL, bool VISC>
+static void launch_rhs3(const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U, const double* SG,
+                        const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s) {
+  using G = t3::G3<N1>;
+  const int nb = (int)((M.e_count + G::E - 1) / G::E);
+  hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
+}
+
+// last phase on meshes without walls; returns -1 where the v3 kernel does not apply (caller falls back to kt2_rhs)
+int launch_rhs_tensor3(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
+                       const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s) {
+  if (M.e_count <= 0) return 0;
+  if (M.bc) return -1;
+  const bool modal = ph.formulation != 0, visc = ph.formulation == 1;
+  ESDG_T3_DISPATCH(N1v, {
+    if (!modal) (launch_rhs3<N1, false, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
+    else if (visc) (launch_rhs3<N1, true, true>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
+    else (launch_rhs3<N1, true, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
+  });
+  return (int)hipGetLastError();
+}
+
+}  // namespace esdg

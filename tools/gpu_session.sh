@@ -1,0 +1,69 @@
+#!/bin/bash
+# One parameterised GPU-box session script (round 4 on; replaces the per-pass tools/session_r03*.sh of round 3):
+#   gpurun -- 'bash tools/gpu_session.sh <step> [args] [-- <step> [args] ...]'
+# Steps (each writes under gpurun_out/<step>*; a failing step stops the chain):
+#   test [pytest args]     GPU suite (default: tests -m gpu -q), log in gpurun_out/pytest_gpu.log
+#   smoke                  __graft_entry__.smoke()
+#   abenv VAR=VAL [bench args]   same-box A/B of an environment switch of libesdg_hip.so (e.g. ESDG_V2=rhs): new/base x 3
+#   ablib alt.so [bench args]    same-box A/B of two builds (libesdg_hip.so vs esdg_cns_amd/variants/<alt.so>)
+#   kstats TAG [bench args]      rocprofv3 --kernel-trace --stats of one bench run, per-kernel averages
+#   bench [bench args]           python bench.py ... > gpurun_out/bench_<n>.json
+#   py script.py [args]          python <script> (log in gpurun_out/py_<name>.log)
+#   ubench name                  build + run tools/ubench/<name>.hip (log in gpurun_out/ubench_<name>.log)
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+grepms() { grep -o '"ms_per_step": [0-9.]*\|"phase_ms": \[[^]]*\]\|"kernel_ms": [0-9.]*' | tr '\n' ' '; }
+run_step() {
+  local step=$1; shift
+  case $step in
+    test)
+      local a=("$@"); [ ${#a[@]} -eq 0 ] && a=(tests -m gpu -q)
+      timeout -k 10 1000 python -m pytest "${a[@]}" > gpurun_out/pytest_gpu.log 2>&1; local rc=$?
+      tail -5 gpurun_out/pytest_gpu.log; return $rc ;;
+    smoke)
+      timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; local rc=$?
+      tail -2 gpurun_out/smoke.log; return $rc ;;
+    abenv)
+      local kv=$1; shift
+      for v in new base new base new base; do
+        echo -n "$v: "
+        if [ $v = base ]; then (export "$kv"; timeout -k 10 300 python bench.py --no-cpu-baseline "$@" 2>/dev/null | grepms)
+        else timeout -k 10 300 python bench.py --no-cpu-baseline "$@" 2>/dev/null | grepms; fi
+        echo
+      done ;;
+    ablib)
+      local alt=$1; shift
+      cp esdg_cns_amd/libesdg_hip.so /tmp/ab_new.so
+      for v in new base new base new base; do
+        if [ $v = base ]; then cp esdg_cns_amd/variants/$alt esdg_cns_amd/libesdg_hip.so; else cp /tmp/ab_new.so esdg_cns_amd/libesdg_hip.so; fi
+        echo -n "$v: "; timeout -k 10 300 python bench.py --no-cpu-baseline "$@" 2>/dev/null | grepms; echo
+      done
+      cp /tmp/ab_new.so esdg_cns_amd/libesdg_hip.so ;;
+    kstats)
+      local tag=$1; shift
+      bash tools/kstats.sh "$tag" "$@" ;;
+    bench)
+      local n=$(ls gpurun_out/bench_*.json 2>/dev/null | wc -l)
+      timeout -k 10 900 python bench.py "$@" > gpurun_out/bench_$n.json 2> gpurun_out/bench_$n.err; local rc=$?
+      tail -c 3000 gpurun_out/bench_$n.json; return $rc ;;
+    py)
+      local s=$1; shift
+      timeout -k 10 900 python "$s" "$@" > gpurun_out/py_$(basename $s .py).log 2>&1; local rc=$?
+      tail -25 gpurun_out/py_$(basename $s .py).log; return $rc ;;
+    ubench)
+      local n=$1; shift
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/ub_$n tools/ubench/$n.hip || return 1
+      timeout -k 10 300 /tmp/ub_$n "$@" > gpurun_out/ubench_$n.log 2>&1; local rc=$?
+      cat gpurun_out/ubench_$n.log | tail -40; return $rc ;;
+    *) echo "unknown step $step"; return 2 ;;
+  esac
+}
+args=()
+for a in "$@"; do
+  if [ "$a" = "--" ]; then
+    echo "=== ${args[*]}"; run_step "${args[@]}" || { echo "step failed: ${args[*]}"; exit 1; }
+    args=()
+  else args+=("$a"); fi
+done
+[ ${#args[@]} -gt 0 ] && { echo "=== ${args[*]}"; run_step "${args[@]}" || { echo "step failed: ${args[*]}"; exit 1; }; }
+exit 0
