@@ -554,6 +554,9 @@ struct esdg_ctx {
   Tables T{};
   TensorTables TT{};
   bool use_fast = false;
+  bool bf = false;         // trace buffers laid out by mesh face (MeshDev::bf): 2D contexts whose phases all run v2 / v3 kernels;
+                           // ESDG_TRACE_LAYOUT=face in the environment: on (A/B; measured slower, off by default)
+  bool force_linear = false;   // ... switched off for the calls that mix in a round-1 kernel (esdg_viscous_entropy_test)
   int v2 = 0;              // ESDG_V2=1 | rhs | sigma in the environment: the v2 kernel where a v3 kernel exists (A/B; bit 0: phase 1,
                            // bit 1: last phase)
   int v1 = 0;              // ESDG_V1=1 in the environment: round-1 tensor kernels only (A/B against esdg_kernels_tensor2.hip);
@@ -568,7 +571,7 @@ struct esdg_ctx {
   int Np = 0, Nq = 0, Nfq = 0;
   // device storage
   DevBuf d_pair_ij, d_pair_c, d_inc_ptr, d_inc, d_Ef_i, d_Ef_v, d_Ph_i, d_Ph_v, d_Lf_i, d_Lf_v, d_Dr_i, d_Dr_v, d_Ds_i,
-      d_Ds_v, d_Vq, d_Pq, d_geo, d_fnrm, d_fnd, d_fsd, d_wgeo, d_mapP, d_bc, d_vlid, d_wJq, d_sendlist, d_partial;
+      d_Ds_v, d_Vq, d_Pq, d_geo, d_fnrm, d_fnd, d_fsd, d_wgeo, d_mapP, d_bc, d_vlid, d_wJq, d_sendlist, d_partial, d_mapP_s, d_sendlist_s;
   DevBuf t_dbl, t_int, d_G9, d_Jq, d_nrm, d_hdv, d_hdf, d_hdn;
   DevBuf t_nd, t_ni, t_fd, t_fi;   // per-node rows of the v2 tensor kernels
   DevBuf t_rvd, t_rvi, t_rfd, t_rfi;   // packed rows of kt2_rhs (RhsRows)
@@ -894,6 +897,25 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   UP(d_Dr_i, eDr.idx); UP(d_Dr_v, eDr.val); UP(d_Ds_i, eDs.idx); UP(d_Ds_v, eDs.val);
   UP(d_Vq, Vq.a); UP(d_Pq, Pq.a);
   UP(d_geo, geo); UP(d_mapP, mapP); UP(d_sendlist, sendlist);
+  // trace buffers by mesh face (MeshDev::bf): neighbour indices and pack lists as slots of that layout
+  // Measured in round 4 (profiles/experiments/README.md): phase 0's stores +12 % (four planes per store instruction), phase 1 +1 %,
+  // last phase -1 %, RHS +1.7 % -- the over-fetch the layout removes is served by the Infinity Cache (the traces were written by the
+  // kernel before), not by HBM.  Off unless ESDG_TRACE_LAYOUT=face.
+  c->bf = false;
+  if (const char* env = getenv("ESDG_TRACE_LAYOUT"))
+    c->bf = env[0] == 'f' && use_fast && c->v1 == 0 && !c->ph.dbg && N1 >= 2 && N1 <= 8 && (int64_t)K * Nfq < ((int64_t)1 << 31);
+  if (c->bf) {
+    const int64_t KF = (int64_t)K * Nfq, KN1 = (int64_t)K * N1;
+    auto slot = [&](int32_t n) -> int32_t {
+      if ((int64_t)n >= KF) return n;   // ghost records stay behind the planes
+      const int64_t e = n / Nfq, fn = n % Nfq;
+      return (int32_t)((fn / N1) * KN1 + e * N1 + fn % N1);
+    };
+    std::vector<int32_t> mapPs(mapP.size()), sls(sendlist.size());
+    for (size_t i = 0; i < mapP.size(); ++i) mapPs[i] = slot(mapP[i]);
+    for (size_t i = 0; i < sendlist.size(); ++i) sls[i] = slot(sendlist[i]);
+    UP(d_mapP_s, mapPs); UP(d_sendlist_s, sls);
+  }
   {   // per-node normals exactly as passed (MeshDev::fnrm)
     std::vector<double> fn3((size_t)K * Nfq * 3);
     for (size_t n = 0; n < (size_t)K * Nfq; ++n) { fn3[3 * n] = mesh->nxJ[n]; fn3[3 * n + 1] = mesh->nyJ[n]; fn3[3 * n + 2] = mesh->sJ[n]; }
@@ -1305,10 +1327,12 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
     if (e_count == 0) return ESDG_OK;
   }
   struct RangeGuard {   // full-range launches leave the mesh record untouched
-    MeshDev& M; int64_t K;
-    ~RangeGuard() { M.e_begin = 0; M.e_count = K; M.launch_role = 0; }
-  } rg{ctx->M, ctx->K};
+    MeshDev& M; int64_t K; const int32_t* mapP;
+    ~RangeGuard() { M.e_begin = 0; M.e_count = K; M.launch_role = 0; M.mapP = mapP; M.bf = 0; }
+  } rg{ctx->M, ctx->K, ctx->M.mapP};
   if (ranged) { ctx->M.e_begin = e_begin; ctx->M.e_count = e_count; ctx->M.launch_role = role; }
+  const bool bf = ctx->bf && !ctx->force_linear;   // traces by mesh face: the kernels below see slots in mapP
+  if (bf) { ctx->M.mapP = ctx->d_mapP_s.as<int32_t>(); ctx->M.bf = 1; }
   if (!ctx->ws) return fail(ESDG_ERR_STATE, "workspace not bound (esdg_bind_workspace)");
   if (phase < 0 || phase >= ctx->nphases) return fail(ESDG_ERR_ARG, "bad phase %d", phase);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1319,7 +1343,7 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
   double* B = visc ? reinterpret_cast<double*>(ctx->ws + ctx->off_B) : nullptr;
   double* SG = (visc && ctx->use_fast) ? reinterpret_cast<double*>(ctx->ws + ctx->off_S) : nullptr;
   int rc = 0;
-  const int32_t* sl = ctx->d_sendlist.as<int32_t>();
+  const int32_t* sl = bf ? ctx->d_sendlist_s.as<int32_t>() : ctx->d_sendlist.as<int32_t>();
   if (ctx->dim == 3) {
     if (phase == 0) {
       rc = launch_project_hex(ctx->T.N1, ctx->HT, ctx->M, ctx->ph, Q, A_U, s);
@@ -1338,7 +1362,11 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
     // v2 kernel (the visc_test reduction stays with kt_sigma); ESDG_V1=1: A/B.  On meshes with walls the two viscous phases
     // must come from the same set (kt_sigma stores sigma for kt_rhs, kt2_sigma the volume divergence and, at boundary
     // nodes, minus the prescribed stress jump for kt2_rhs): v2 only if neither phase is forced to v1; ESDG_V1=walls: v1 there
-    if (ctx->use_fast && (ctx->M.bc ? v2_on_walls(ctx) : !(ctx->v1 & 1)))
+    rc = -1;
+    if (ctx->use_fast && !ctx->M.bc && !ctx->ph.dbg && !(ctx->v1 & 1) && !(ctx->v2 & 1))   // v3 kernel (ESDG_V2=sigma: the v2 kernel, A/B)
+      rc = launch_sigma_tensor3(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, SG, s);
+    if (rc != -1) {}
+    else if (ctx->use_fast && (ctx->M.bc ? v2_on_walls(ctx) : !(ctx->v1 & 1)))
       rc = launch_sigma_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, SG, s);
     else
       rc = ctx->use_fast ? launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, SG, nullptr, s)
@@ -1407,7 +1435,9 @@ int esdg_halo_pack(esdg_ctx* ctx, int xch, void* stream) {
   if (!ctx->ws) return fail(ESDG_ERR_STATE, "workspace not bound (esdg_bind_workspace)");
   if (!ctx->nsend) return ESDG_OK;
   const Exchange& x = ctx->xch[xch];
-  int rc = launch_pack(reinterpret_cast<const double*>(ctx->ws + x.buf_off), x.ncomp, ctx->d_sendlist.as<int32_t>(), ctx->nsend,
+  const bool bf = ctx->bf && !ctx->force_linear;
+  int rc = launch_pack(reinterpret_cast<const double*>(ctx->ws + x.buf_off), x.ncomp,
+                       bf ? ctx->d_sendlist_s.as<int32_t>() : ctx->d_sendlist.as<int32_t>(), ctx->nsend,
                        reinterpret_cast<double*>(ctx->ws + x.send_off), static_cast<hipStream_t>(stream));
   if (rc) return fail(ESDG_ERR_NO_DEVICE, "pack launch: %s", hipGetErrorString((hipError_t)rc));
   return ESDG_OK;
@@ -1691,6 +1721,9 @@ int esdg_viscous_entropy_test(esdg_ctx* ctx, const double* Q, double* out, void*
   if (!ctx->M.wJq) return fail(ESDG_ERR_STATE, "wJq was not supplied at esdg_create");
   if (!ctx->ws) return fail(ESDG_ERR_STATE, "workspace not bound (esdg_bind_workspace)");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // (phase 1 below is the round-1 kt_sigma, which reads the linear trace layout: phase 0 and its pack write that one here)
+  struct LinearGuard { esdg_ctx* c; ~LinearGuard() { c->force_linear = false; } } lg{ctx};
+  ctx->force_linear = true;
   int rc = esdg_rhs_phase(ctx, 0, Q, nullptr, stream);   // (packs what the neighbours need)
   if (rc) return rc;
   if (ctx->nghost) {   // sharded: the neighbours' traces of phase 0, then this rank's share of the sum (like esdg_rhstest)

@@ -63,6 +63,8 @@ int launch_project_tensor2(int N1, const TensorTables& TT, const MeshDev& M, con
 // v3 last-phase kernel (esdg_kernels_tensor3.hip); -1 where it does not apply
 int launch_rhs_tensor3(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
                        const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s);
+int launch_sigma_tensor3(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
+                         double* B, double* SG, hipStream_t s);
 struct LsrkFuse;
 int launch_rhs_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
                       const double* A_U, const double* SG, const double* B, double* rhs, const LsrkFuse& lf,
@@ -118,7 +120,21 @@ struct MeshDev {
   // esdg_rhs_phase_range): 1 = the interior beside which boundary strips run, 2 = a boundary strip.  The persistent
   // kt2_sigma leaves a few workgroup slots free in role 1 and asks for no more than those in role 2 (ESDG_T2_RESERVE).
   int32_t launch_role;
+  // Trace buffers laid out BY MESH FACE (v2 / v3 tensor kernels, round 4): record of local face node fn = f N1 + k of element e
+  // at slot f (K N1) + e N1 + k instead of e Nfq + fn -- four planes, one per face of the reference element, so that the faces a
+  // workgroup's consecutive elements read from their neighbours across face f are ONE contiguous run of the opposite plane
+  // (1 KB for six elements at N = 4) instead of one 160-byte run per element inside that element's 640-byte block.  Measured
+  // with known byte counts (profiles/r04_fetch_calibration.txt): the per-element runs fetch 1.6 x their bytes (two 128-byte lines
+  // per 160-byte run) and stream at 4.7 instead of 6.4 TB/s.  With bf set, mapP holds SLOTS (remapped on the host, ghost
+  // slots >= K Nfq unchanged).  0: the linear layout (round-1 and generic kernels, hexahedra).
+  int32_t bf;
 };
+
+// slot of the trace record (A_U, B) of local face node fn of element e
+template <int N1>
+__device__ __forceinline__ int64_t trace_slot(const MeshDev& M, int64_t e, unsigned fn) {
+  return M.bf ? (int64_t)(fn / N1) * (M.K * N1) + e * N1 + (int64_t)(fn % N1) : e * (4 * N1) + (int64_t)fn;
+}
 
 // Attribution builds (-DESDG_EXP_WINDOW=mask, mask = 2^k - 1; tools/session_r03b.sh): every global address a kernel of the
 // tensor path forms -- state, geometry, neighbour index, traces, outputs -- is folded into the first mask+1 elements, which

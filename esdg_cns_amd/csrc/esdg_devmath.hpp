@@ -62,6 +62,12 @@ __device__ __forceinline__ double sqrt_fast(double x) {
 // pressure of the NORMAL kinetic energy only, sqrt(|u_n|) quirk Q1) for the face normal (nx, ny) / sJ.  gm1 = gamma - 1.
 __device__ __forceinline__ void trace_rest(double* q, double nx, double ny, double isJ, double gm1);
 
+// the value lane 0 of the wave holds (wave-uniform afterwards)
+__device__ __forceinline__ double first_lane(double x) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+
 // Wave issue priority (s_setprio, 0 = default ... 3) at the two ends of a one-shot workgroup's life: PRIO_ENTRY while a new
 // workgroup computes its addresses and issues its global loads, PRIO_EXIT from the gather / projection / store stage on.  0 = no
 // instruction.  Measured in round 3 (profiles/experiments/r03_prio_ab.log): entry priority 3 takes 6 % off the hex phase-0 kernel
@@ -84,9 +90,14 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// (the part without the logarithms: q[6], q[7]; kt3_rhs takes the logs only where some flux of the wave reads them)
+__device__ __forceinline__ void trace_rest_nolog(double* q, double nx, double ny, double isJ, double gm1);
 __device__ __forceinline__ void trace_rest(double* q, double nx, double ny, double isJ, double gm1) {
   q[4] = log_pos(q[0]);
   q[5] = log_pos(q[3]);
+  trace_rest_nolog(q, nx, ny, isJ, gm1);
+}
+__device__ __forceinline__ void trace_rest_nolog(double* q, double nx, double ny, double isJ, double gm1) {
   const double R = rcp_refined(q[0] * q[3]);
   const double ib = R * q[0], ir = R * q[3];                                 // 1/beta, 1/rho
   const double E = __builtin_fma(.5 * q[0], __builtin_fma(q[1], q[1], q[2] * q[2]), q[0] * ib * (.5 / gm1));

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_s
         double* bb = B + ESDG_EW(ce0) * Nfq * B_NC;
 #pragma unroll
         for (int r = 0; r < BPT; ++r) { const int idx = (int)tid + r * G::GT; if (idx < cnb) bb[idx] = bt[r]; }
-      } else if (cfa) { double* bb = B + (ESDG_EW(ce0) * Nfq + tf) * B_NC; bb[0] = csn[0]; bb[1] = csn[1]; bb[2] = csn[2]; }
+      } else if (cfa) { double* bb = B + trace_slot<N1>(M, ESDG_EW(ce0) + ef, fn) * B_NC; bb[0] = csn[0]; bb[1] = csn[1]; bb[2] = csn[2]; }
       __builtin_amdgcn_sched_barrier(0);
     }
     // mapP first: it is waited for first (vmcnt counts in issue order), the others may then still be in flight.
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_s
       } else if (ESDG_T2_SIGMA_DEFER_STORES) {
         csn[0] = sn[0]; csn[1] = sn[1]; csn[2] = sn[2]; cfa = fact; ce0 = e0;
       } else if (fact) {
-        double* bb = B + (ESDG_EW(e0) * Nfq + tf) * B_NC;
+        double* bb = B + trace_slot<N1>(M, ESDG_EW(e0) + ef, fn) * B_NC;
         bb[0] = sn[0]; bb[1] = sn[1]; bb[2] = sn[2];
       }
     }
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_s
       double* bb = B + ESDG_EW(ce0) * Nfq * B_NC;
 #pragma unroll
       for (int r = 0; r < BPT; ++r) { const int idx = (int)tid + r * G::GT; if (idx < cnb) bb[idx] = sBs[idx]; }
-    } else if (cfa) { double* bb = B + (ESDG_EW(ce0) * Nfq + tf) * B_NC; bb[0] = csn[0]; bb[1] = csn[1]; bb[2] = csn[2]; }
+    } else if (cfa) { double* bb = B + trace_slot<N1>(M, ESDG_EW(ce0) + ef, fn) * B_NC; bb[0] = csn[0]; bb[1] = csn[1]; bb[2] = csn[2]; }
   }
   T2_STAMP_FLUSH;
 }
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_project(TensorTables TT, Mesh
   double qf[4];
   prim_of_v2<MODAL>(Vf, qf);
   if (fact) {
-    d2* rec = reinterpret_cast<d2*>(A_U + (ESDG_EW(e0) * Nfq + tf) * FAU_NC);
+    d2* rec = reinterpret_cast<d2*>(A_U + trace_slot<N1>(M, ESDG_EW(e0) + ef, fn) * FAU_NC);
     rec[0] = make_double2(qf[0], qf[1]);
     rec[1] = make_double2(qf[2], qf[3]);
   }
@@ -948,6 +948,7 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (RhsLds2<N1, MODAL, VISC>::WPE)) void
   double x[4], geo[GPT], qM[8], qP[8], bPn[3] = {0, 0, 0}, bOwn[3] = {0, 0, 0}, dvs[3] = {0, 0, 0};
   const unsigned tvl = tv < (unsigned)(nE * Nq) ? tv : 0u, tfl = tf < (unsigned)(nE * Nfq) ? tf : 0u, tvg = tv;
   const int64_t nf = e0 * Nfq + tfl;
+  const int64_t nfs = trace_slot<N1>(M, e0 + tfl / Nfq, tfl % Nfq);   // this face node's record in the trace buffers (MeshDev::bf)
   const unsigned mp = ESDG_EWN((unsigned)M.mapP[nf], Nfq);
   // (Measured and removed in round 3 -- a structured-neighbour guess of mp from kernel arguments, the neighbour-trace loads
   // issued from it at entry and mp verified at first use: 4 % slower.  The traces are not needed until after the volume-volume
@@ -1013,7 +1014,7 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (RhsLds2<N1, MODAL, VISC>::WPE)) void
     const d2* aM = reinterpret_cast<const d2*>(A_U + nfx * FAU_NC);
     const d2* aP = reinterpret_cast<const d2*>(A_U + mpx * FAU_NC);
 #else
-    const d2* aM = reinterpret_cast<const d2*>(A_U + nf * FAU_NC);
+    const d2* aM = reinterpret_cast<const d2*>(A_U + nfs * FAU_NC);
     const d2* aP = reinterpret_cast<const d2*>(A_U + (size_t)mp * FAU_NC);
 #endif
 #pragma unroll
@@ -1125,7 +1126,7 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (RhsLds2<N1, MODAL, VISC>::WPE)) void
     T2_STAMP(4);   // volume-volume rounds
     if (VISC) {   // needed after the volume-face pairs: issued here, their destinations are not live during the rounds above
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { bPn[c] = B[(size_t)mp * B_NC + c]; bOwn[c] = B[nf * B_NC + c]; dvs[c] = SG[c * KN + e0 * Nq + tvl]; }
+      for (int c = 0; c < 3; ++c) { bPn[c] = B[(size_t)mp * B_NC + c]; bOwn[c] = B[nfs * B_NC + c]; dvs[c] = SG[c * KN + e0 * Nq + tvl]; }
     }
     // ---- face lanes: interface flux and penalty from the two trace states (registers only) -----------------------------------
     const double* gf = sGeo + ef * GEO_STRIDE;     // (slots of elements beyond the mesh hold the clamped loads: finite, unused)

@@ -105,9 +105,9 @@ __device__ __forceinline__ void ec_flux_dir(const double* qL, const double* qR, 
 #endif
 }
 
-// conservative -> (rho,u,v,beta,log rho,log beta)
+// conservative -> (rho,u,v,beta)
 template <bool MODAL>
-__device__ __forceinline__ void prim_logs(const double* U, double* q) {
+__device__ __forceinline__ void prims(const double* U, double* q) {
   constexpr double GM1 = Gas2<MODAL>::GM1;
   const double m2 = U[1] * U[1] + U[2] * U[2];
   const double rre = U[0] * U[3] - .5 * m2;
@@ -117,6 +117,11 @@ __device__ __forceinline__ void prim_logs(const double* U, double* q) {
   q[1] = U[1] * ir;
   q[2] = U[2] * ir;
   q[3] = (U[0] * U[0]) * (U[0] * R) * (1.0 / (2 * GM1));
+}
+// conservative -> (rho,u,v,beta,log rho,log beta)
+template <bool MODAL>
+__device__ __forceinline__ void prim_logs(const double* U, double* q) {
+  prims<MODAL>(U, q);
   q[4] = log_pos(U[0]);
   q[5] = log_pos(q[3]);
 }
