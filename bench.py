@@ -36,8 +36,13 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 fp64 lanes x 2 flop x 2.4 G
 # What this pool's MI355X boxes deliver to the simplest kernels (tools/ubench, output committed as profiles/r03_ubench.txt):
 # a plain device-to-device copy and independent fp64 FMAs from 4 waves x 8 chains per SIMD.  The two floors of
 # `roofline.floors_ms` are traffic / PRACTICAL_HBM_GBS and fp64 flops / MEASURED_FP64_TFLOPS; `roofline.bound` names the larger.
-PRACTICAL_HBM_GBS = 5300.0
+PRACTICAL_HBM_GBS = 4700.0    # round 4: a hand-written float4 / double copy (read + write) on this pool, tools/ubench/fetch_calib.hip ->
+                              # profiles/r04_fetch_calibration.txt: 4.6-4.8 TB/s; read-only streams 6.2, write-only 6.5-6.9 (round 3
+                              # used a torch copy_ measured at 5.3 on other boxes of the pool)
 MEASURED_FP64_TFLOPS = 66.5
+VALU_CYCLES_PER_INST = 4.7    # measured issue cost of one fp64 wave-instruction per SIMD (tools/ubench/fma64.hip, 4 waves x 8 chains)
+N_SIMD = 1024                 # 256 CUs x 4
+SCLK_HZ = 2.4e9
 PREWARM_EVALS = 200           # untimed RHS evaluations before the warm-up steps (GPU clock ramp), see run()
 REPS = 5                      # repetitions of the K-step timed region (the first one is the contract's; median/min reported)
 
@@ -62,6 +67,28 @@ def build_problem(N, Kx, Ky_total, e0, e1, formulation):
     rho, u, v, p = ph.vortex(xx, yy, 0)
     Q = [np.asfortranarray(q) for q in ph.primitive_to_conservative(rho, u, v, p)]
     return rd, md, ops, Q
+
+
+def rough_state(Q, seed=20250117):
+    """SURVEY.md section 8(d) robustness variant of a 2D state: rho and p multiplied by 1 + 0.01 xi, xi in [-1, 1) from
+    splitmix64(seed), xi = 2 (x >> 11) 2^-53 - 1, node-major order.  On this state no wave of the last-phase kernel finds its
+    densities within 1e-4 of each other, so every log-mean takes the reference's logarithm branch and none of the
+    data-dependent short cuts of kt3_rhs (all-series flux variant, logarithms skipped) applies."""
+    rho, ru, rv, E = [np.array(q, dtype=np.float64, order="F") for q in Q]
+    n = rho.size
+    x = (np.arange(1, 2 * n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        z = x
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    xi = 2.0 * (z >> np.uint64(11)).astype(np.float64) * 2.0 ** -53 - 1.0
+    u, v = ru / rho, rv / rho
+    p = 0.4 * (E - .5 * rho * (u * u + v * v))
+    a = (1 + 0.01 * xi[:n]).reshape(rho.shape, order="F")
+    b = (1 + 0.01 * xi[n:]).reshape(rho.shape, order="F")
+    rho2, p2 = rho * a, p * b
+    return [np.asfortranarray(q) for q in (rho2, rho2 * u, rho2 * v, p2 / 0.4 + .5 * rho2 * (u * u + v * v))]
 
 
 def build_hex_problem(N, Kx, Ky, Kz_total, e0, e1, curve=0.0, per_node=False):
@@ -217,6 +244,57 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def attach_with_agreement(attach, destroy, prove, dist, flag_device, rank, watchdog_s=300.0, _exit=os._exit):
+    """N > 1: attach the library's RCCL transport on every rank and agree on the outcome.  Returns (transport, rccl_ranks, note).
+    Stage 1: `attach()` (the id hand-off and esdg_comm_init: ncclCommInitRank + plan cross-check with the neighbours) on every
+    rank, then ONE agreement over the bootstrap group before any evaluation is posted.  A failure up to here has left no send or
+    receive pending, so every rank falls back to the torch.distributed transport together (the JSON line says so:
+    config.transport / config.transport_note; --require-rccl turns that into exit code 4).
+    Stage 2: `prove()` (two evaluations).  A rank that fails there may leave its peers inside a posted ncclRecv, which no
+    collective agreement can reach any more: it prints the reason and exits with code 5 (no fallback, no re-exec); its peers are
+    ended by the watchdog, which bounds both stages (exit code 6), so that a hung communicator ends the run instead of the round.
+    (`_exit` is the process exit used by stage 2 and the watchdog; the CPU test of this function replaces nothing else.)"""
+    import threading
+    import torch
+
+    def _hung():
+        print(f"bench.py: rank {rank}: RCCL attach / proving evaluations did not finish within {watchdog_s:g} s -- giving up", file=sys.stderr, flush=True)
+        _exit(6)
+    dog = threading.Timer(watchdog_s, _hung)
+    dog.daemon = True
+    dog.start()
+    err, rccl_ranks = "", 0
+    try:
+        rccl_ranks = attach()
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    flag = torch.tensor([1.0 if err else 0.0], device=flag_device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if float(flag.item()) > 0:
+        try:
+            destroy()
+        except Exception:  # noqa: BLE001
+            pass
+        dog.cancel()
+        note = "library RCCL transport could not be attached on a rank (" + (err or "another rank") + "); fell back to torch.distributed P2P"
+        if rank == 0:
+            print("bench.py: " + note, file=sys.stderr)
+        return "torch", 0, note
+    try:
+        prove()
+    except Exception as e:  # noqa: BLE001
+        print(f"bench.py: rank {rank}: evaluation over the library's RCCL transport failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        _exit(5)
+    dog.cancel()
+    return "rccl", rccl_ranks, None
+
+
+def exit_code(world, require_rccl, transport, rccl_ranks):
+    """Process exit code after the JSON line: 4 when --require-rccl was given and the library's RCCL transport did not run on
+    all ranks, else 0."""
+    return 4 if (world > 1 and require_rccl and (transport != "rccl" or rccl_ranks != world)) else 0
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` as typed: start the N ranks as a torch.distributed.run child (fresh processes; this one has
     not touched a GPU) and pass their output and exit code on."""
@@ -284,46 +362,17 @@ def run(args):
     out = eng.new_state()
     transport_note = None
     if world > 1 and transport == "rccl":
-        # Stage 1: the id hand-off and esdg_comm_init (ncclCommInitRank + plan cross-check with the neighbours) on every rank,
-        # then ONE agreement over the bootstrap group before any evaluation is posted.  A failure up to here has left no
-        # send or receive pending, so every rank can fall back to the torch.distributed transport together (the JSON line
-        # says so: config.transport / config.transport_note; --require-rccl turns that into exit code 4).
-        # Stage 2: two proving evaluations.  A rank that fails there may leave its peers inside a posted ncclRecv, which no
-        # collective agreement can reach any more: it prints the reason and the whole job exits non-zero (no fallback, no
-        # re-exec).  A watchdog bounds both stages, so that a hung communicator ends the run instead of the round.
-        import threading
+        def _prove():
+            for _ in range(2):
+                eng.rhs_into(Qd, out)
+            torch.cuda.synchronize()
 
-        def _hung():
-            print(f"bench.py: rank {rank}: RCCL attach / proving evaluations did not finish within 300 s -- giving up", file=sys.stderr, flush=True)
-            os._exit(6)
-        dog = threading.Timer(300.0, _hung)
-        dog.daemon = True
-        dog.start()
-        err = ""
-        try:
-            rccl_ranks = eng.attach_rccl()
-        except Exception as e:  # noqa: BLE001
-            err = f"{type(e).__name__}: {e}"
-        flag = torch.tensor([1.0 if err else 0.0], device=torch.device("cuda", dev) if args.backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if float(flag.item()) > 0:
-            try:
-                eng.L.esdg_comm_destroy(eng.ctx)
-            except Exception:  # noqa: BLE001
-                pass
-            eng.transport, transport, rccl_ranks = "torch", "torch", 0
-            transport_note = "library RCCL transport could not be attached on a rank (" + (err or "another rank") + "); fell back to torch.distributed P2P"
-            if rank == 0:
-                print("bench.py: " + transport_note, file=sys.stderr)
-        else:
-            try:
-                for _ in range(2):
-                    eng.rhs_into(Qd, out)
-                torch.cuda.synchronize()
-            except Exception as e:  # noqa: BLE001
-                print(f"bench.py: rank {rank}: evaluation over the library's RCCL transport failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
-                os._exit(5)
-        dog.cancel()
+        def _destroy():
+            eng.L.esdg_comm_destroy(eng.ctx)
+        flag_dev = torch.device("cuda", dev) if args.backend == "nccl" else "cpu"
+        transport, rccl_ranks, transport_note = attach_with_agreement(eng.attach_rccl, _destroy, _prove, dist, flag_dev, rank)
+        if transport != "rccl":
+            eng.transport = "torch"
     Np, K_local, nfld = eng.Np, eng.K, eng.nfld
 
     def sync_all():
@@ -364,21 +413,43 @@ def run(args):
     nph = eng.nphases
     nrep = 20
     stream = torch.cuda.current_stream()
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(nph + 1)] for _ in range(nrep)]
+    # (round 4: `nrep` back-to-back launches of ONE phase between two events, phase by phase, after a complete evaluation has
+    # filled the trace buffers -- an event between every two kernels of the normal sequence added its own gap to each of them,
+    # and the phases then summed to 3 % more than ms_per_step)
     q, o = C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr())
-    for ev in evs:
-        ev[0].record(stream)
-        for ph in range(nph):
+    eng.rhs_into(Qd, out)
+    phase_ms = []
+    for ph in range(nph):
+        e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
             engine.check(eng.L.esdg_rhs_phase(eng.ctx, ph, q, o, eng._stream()))
-            ev[ph + 1].record(stream)
-    torch.cuda.synchronize()
-    phase_ms = [float(np.mean([ev[ph].elapsed_time(ev[ph + 1]) for ev in evs])) for ph in range(nph)]
+        e0_.record(stream)
+        for _ in range(nrep):
+            engine.check(eng.L.esdg_rhs_phase(eng.ctx, ph, q, o, eng._stream()))
+        e1_.record(stream)
+        torch.cuda.synchronize()
+        phase_ms.append(float(e0_.elapsed_time(e1_)) / nrep)
     kdur_ms = phase_ms[-1]
+    # The same evaluation on a state without smooth regions (2D, one GPU): kt3_rhs takes data-dependent short cuts where a whole
+    # wave's densities agree to 1e-4 -- most of the vortex's far field -- with bit-identical results; this is the time without them.
+    rough_ms = None
+    if not hexw and world == 1:
+        Qr = eng.upload(rough_state(Q))
+        for _ in range(20):
+            eng.rhs_into(Qr, out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.rhs_into(Qr, out)
+        torch.cuda.synchronize()
+        rough_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        del Qr
+        eng.rhs_into(Qd, out)
     alg_bytes = 16.0 * nfld * Np * K_local       # read state once + write rhs once
     achieved = alg_bytes / (kdur_ms * 1e-3) / 1e9
 
     # --- PMC-derived figures (rocprofv3 passes of this command, tools/profile_round.sh -> profiles/pmc_traffic.json) ----
-    traffic = whole_traffic = prof_us = valu_frac = whole_valu_frac = fp64_flops = None
+    traffic = whole_traffic = prof_us = valu_frac = whole_valu_frac = fp64_flops = insts_k = insts_whole = None
     pmc_stale = None
     rec = {}
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -392,6 +463,7 @@ def run(args):
                 prof_us = rec.get("k_rhs_rocprofv3_avg_us")
                 whole_traffic = rec.get("whole_rhs_hbm_bytes")
                 fp64_flops = rec.get("k_rhs_fp64_flops_per_launch")
+                insts_k, insts_whole = rec.get("k_rhs_insts_valu_per_launch"), rec.get("whole_rhs_insts_valu")
                 if fp64_flops:
                     valu_frac = fp64_flops / (kdur_ms * 1e-3) / (FP64_VALU_PEAK_TFLOPS * 1e12)
                 if rec.get("whole_rhs_fp64_flops"):
@@ -399,7 +471,7 @@ def run(args):
         except Exception:
             pass
     kname = "kh_rhs (last phase: surface flux + flux differencing + lift)" if hexw else \
-        "kt2_rhs (last phase: flux differencing + viscous divergence + projection)"
+        "kt3_rhs (last phase: flux differencing + viscous divergence + projection)"
     # --- which roof binds: computed, per formulation, from the numbers of this line ------------------------------------
     # HBM floor = bytes moved / the pool's practical copy rate; fp64 floor = counted fp64 flops / the measured vector peak.
     # Bytes: the PMC traffic of this command where the committed profile is current, else the design bytes per element
@@ -421,20 +493,31 @@ def run(args):
     bytes_k = traffic if traffic else design_k * K_local
     bytes_whole = whole_traffic if whole_traffic else design_whole * K_local
     whole_flops = rec.get("whole_rhs_fp64_flops") if (rec and not pmc_stale) else None
+    # compute-side floor: ALL vector instructions the kernel issues (SQ_INSTS_VALU: fp64 arithmetic, logs, reciprocals, selects,
+    # integer and address work alike) at the measured issue cost of one wave-instruction per SIMD -- the fp64-flop floor alone
+    # ignored a quarter of the instruction stream
+    def _issue_ms(n):
+        return None if not n else n * VALU_CYCLES_PER_INST / (N_SIMD * SCLK_HZ) * 1e3
     floors = {"hbm_kernel": bytes_k / (PRACTICAL_HBM_GBS * 1e9) * 1e3,
               "fp64_kernel": None if not fp64_flops else fp64_flops / (MEASURED_FP64_TFLOPS * 1e12) * 1e3,
+              "valu_issue_kernel": _issue_ms(insts_k),
               "hbm_whole_rhs": bytes_whole / (PRACTICAL_HBM_GBS * 1e9) * 1e3,
               "fp64_whole_rhs": None if not whole_flops else whole_flops / (MEASURED_FP64_TFLOPS * 1e12) * 1e3,
+              "valu_issue_whole_rhs": _issue_ms(insts_whole),
               "bytes_basis": "pmc" if traffic else "design"}
 
     def _bound(h, f):
-        return "hbm" if (f is None or h >= f) else "fp64-valu"
+        # no counted instruction stream for this build (stale or absent PMC file): no claim
+        return None if f is None else ("hbm" if h >= f else "valu-issue")
     roofline = {
         # `bound`: the larger floor of the dominant kernel (see floors_ms); `frac` stays the HBM figure the north star names
         # (algorithmic bytes / kernel time / 8 TB/s), `valu_frac` the counted fp64 flops of the same kernel against the fp64
         # vector peak; `whole_rhs_bound` the same comparison over all phases of one evaluation
-        "bound": _bound(floors["hbm_kernel"], floors["fp64_kernel"]), "kernel": kname,
-        "whole_rhs_bound": _bound(floors["hbm_whole_rhs"], floors["fp64_whole_rhs"]),
+        "bound": _bound(floors["hbm_kernel"], floors["valu_issue_kernel"]), "kernel": kname,
+        "whole_rhs_bound": _bound(floors["hbm_whole_rhs"], floors["valu_issue_whole_rhs"]),
+        # measured time over each floor (1 = at the floor)
+        "kernel_over_floor": {"hbm": kdur_ms / floors["hbm_kernel"],
+                              "valu_issue": None if not floors["valu_issue_kernel"] else kdur_ms / floors["valu_issue_kernel"]},
         "floors_ms": floors, "practical_hbm_gbs": PRACTICAL_HBM_GBS, "measured_fp64_tflops": MEASURED_FP64_TFLOPS,
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic, "kernel_ms": kdur_ms, "phase_ms": phase_ms,
@@ -448,10 +531,14 @@ def run(args):
     # --- N > 1: the single-GPU time of the SAME per-rank shard (stand-alone periodic strip / slab, no exchange), so that a
     # scaling curve is read against its own weak-scaling base and not against the 512^2 point of --gpus 1 ------------------
     weak_base_ms = None
+    if world > 1 and not args.no_weak_base:
+        # every rank drops its engine -- and with it the library's RCCL communicator -- at the same point, then rank 0 runs the
+        # base alone while the others wait at the barrier below (no rank keeps a communicator whose peer is gone)
+        del eng
+        torch.cuda.empty_cache()
+        dist.barrier()
     if world > 1 and rank == 0 and not args.no_weak_base:
         try:
-            del eng
-            torch.cuda.empty_cache()
             if hexw:
                 rd1, md1, ops1, Q1 = build_hex_problem(N, Kx, Kx, args.kz_per_gpu, 0, Kx * Kx * args.kz_per_gpu, args.hex_curve,
                                                           args.hex_geometry == "per-node")
@@ -473,7 +560,7 @@ def run(args):
 
     if hexw:
         workload = (f"euler3d_hex_N{N}_{Kx}x{Kx}x{Kz_total}_periodic_box_lf{args.lf:g}" + (f"_curved{args.hex_curve:g}" if args.hex_curve else "")
-                    + ("" if args.hex_geometry == "per-node" else "_element_geometry"))
+                    + ("_pernode_geometry" if args.hex_geometry == "per-node" else "_element_geometry"))
         metric = f"element-DOF updates/sec (RHS evals/s) at N={N}, 3D hex Euler"
     else:
         workload = (f"{args.formulation}2d_N{N}_{Kx}x{Ky_total}_quads_periodic_vortex"
@@ -488,8 +575,11 @@ def run(args):
                    "parallelism": f"element-{'slabs' if hexw else 'strips'} x{world}", "prewarm_evals": PREWARM_EVALS,
                    "backend": args.backend if world > 1 else None, "transport": transport if world > 1 else None, "transport_note": transport_note,
                    "rccl_ranks": rccl_ranks, "visible_gpus": ndev, "oversubscribed": oversub,
-                   "weak_scaling_base_ms": weak_base_ms},
+                   "weak_scaling_base_ms": weak_base_ms,
+                   "hex_geometry_mode": (None if not hexw else ("curved per-node arrays (1)" if args.hex_curve else
+                                         ("per-node 10-bit differences (2)" if args.hex_geometry == "per-node" else "element record (0)")))},
         "rhs_evals_per_s": evals_per_s, "elements_per_s": K_total * evals_per_s,
+        "ms_per_step_rough_state": rough_ms,
         "ms_per_step_median": per[len(per) // 2], "ms_per_step_min": per[0], "ms_per_step_reps": [r / args.steps * 1e3 for r in reps],
         "roofline": roofline,
     }
@@ -502,9 +592,7 @@ def run(args):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if world > 1 and args.require_rccl and (transport != "rccl" or rccl_ranks != world):
-        return 4
-    return 0
+    return exit_code(world, args.require_rccl, transport, rccl_ranks)
 
 
 def main():

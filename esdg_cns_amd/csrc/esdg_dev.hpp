@@ -63,8 +63,6 @@ int launch_project_tensor2(int N1, const TensorTables& TT, const MeshDev& M, con
 // v3 last-phase kernel (esdg_kernels_tensor3.hip); -1 where it does not apply
 int launch_rhs_tensor3(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
                        const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s);
-int launch_sigma_tensor3(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
-                         double* B, double* SG, hipStream_t s);
 struct LsrkFuse;
 int launch_rhs_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
                       const double* A_U, const double* SG, const double* B, double* rhs, const LsrkFuse& lf,
@@ -86,7 +84,8 @@ struct MeshDev {
   // The same per-node normals for the v2 tensor kernels, as single-precision DIFFERENCES to the face means of the geometry
   // record: fnd[K][Nfq][2] = (nxJ, nyJ) - mean, fsd[K][Nfq] = sJ - mean (read by the wall instantiations only).  On an affine
   // face a node's value differs from the mean by some thousand ulps at most, so mean + (double)(float)(v - mean) == v bit for
-  // bit (checked at esdg_create) -- a third of the bytes of fnrm.  Where only a quantity that is itself a small jump is
+  // bit for every component that carries the face (checked at esdg_create; a component below sJ / 4 may lose 2^-24 of its
+  // difference, <= 6e-18 sJ) -- a third of the bytes of fnrm.  Where only a quantity that is itself a small jump is
   // scaled by the normal (LF wavespeed and penalty: sJ, lambda) the kernels use the mean.
   const float* fnd;
   const float* fsd;

@@ -38,6 +38,21 @@ constexpr int NXCD = 8;
 #define ESDG_KH_COALESCE 1
 #endif
 
+// J2 experiment (A/B hook, off): in kh_rhs one wave is one element and at N1 = 4 a lane's direction-0
+// partners sit in its own quad (lane = i0 + 4 i1 + 16 i2), so the full round of direction 0 can fetch the partner's record
+// and return the partner's share through DPP quad_perm moves instead of LDS (7 ds_read_b64 + 5 ds_add_f64 -> 24 + 1
+// v_mov_b32_dpp).  Measured in round 4 (profiles/experiments/README.md).
+#ifndef ESDG_KH_DPP
+#define ESDG_KH_DPP 0
+#endif
+template <int CTRL> __device__ __forceinline__ double dpp_quad(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+constexpr int DPP_QUAD_NEXT = 0x39;   // quad_perm [1,2,3,0]: lane i reads lane (i + 1) % 4 of its quad
+constexpr int DPP_QUAD_PREV = 0x93;   // quad_perm [3,0,1,2]: lane i reads lane (i - 1) % 4 of its quad
+
 template <int N1> struct HCfg {
   static constexpr int Nq = N1 * N1 * N1, Nfq = 6 * N1 * N1, NIT = (Nfq + HW - 1) / HW;
 };
@@ -400,9 +415,34 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
           const int node = vin ? lane + (j - id) * stride : lane;
           double qn[7], F[HEX_NFLD];
           const int ns = slot_of(node);
+          const bool dpp = ESDG_KH_DPP && N1 == 4 && !CURVED && d == 0 && m == 1;   // (uniform)
+          if (dpp) {
 #pragma unroll
-          for (int c = 0; c < 7; ++c) qn[c] = sP[c * HW + ns];
+            for (int c = 0; c < 7; ++c) qn[c] = dpp_quad<DPP_QUAD_NEXT>(qv[c]);
+          } else {
+#pragma unroll
+            for (int c = 0; c < 7; ++c) qn[c] = sP[c * HW + ns];
+          }
           double W = sTab[L.S + (d * N1 + id) * N1 + j] * wt;
+          if (dpp) {
+            if (DELTA) {
+              int a0, a1, a2, b0, b1, b2;
+              const unsigned kown = opd == 0 ? kv[0] : (opd == 1 ? kv[1] : kv[2]);
+              unpack3(kown, a0, a1, a2);
+              unpack3((unsigned)__builtin_amdgcn_mov_dpp((int)kown, DPP_QUAD_NEXT, 0xf, 0xf, true), b0, b1, b2);
+              ec_flux_dir(qv, qn, __builtin_fma(hsG, (double)(a0 + b0), gx), __builtin_fma(hsG, (double)(a1 + b1), gy),
+                          __builtin_fma(hsG, (double)(a2 + b2), gz), F);
+            } else {
+              ec_flux_dir(qv, qn, gx, gy, gz, F);
+            }
+#pragma unroll
+            for (int c = 0; c < HEX_NFLD; ++c) {   // own share, and the share of the pair whose partner this lane is
+              const double wf = W * F[c];
+              acc[c] += wf;
+              acc[c] -= dpp_quad<DPP_QUAD_PREV>(wf);
+            }
+            continue;
+          }
           if (CURVED) {   // metric of the pair = average of the two nodes (the .5 goes into the weight)
             W *= .5;
             ec_flux_dir(qv, qn, sM[opd * HW + myslot] + sM[opd * HW + ns], sM[(3 + opd) * HW + myslot] + sM[(3 + opd) * HW + ns],
@@ -482,6 +522,7 @@ __global__ __launch_bounds__(HW * HNWV) void kh_rhs(HexTables HT, MeshDev M, Phy
   // face total through a cross-lane swap: 5 + 3 flux evaluations per lane instead of 5 + 5 with half the wave idle.
   constexpr int REM = Nfq - HW * (NIT - 1);
   constexpr bool SPLIT = NIT >= 2 && REM <= HW / 2 && N1 >= 2;
+  static_assert(!SPLIT || N1 % 2 == 0, "the split face round gives each of a node's two lanes N1 / 2 volume partners");
 #pragma unroll 1
   for (int it = 0; it < NIT; ++it) {
     const bool split = SPLIT && it == NIT - 1;                    // uniform

@@ -68,8 +68,12 @@ __device__ __forceinline__ int64_t xcd_group3(int64_t b, int64_t n) {
 #ifndef ESDG_T3_LAZY_LOGS
 #define ESDG_T3_LAZY_LOGS 1   // (A/B hook: 0 = the logarithms of every node and trace state, always)
 #endif
-#ifndef ESDG_T3_WPE
-#define ESDG_T3_WPE 3   // waves per SIMD asked of the register allocator (A/B hook)
+// waves per SIMD asked of the register allocator: three up to N1 = 6 (168 VGPRs: the N1 + 2 accumulators of a line take 8 (N1 + 2)
+// of them), two at N1 = 7, one at N1 = 8 (ESDG_T3_WPE overrides, A/B hook)
+#ifdef ESDG_T3_WPE
+template <int N1> struct Wpe3 { static constexpr int W = ESDG_T3_WPE; };
+#else
+template <int N1> struct Wpe3 { static constexpr int W = N1 <= 6 ? 3 : (N1 == 7 ? 2 : 1); };
 #endif
 
 #ifdef ESDG_T3_NUM_VGPR
@@ -78,7 +82,7 @@ __device__ __forceinline__ int64_t xcd_group3(int64_t b, int64_t n) {
 #define T3_VGPR_ATTR
 #endif
 template <int N1, bool MODAL, bool VISC>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ESDG_T3_WPE, ESDG_T3_WPE))) T3_VGPR_ATTR void kt3_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Wpe3<N1>::W))) T3_VGPR_ATTR void kt3_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                           const double* __restrict__ A_U, const double* __restrict__ SG,
                                                           const double* __restrict__ B, double* __restrict__ rhs, LsrkFuse lf) {
   using G = G3<N1>;
@@ -453,318 +457,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ESDG_T3_WPE,
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// phase 1 (CNS, meshes without walls): sigma = K(v) grad v -> normal-stress traces B and the volume part of div sigma
-// (rhs_viscous! cavity_optimized.jl:749-815 in collocated form, dg_grad! :548-569, viscous_matrices! :613-645; the formulas are
-// those of kt2_sigma in esdg_kernels_tensor2.hip).  kt2_sigma is persistent with two waves per group, ~110 LDS instructions per
-// 333 VALU instructions, a fifth of its LDS cycles in bank conflicts and two waves per SIMD: its compute-only time (every
-// address folded into L2) is 2.2 x its VALU floor.  Here, as in kt3_rhs, a workgroup is one wave with E = 64 / (2 N1) elements:
-//   node rounds   Vq, entropy variables (v2,v3,v4) -> LDS
-//   line lanes    lane (element, direction d, line o) reads the N1 values of its line, forms the line derivative at all N1 nodes
-//                 (N1^2 FMAs per component from registers), the values at the two face nodes at the line's ends, their half jumps
-//                 to the neighbours' (from the A_U records) times the node's own normal, and the lift of those to its N1 nodes:
-//                 the line's share of J grad v at every node -> LDS (direction 0 writes, direction 1 adds)
-//   node rounds   theta = (sum of the two shares) / J, sigma = K(v) theta -> LDS
-//   line lanes    contravariant component of sigma along the line, its line derivative = the line's share of the volume
-//                 divergence -> LDS (two steps as above); sigma at the two face nodes, normal stress -> B
-//   node rounds   volume divergence -> SG
-// ---------------------------------------------------------------------------------------------------------------------
-template <int N1>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void kt3_sigma(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
-                                                                                         const double* __restrict__ A_U, double* __restrict__ B,
-                                                                                         double* __restrict__ SG) {
-  using G = G3<N1>;
-  constexpr int TW = G::TW, Nq = G::Nq, Nfq = G::Nfq, NLN = G::NLN, E = G::E, NV = G::NV, NF = G::NF, LL = G::LL, NR = G::NR;
-  constexpr TensorLayout TL(N1);
-  constexpr int NGEO = E * GEO_STRIDE, GPT = (NGEO + TW - 1) / TW;
-  constexpr int T0 = TL.PF, NT = TL.IP - TL.PF, TPT = (NT + TW - 1) / TW;   // staged part of the 1D tables: PF PTF PD WFAC EE DG IQ
-  constexpr double GM1 = t2::GM1;
-  static_assert(NV % 2 == 0, "pair planes stay 16-byte aligned behind a plane of doubles");
-  constexpr int NBR = (NF * B_NC + TW - 1) / TW;                            // rounds of the staged B store
-  constexpr int NAR = 9 * NV > NF * B_NC ? 9 * NV : NF * B_NC;
-  __shared__ __align__(16) double arena[NAR];
-  __shared__ __align__(16) double sGeo[GPT * TW];
-  __shared__ __align__(16) double sTab[TPT * TW];
-  d2* sA = reinterpret_cast<d2*>(arena);                 // Vq buffers [2][NV] each
-  d2* sB = reinterpret_cast<d2*>(arena + 4 * NV);
-  d2* sVp = reinterpret_cast<d2*>(arena);                // [NV] (v2, v3)
-  double* sV4 = arena + 2 * NV;                          // [NV] v4
-  d2* sT = reinterpret_cast<d2*>(arena + 3 * NV);        // [3][NV] (tx0,tx1) (tx2,ty0) (ty1,ty2): J grad v
-  d2* sSg = reinterpret_cast<d2*>(arena);                // [3][NV] (sx0,sx1) (sx2,sy0) (sy1,sy2)
-  d2* sDp = reinterpret_cast<d2*>(arena + 6 * NV);       // [NV] (dv0, dv1)
-  double* sD2 = arena + 8 * NV;                          // [NV] dv2
-  double* sBs = arena;                                   // [NF][3] normal stress, staged for a coalesced store
-
-  const unsigned tid = threadIdx.x;
-  const int64_t e0r = M.e_begin + (int64_t)blockIdx.x * E;
-  const int nE = (int)min((int64_t)E, M.e_begin + M.e_count - e0r);
-  const int64_t e0 = ESDG_EW(e0r);
-  const int64_t KN = M.K * Nq;
-
-  const unsigned ln = tid < (unsigned)LL ? tid : tid - LL;
-  const unsigned el = ln / NLN, lr = ln - el * NLN, d = lr / N1, o = lr - d * N1;
-  const unsigned elc = el < (unsigned)nE ? el : 0u;
-  const unsigned n0 = el * Nq + (d ? o : N1 * o), st = d ? N1 : 1;
-  const int fA = TT.ints[TL.FN + (2 * d) * N1 + o], fB = TT.ints[TL.FN + (2 * d + 1) * N1 + o];
-  const int64_t nfA = (e0 + elc) * Nfq + fA, nfB = (e0 + elc) * Nfq + fB;
-  const unsigned mpA = ESDG_EWN((unsigned)M.mapP[nfA], Nfq), mpB = ESDG_EWN((unsigned)M.mapP[nfB], Nfq);
-
-  // ---- global loads ---------------------------------------------------------------------------------------------------------------
-  double x[NR][4], geo[GPT], tab[TPT];
-#pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    const unsigned n = tid + r * TW, s = n < (unsigned)NV ? n : n - NV, sl = s < (unsigned)(nE * Nq) ? s : 0u;
-#pragma unroll
-    for (int f = 0; f < 4; ++f) x[r][f] = Q[f * KN + e0 * Nq + sl];
-  }
-#pragma unroll
-  for (int i = 0; i < GPT; ++i) { const unsigned n = tid + i * TW; geo[i] = M.geo[e0 * GEO_STRIDE + (n < (unsigned)(nE * GEO_STRIDE) ? n : 0u)]; }
-#pragma unroll
-  for (int i = 0; i < TPT; ++i) { const unsigned n = tid + i * TW; tab[i] = TT.dbl[T0 + (n < (unsigned)NT ? n : 0u)]; }
-  d2 uA0, uA1, uB0, uB1;   // neighbours' trace records (rho,u) (v,beta) of the line's two face nodes
-  {
-    const d2* pa = reinterpret_cast<const d2*>(A_U + (size_t)mpA * FAU_NC);
-    const d2* pb = reinterpret_cast<const d2*>(A_U + (size_t)mpB * FAU_NC);
-    uA0 = pa[0]; uA1 = pa[1]; uB0 = pb[0]; uB1 = pb[1];
-  }
-  const float2 ndA = reinterpret_cast<const float2*>(M.fnd)[nfA], ndB = reinterpret_cast<const float2*>(M.fnd)[nfB];
-
-  // ---- staging ------------------------------------------------------------------------------------------------------------------------
-#pragma unroll
-  for (int i = 0; i < GPT; ++i) sGeo[tid + i * TW] = geo[i];
-#pragma unroll
-  for (int i = 0; i < TPT; ++i) sTab[tid + i * TW] = tab[i];
-  unsigned slot[NR], nq[NR];
-#pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    const unsigned n = tid + r * TW;
-    slot[r] = n < (unsigned)NV ? n : n - NV;
-    nq[r] = slot[r] % Nq;
-    sA[slot[r]] = make_double2(x[r][0], x[r][1]);
-    sA[NV + slot[r]] = make_double2(x[r][2], x[r][3]);
-  }
-  __syncthreads();
-  // ---- node rounds: Uq = Vq Qn (as in kt3_rhs), entropy variables 2..4 ------------------------------------------------------------------
-#pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    const unsigned ev = slot[r] / Nq, a = nq[r] % N1, b = nq[r] / N1;
-    const double* c = sTab + (TL.IQ - T0) + a * N1;
-    const d2* rw = sA + ev * Nq + N1 * b;
-    d2 p = rw[0], t = rw[NV];
-    const double c0 = c[0];
-    double w0 = c0 * p.x, w1 = c0 * p.y, w2 = c0 * t.x, w3 = c0 * t.y;
-#pragma unroll
-    for (int i = 1; i < N1; ++i) {
-      p = rw[i]; t = rw[NV + i];
-      const double ci = c[i];
-      w0 = __builtin_fma(ci, p.x, w0); w1 = __builtin_fma(ci, p.y, w1);
-      w2 = __builtin_fma(ci, t.x, w2); w3 = __builtin_fma(ci, t.y, w3);
-    }
-    sB[slot[r]] = make_double2(w0, w1);
-    sB[NV + slot[r]] = make_double2(w2, w3);
-  }
-  __syncthreads();
-  double V[NR][3];
-#pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    const unsigned ev = slot[r] / Nq, a = nq[r] % N1, b = nq[r] / N1;
-    const double* c = sTab + (TL.IQ - T0) + a * N1;
-    const d2* rw = sB + ev * Nq + b;
-    d2 p = rw[0], t = rw[NV];
-    const double c0 = c[0];
-    double U0 = c0 * p.x, U1 = c0 * p.y, U2 = c0 * t.x, U3 = c0 * t.y;
-#pragma unroll
-    for (int j = 1; j < N1; ++j) {
-      p = rw[N1 * j]; t = rw[NV + N1 * j];
-      const double cj = c[j];
-      U0 = __builtin_fma(cj, p.x, U0); U1 = __builtin_fma(cj, p.y, U1);
-      U2 = __builtin_fma(cj, t.x, U2); U3 = __builtin_fma(cj, t.y, U3);
-    }
-    const double m2 = U1 * U1 + U2 * U2;
-    const double rre = __builtin_fma(U0, U3, -.5 * m2);          // rho * rhoe
-    const double tt = U0 * rcp_refined(rre);                     // 1 / rhoe
-    V[r][0] = U1 * tt; V[r][1] = U2 * tt; V[r][2] = -(U0 * tt);  // (rho u, rho v, -rho) / rhoe  (cavity :464-467)
-  }
-  __syncthreads();   // every lane is past its reads of the Vq buffers
-#pragma unroll
-  for (int r = 0; r < NR; ++r) { sVp[slot[r]] = make_double2(V[r][0], V[r][1]); sV4[slot[r]] = V[r][2]; }
-  __syncthreads();
-
-  // ---- line lanes: the line's share of J grad v at its nodes ----------------------------------------------------------------------------
-  const double* g = sGeo + el * GEO_STRIDE;
-  const int opd = d ? TT.op1 : TT.op0;
-  const double gxd = g[opd], gyd = g[2 + opd];
-  const double* DGd = sTab + (TL.DG - T0) + d * N1 * N1;
-  const double* EEA = sTab + (TL.EE - T0) + (2 * d) * N1;
-  const double* EEB = sTab + (TL.EE - T0) + (2 * d + 1) * N1;
-  double nrA[2], nrB[2];   // the two face nodes' own normals (face mean of the record + this node's difference, exactly)
-  {
-    const double* gmA = g + 5 + 3 * (fA / N1);
-    const double* gmB = g + 5 + 3 * (fB / N1);
-    nrA[0] = gmA[0] + (double)ndA.x; nrA[1] = gmA[1] + (double)ndA.y;
-    nrB[0] = gmB[0] + (double)ndB.x; nrB[1] = gmB[1] + (double)ndB.y;
-  }
-  {
-    double Vl[N1][3];
-#pragma unroll
-    for (int j = 0; j < N1; ++j) { const d2 p = sVp[n0 + j * st]; Vl[j][0] = p.x; Vl[j][1] = p.y; Vl[j][2] = sV4[n0 + j * st]; }
-    // half jumps to the neighbours' values, times the node's normal (dg_grad! :560-566): neighbour (v2,v3,v4) = (b u, b v, -b),
-    // b = 2 (gamma-1) beta, from its trace record
-    double jxA[3], jyA[3], jxB[3], jyB[3];
-    {
-      double vfA[3], vfB[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { vfA[c] = EEA[0] * Vl[0][c]; vfB[c] = EEB[0] * Vl[0][c]; }
-#pragma unroll
-      for (int j = 1; j < N1; ++j)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { vfA[c] = __builtin_fma(EEA[j], Vl[j][c], vfA[c]); vfB[c] = __builtin_fma(EEB[j], Vl[j][c], vfB[c]); }
-      const double bA = 2 * GM1 * uA1.y, bB = 2 * GM1 * uB1.y;
-      const double vPA[3] = {bA * uA0.y, bA * uA1.x, -bA}, vPB[3] = {bB * uB0.y, bB * uB1.x, -bB};
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const double hA = .5 * (vPA[c] - vfA[c]), hB = .5 * (vPB[c] - vfB[c]);
-        jxA[c] = nrA[0] * hA; jyA[c] = nrA[1] * hA; jxB[c] = nrB[0] * hB; jyB[c] = nrB[1] * hB;
-      }
-    }
-    const double ptA = sTab[(TL.PTF - T0) + (2 * d) * N1 + o], ptB = sTab[(TL.PTF - T0) + (2 * d + 1) * N1 + o];
-    const double wfA = sTab[(TL.WFAC - T0) + fA], wfB = sTab[(TL.WFAC - T0) + fB];
-    const double* PFA = sTab + (TL.PF - T0) + (2 * d) * N1;
-    const double* PFB = sTab + (TL.PF - T0) + (2 * d + 1) * N1;
-    double T[N1][6];
-#pragma unroll
-    for (int i = 0; i < N1; ++i) {
-      double dV[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) dV[c] = DGd[i * N1] * Vl[0][c];
-#pragma unroll
-      for (int j = 1; j < N1; ++j)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) dV[c] = __builtin_fma(DGd[i * N1 + j], Vl[j][c], dV[c]);
-      const double lwA = (PFA[i] * ptA) * wfA, lwB = (PFB[i] * ptB) * wfB;   // collocated lift weights (PF PTF WFAC)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        T[i][c] = __builtin_fma(lwB, jxB[c], __builtin_fma(lwA, jxA[c], gxd * dV[c]));
-        T[i][3 + c] = __builtin_fma(lwB, jyB[c], __builtin_fma(lwA, jyA[c], gyd * dV[c]));
-      }
-    }
-    __syncthreads();   // (the V planes are dead: the node lanes keep their values)
-    if (d == 0) {
-#pragma unroll
-      for (int i = 0; i < N1; ++i) {
-        const unsigned n = n0 + i * st;
-        sT[n] = make_double2(T[i][0], T[i][1]); sT[NV + n] = make_double2(T[i][2], T[i][3]); sT[2 * NV + n] = make_double2(T[i][4], T[i][5]);
-      }
-    }
-    __syncthreads();
-    if (d == 1) {
-#pragma unroll
-      for (int i = 0; i < N1; ++i) {
-        const unsigned n = n0 + i * st;
-        const d2 a0 = sT[n], a1 = sT[NV + n], a2 = sT[2 * NV + n];
-        sT[n] = make_double2(a0.x + T[i][0], a0.y + T[i][1]); sT[NV + n] = make_double2(a1.x + T[i][2], a1.y + T[i][3]);
-        sT[2 * NV + n] = make_double2(a2.x + T[i][4], a2.y + T[i][5]);
-      }
-    }
-    __syncthreads();
-  }
-  // ---- node rounds: theta = (.)/J, sigma = K(v) theta ---------------------------------------------------------------------------------------
-  {
-    double sg[NR][6];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const unsigned s = slot[r], ev = s / Nq;
-      const double iJ = rcp_refined(sGeo[ev * GEO_STRIDE + 4]);
-      const d2 a0 = sT[s], a1 = sT[NV + s], a2 = sT[2 * NV + s];
-      const double tx[3] = {a0.x * iJ, a0.y * iJ, a1.x * iJ}, ty[3] = {a1.y * iJ, a2.x * iJ, a2.y * iJ};
-      t2::viscous_stress(V[r], tx, ty, -ph.lambda, ph.mu, ph.kappa, sg[r], sg[r] + 3);
-    }
-    __syncthreads();   // every lane is past its reads of the gradient planes, part of which takes sigma
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const unsigned s = slot[r];
-      sSg[s] = make_double2(sg[r][0], sg[r][1]); sSg[NV + s] = make_double2(sg[r][2], sg[r][3]); sSg[2 * NV + s] = make_double2(sg[r][4], sg[r][5]);
-    }
-    __syncthreads();
-  }
-  // ---- line lanes: volume divergence along the line, normal stress at the two face nodes ------------------------------------------------------
-  double snA[3], snB[3];
-  {
-    double Sl[N1][3];                 // contravariant component of sigma along the line's direction
-    double fA6[6], fB6[6];            // sigma at the two face nodes
-#pragma unroll
-    for (int j = 0; j < N1; ++j) {
-      const unsigned n = n0 + j * st;
-      const d2 p0 = sSg[n], p1 = sSg[NV + n], p2 = sSg[2 * NV + n];
-      const double sj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
-#pragma unroll
-      for (int c = 0; c < 3; ++c) Sl[j][c] = __builtin_fma(gyd, sj[3 + c], gxd * sj[c]);
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        fA6[c] = j == 0 ? EEA[0] * sj[c] : __builtin_fma(EEA[j], sj[c], fA6[c]);
-        fB6[c] = j == 0 ? EEB[0] * sj[c] : __builtin_fma(EEB[j], sj[c], fB6[c]);
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {   // (Ef*sigma_x)*nxJ + (Ef*sigma_y)*nyJ with the node's own normal
-      snA[c] = __builtin_fma(fA6[3 + c], nrA[1], fA6[c] * nrA[0]);
-      snB[c] = __builtin_fma(fB6[3 + c], nrB[1], fB6[c] * nrB[0]);
-    }
-    double dv[N1][3];
-#pragma unroll
-    for (int i = 0; i < N1; ++i) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) dv[i][c] = DGd[i * N1] * Sl[0][c];
-#pragma unroll
-      for (int j = 1; j < N1; ++j)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) dv[i][c] = __builtin_fma(DGd[i * N1 + j], Sl[j][c], dv[i][c]);
-    }
-    if (d == 0) {   // (the divergence planes lie behind sigma's)
-#pragma unroll
-      for (int i = 0; i < N1; ++i) { const unsigned n = n0 + i * st; sDp[n] = make_double2(dv[i][0], dv[i][1]); sD2[n] = dv[i][2]; }
-    }
-    __syncthreads();
-    if (d == 1) {
-#pragma unroll
-      for (int i = 0; i < N1; ++i) {
-        const unsigned n = n0 + i * st;
-        const d2 a = sDp[n];
-        sDp[n] = make_double2(a.x + dv[i][0], a.y + dv[i][1]); sD2[n] += dv[i][2];
-      }
-    }
-    if (!M.bf) {   // (uniform) sigma's planes are dead (barrier above): the wave's normal-stress records, in storage order
-      const unsigned rA = (el * Nfq + fA) * B_NC, rB = (el * Nfq + fB) * B_NC;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { sBs[rA + c] = snA[c]; sBs[rB + c] = snB[c]; }
-    }
-    __syncthreads();
-  }
-  // ---- stores -----------------------------------------------------------------------------------------------------------------------------
-#pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    const unsigned n = tid + r * TW;
-    if (n < (unsigned)(nE * Nq)) {
-      const d2 a = sDp[n];
-      double* o3 = SG + e0 * Nq + n;
-      o3[0] = a.x; o3[KN] = a.y; o3[2 * KN] = sD2[n];
-    }
-  }
-  if (!M.bf) {
-    double* bb = B + e0 * Nfq * B_NC;
-#pragma unroll
-    for (int r = 0; r < NBR; ++r) {
-      const unsigned n = tid + r * TW;
-      if (n < (unsigned)(nE * Nfq * B_NC)) bb[n] = sBs[n];
-    }
-  } else if (tid < (unsigned)LL && el < (unsigned)nE) {
-    double* ba = B + trace_slot<N1>(M, e0 + el, (unsigned)fA) * B_NC;
-    double* bbp = B + trace_slot<N1>(M, e0 + el, (unsigned)fB) * B_NC;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { ba[c] = snA[c]; bbp[c] = snB[c]; }
-  }
-}
-
 }  // namespace t3
 
 #define ESDG_T3_DISPATCH(N1v, BODY)                  \
@@ -797,19 +489,6 @@ int launch_rhs_tensor3(int N1v, const TensorTables& TT, const MeshDev& M, const 
     if (!modal) (launch_rhs3<N1, false, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
     else if (visc) (launch_rhs3<N1, true, true>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
     else (launch_rhs3<N1, true, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
-  });
-  return (int)hipGetLastError();
-}
-
-// phase 1 on meshes without walls; -1 where the v3 kernel does not apply (caller falls back to kt2_sigma)
-int launch_sigma_tensor3(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
-                         double* B, double* SG, hipStream_t s) {
-  if (M.e_count <= 0) return 0;
-  if (M.bc) return -1;
-  ESDG_T3_DISPATCH(N1v, {
-    using G = t3::G3<N1>;
-    const int nb = (int)((M.e_count + G::E - 1) / G::E);
-    hipLaunchKernelGGL((t3::kt3_sigma<N1>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, B, SG);
   });
   return (int)hipGetLastError();
 }

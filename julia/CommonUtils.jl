@@ -46,21 +46,25 @@ function geometric_factors(x, y, Dr, Ds)
     return ys, -yr, -xs, xr, J
 end
 
-"3D: (rxJ, sxJ, txJ, ryJ, syJ, tyJ, rzJ, szJ, tzJ, J), cross products of the columns of the mapping's Jacobian"
+"""
+3D: (rxJ, sxJ, txJ, ryJ, syJ, tyJ, rzJ, szJ, tzJ, J) in the curl-conservative form of Kopriva (2006), which is what the
+reference's `geometric_factors` computes and what keeps the discrete metric identities -- free-stream preservation and entropy
+conservation -- on the curved mapping of dg3D_euler_hex.jl (plain cross products of the Jacobian's columns agree with it on
+affine meshes only).  Same operations as `setup_dg.geometric_factors_3d` of the Python host, whose free-stream test on the
+curved mapping stands in for this un-run file (tests/test_hex_cpu.py).
+"""
 function geometric_factors(x, y, z, Dr, Ds, Dt)
+    function curl(a, b)
+        Fr, Fs, Ft = (Dr * a) .* b, (Ds * a) .* b, (Dt * a) .* b
+        return Dt * Fs - Ds * Ft, Dr * Ft - Dt * Fr, Ds * Fr - Dr * Fs
+    end
+    rxJ, sxJ, txJ = curl(y, z)
+    ryJ, syJ, tyJ = (-).(curl(x, z))
+    rzJ, szJ, tzJ = (-).(curl(y, x))
     xr, xs, xt = Dr * x, Ds * x, Dt * x
     yr, ys, yt = Dr * y, Ds * y, Dt * y
     zr, zs, zt = Dr * z, Ds * z, Dt * z
     J = @. xr * (ys * zt - zs * yt) - yr * (xs * zt - zs * xt) + zr * (xs * yt - ys * xt)
-    rxJ = @. ys * zt - zs * yt
-    ryJ = @. -(xs * zt - zs * xt)
-    rzJ = @. xs * yt - ys * xt
-    sxJ = @. -(yr * zt - zr * yt)
-    syJ = @. xr * zt - zr * xt
-    szJ = @. -(xr * yt - yr * xt)
-    txJ = @. yr * zs - zr * ys
-    tyJ = @. -(xr * zs - zr * xs)
-    tzJ = @. xr * ys - yr * xs
     return rxJ, sxJ, txJ, ryJ, syJ, tyJ, rzJ, szJ, tzJ, J
 end
 

@@ -413,7 +413,7 @@ end
 # for runs where the time loop is not worth porting; the device-resident loop is section 2 of INTEGRATION.md).
 module Scripts
 using ..ESDGHip
-export bind!, rhs, rhsRK!
+export bind!, rhs, rhsRK!, rhs_inviscid!, rhs_viscous!
 const CTX = Dict{Symbol,Any}()
 const ENGINES = IdDict{Any,Any}()
 "globals of the driver the reference functions read: `bind!(rd = rd, Ef = Ef)` (Euler quad / hex), `bind!(rd = rd, mu = mu, lambda = lambda, Pr = Pr)` (CNS)"
@@ -442,6 +442,59 @@ function rhsRK!(Q, rd, md, Re, BCTYPE, ops, flux_fun, inviscid_dissp, viscous_di
     ESDGHip.upload!(e, Q)
     rhstest, rhstest_visc = ESDGHip.rhsRK!(e; compute_rhstest = true)
     rhsQ, rhstest, rhstest_visc
+end
+"the cached CNS engine of a mesh (created by `rhsRK!` / `rhs_inviscid!`, or here from `bind!(ops = ops, ...)`)"
+function cns_engine(md, rd, ops, Re, BCTYPE, inviscid_dissp, viscous_dissp)
+    engine_for((md, ops, BCTYPE), () -> ESDGHip.CnsEngine(rd, md, ops; Re = Re, mu = CTX[:mu], lambda = CTX[:lambda], Pr = CTX[:Pr],
+        BCTYPE = BCTYPE, inviscid_dissp = inviscid_dissp, viscous_dissp = viscous_dissp,
+        lid = get(CTX, :lid, nothing), vlid = get(CTX, :vlid, nothing)))
+end
+"one part of the right-hand side on host arrays: parts = 1 `rhs_inviscid!`, 2 `rhs_viscous!` (esdg_set_parts)"
+function part_rhs(e, Q, parts)
+    ESDGHip.check(ccall((:esdg_set_parts, ESDGHip.LIB), Cint, (Ptr{Cvoid}, Cint), e.ctx, parts))
+    out = try
+        first(ESDGHip.rhs(e, Q))
+    finally
+        ccall((:esdg_set_parts, ESDGHip.LIB), Cint, (Ptr{Cvoid}, Cint), e.ctx, 3)
+    end
+    out
+end
+"""
+`rhsQ, rhstest = rhs_inviscid!(Q, md, ops, flux_fun, compute_rhstest, inviscid_dissp, VU, Qh, QF, QM, QP, Uf, UP, rhsQ, tmp, tmp2, lam, LFc)`
+-- dg2D_CNS_cavity_optimized.jl:447; the twelve work arrays are accepted and ignored.  The script's function reads `rd`, `Re`
+and `BCTYPE` from globals: `bind!(rd = rd, Re = Re, BCTYPE = BCTYPE, mu = mu, lambda = lambda, Pr = Pr)` once.
+`rhstest` = sum(wJq .* v .* (Vq*rhsQ)) of this part (`:519-526`).
+"""
+function rhs_inviscid!(Q, md, ops, flux_fun, compute_rhstest, inviscid_dissp, work...)
+    e = cns_engine(md, CTX[:rd], ops, CTX[:Re], get(CTX, :BCTYPE, 1), inviscid_dissp, get(CTX, :viscous_dissp, true))
+    rhsQ = part_rhs(e, Q, 1)
+    rhstest = 0.0
+    if compute_rhstest
+        ESDGHip.upload!(e, Q)
+        ESDGHip.check(ccall((:esdg_set_parts, ESDGHip.LIB), Cint, (Ptr{Cvoid}, Cint), e.ctx, 1))
+        rhstest = try ESDGHip.rhs!(e; compute_rhstest = true) finally
+            ccall((:esdg_set_parts, ESDGHip.LIB), Cint, (Ptr{Cvoid}, Cint), e.ctx, 3) end
+    end
+    rhsQ, rhstest
+end
+"""
+`visc_rhsQ, visc_test = rhs_viscous!(Q, md, rd, Re, BCTYPE, viscous_dissp, rhs, VU, VUx, VUy, sigma_x, sigma_y, penalization, Kxx, Kyy, Kxy)`
+-- dg2D_CNS_cavity_optimized.jl:749; the ten work arrays are accepted and ignored.  The operator tuple is the one `rhsRK!` /
+`rhs_inviscid!` was called with for this mesh, or `bind!(ops = ops)`.  `visc_test` is the second return of the script's
+function, the boundary / penalty part of the viscous entropy balance (`:962-969` add it to `rhstest_visc`).
+"""
+function rhs_viscous!(Q, md, rd, Re, BCTYPE, viscous_dissp, work...)
+    ops = nothing
+    for k in keys(ENGINES)
+        (k isa Tuple && length(k) == 3 && k[1] === md && k[3] == BCTYPE) && (ops = k[2])
+    end
+    ops === nothing && (ops = CTX[:ops])
+    e = cns_engine(md, rd, ops, Re, BCTYPE, get(CTX, :inviscid_dissp, true), viscous_dissp)
+    rhsQ = part_rhs(e, Q, 2)
+    ESDGHip.upload!(e, Q)
+    vt = zeros(1)
+    ESDGHip.check(ccall((:esdg_viscous_entropy_test, ESDGHip.LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), e.ctx, e.Qd, vt, C_NULL))
+    rhsQ, vt[1]
 end
 end # module Scripts
 

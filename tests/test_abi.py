@@ -159,3 +159,53 @@ def test_julia_commonutils_stand_in_exports_what_the_drivers_call():
     assert len(fracs) == len(want) and all(abs(x - y) <= 1e-16 * abs(y) for x, y in zip(fracs, want))
     assert jl.count("(") == jl.count(")") and jl.count("[") == jl.count("]")
     assert len(re.findall(r"^function ", jl, flags=re.M)) + len(re.findall(r"^module ", jl, flags=re.M)) == len(re.findall(r"^end", jl, flags=re.M))
+
+
+def test_julia_scripts_module_has_the_cns_functions_with_the_scripts_signatures():
+    """ESDGHip.Scripts (un-runnable here) defines `rhs_inviscid!` and `rhs_viscous!` beside `rhs` / `rhsRK!` with the positional
+    layout of /root/reference/examples/CompressibleNS/dg2D_CNS_cavity_optimized.jl:447, 749 (leading arguments by name, the work
+    arrays as a trailing splat), exports them, and switches the parts back to 3 after a partial evaluation."""
+    jl = open(os.path.join(ROOT, "julia", "ESDGHip.jl")).read()
+    scripts = re.search(r"^module Scripts\n(.*?)^end # module Scripts", jl, flags=re.S | re.M).group(1)
+    exported = set(re.findall(r"[A-Za-z_!0-9]+", re.search(r"^export (.*)$", scripts, flags=re.M).group(1)))
+    assert {"rhs", "rhsRK!", "rhs_inviscid!", "rhs_viscous!", "bind!"} <= exported
+    sig = {"rhs_inviscid!": ["Q", "md", "ops", "flux_fun", "compute_rhstest", "inviscid_dissp", "work..."],
+           "rhs_viscous!": ["Q", "md", "rd", "Re", "BCTYPE", "viscous_dissp", "work..."],
+           "rhsRK!": ["Q", "rd", "md", "Re", "BCTYPE", "ops", "flux_fun", "inviscid_dissp", "viscous_dissp", "work..."]}
+    for name, args in sig.items():
+        m = re.search(r"^function " + re.escape(name) + r"\((.*?)\)$", scripts, flags=re.M)
+        assert m, name
+        assert [a.strip() for a in m.group(1).split(",")] == args, (name, m.group(1))
+    # a partial evaluation (esdg_set_parts 1 / 2) is always followed by the reset to 3
+    assert scripts.count("e.ctx, 3)") >= 2 and "esdg_viscous_entropy_test" in scripts
+    assert scripts.count("(") == scripts.count(")")
+
+
+def test_julia_commonutils_metric_terms_are_the_curl_form_and_that_form_preserves_the_free_stream():
+    """the 3D `geometric_factors` of julia/CommonUtils.jl must be Kopriva's curl-conservative form like the reference
+    (src/geometric_factors.jl:34-67), not cross products of the Jacobian's columns.  The file cannot be run; its operations are
+    those of setup_dg.geometric_factors_3d (checked textually), and THAT function satisfies the discrete metric identities
+    Dr*rxJ + Ds*sxJ + Dt*txJ = 0 (and the y, z rows) on the curved mapping of dg3D_euler_hex.jl:67-73 and on a general degree-N mapping,
+    where the cross-product form does not."""
+    import numpy as np
+    from esdg_cns_amd import setup_dg as sd
+    jl = open(os.path.join(ROOT, "julia", "CommonUtils.jl")).read()
+    body = re.search(r"function geometric_factors\(x, y, z, Dr, Ds, Dt\)(.*?)^end", jl, flags=re.S | re.M).group(1)
+    assert "curl(y, z)" in body and "curl(x, z)" in body and "curl(y, x)" in body
+    assert "Dt * Fs - Ds * Ft, Dr * Ft - Dt * Fr, Ds * Fr - Dr * Fs" in body
+    N = 3
+    rd = sd.init_reference_hex(N, sd.gauss_quad(0, 0, N))
+    r, s, t = rd.r, rd.s, rd.t
+    Dr, Ds, Dt = (np.asarray(D.todense()) if hasattr(D, "todense") else np.asarray(D) for D in (rd.Dr, rd.Ds, rd.Dt))
+    dx = (r - 1) * (r + 1) * (s - 1) * (s + 1) * (t - 1) * (t + 1)          # the script's mapping (:67-73), a = 0.12
+    rng = np.random.default_rng(7)
+    bump = [0.05 * rng.standard_normal(r.shape) for _ in range(3)]          # a general degree-N mapping (nodal perturbation)
+    for x, y, z in ((r + .12 * dx, s + .12 * dx, t + .12 * dx), (r + bump[0], s + bump[1], t + bump[2])):
+        g = sd.geometric_factors_3d(x, y, z, Dr, Ds, Dt)
+        for row in range(3):
+            assert np.abs(Dr @ g[3 * row] + Ds @ g[3 * row + 1] + Dt @ g[3 * row + 2]).max() < 1e-12
+    # the cross-product form (what the file held in round 3) violates them on the general mapping
+    x, y, z = r + bump[0], s + bump[1], t + bump[2]
+    yr, ys, yt, zr, zs, zt = Dr @ y, Ds @ y, Dt @ y, Dr @ z, Ds @ z, Dt @ z
+    cross = (ys * zt - zs * yt, -(yr * zt - zr * yt), yr * zs - zr * ys)
+    assert np.abs(Dr @ cross[0] + Ds @ cross[1] + Dt @ cross[2]).max() > 1e-3

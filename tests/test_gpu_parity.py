@@ -10,7 +10,7 @@ double once).  1e-12 is BASELINE.json's tolerance; e_orc is what a faithful Floa
 formulas loses on the same input (its logmean cancels up to four digits at |f| >= 1e-4), i.e. what Julia itself is away
 from the exact result; on the BASELINE vortex states e_orc is 4e-12 ... 6e-11, so 1e-12 alone cannot be met by ANY
 Float64 implementation there, the reference included.  On well-conditioned states (`steep_state`) the strict 1e-12 holds.
-Measured values are printed and written to gpurun_out/parity_errors.json (committed copy: profiles/parity_r02.json).
+Measured values are printed and written to gpurun_out/parity_errors.json (committed copies: profiles/parity_r04.json, parity_r03.json, parity_r02.json).
 """
 import numpy as np
 import pytest

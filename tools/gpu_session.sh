@@ -6,6 +6,7 @@
 #   smoke                  __graft_entry__.smoke()
 #   abenv VAR=VAL [bench args]   same-box A/B of an environment switch of libesdg_hip.so (e.g. ESDG_V2=rhs): new/base x 3
 #   ablib alt.so [bench args]    same-box A/B of two builds (libesdg_hip.so vs esdg_cns_amd/variants/<alt.so>)
+#   testlib alt.so [pytest args] the GPU tests with esdg_cns_amd/variants/<alt.so> in place of the library
 #   kstats TAG [bench args]      rocprofv3 --kernel-trace --stats of one bench run, per-kernel averages
 #   bench [bench args]           python bench.py ... > gpurun_out/bench_<n>.json
 #   py script.py [args]          python <script> (log in gpurun_out/py_<name>.log)
@@ -39,6 +40,13 @@ run_step() {
         echo -n "$v: "; timeout -k 10 300 python bench.py --no-cpu-baseline "$@" 2>/dev/null | grepms; echo
       done
       cp /tmp/ab_new.so esdg_cns_amd/libesdg_hip.so ;;
+    testlib)
+      local alt=$1; shift
+      local a=("$@"); [ ${#a[@]} -eq 0 ] && a=(tests -m gpu -q)
+      cp esdg_cns_amd/libesdg_hip.so /tmp/tl_new.so; cp esdg_cns_amd/variants/$alt esdg_cns_amd/libesdg_hip.so
+      timeout -k 10 1000 python -m pytest "${a[@]}" > gpurun_out/pytest_$alt.log 2>&1; local rc=$?
+      cp /tmp/tl_new.so esdg_cns_amd/libesdg_hip.so
+      tail -4 gpurun_out/pytest_$alt.log; return $rc ;;
     kstats)
       local tag=$1; shift
       bash tools/kstats.sh "$tag" "$@" ;;

@@ -64,14 +64,16 @@ for k in out:
 rhs_name = [k for k in out if "_rhs<" in k]
 sys.path.insert(0, root)
 import bench  # noqa: E402
-main = {k: v for k, v in out.items() if any(t in k for t in ("kt_project", "kt2_project", "kt_sigma", "kt_rhs", "kt2_sigma", "kt2_rhs", "kh_project", "kh_rhs"))}
+main = {k: v for k, v in out.items() if any(t in k for t in ("kt_project", "kt2_project", "kt_sigma", "kt_rhs", "kt2_sigma", "kt2_rhs", "kt3_rhs", "kh_project", "kh_rhs"))}
 # the hash recorded on the GPU box when the passes ran (tools/profile_round.sh); never the hash of whatever the sources are now
 sha_file = os.path.join(src, "kernel_src_sha.txt")
 measured_sha = open(sha_file).read().strip() if os.path.exists(sha_file) else None
 extra = {"kernel_src_sha": measured_sha,
          "whole_rhs_hbm_bytes": sum(v["hbm_bytes_per_launch"] for v in main.values()),
          "whole_rhs_fp64_flops": sum(v.get("fp64_flops", 0.0) for v in main.values()) or None,
-         "k_rhs_fp64_flops_per_launch": (rhs[0].get("fp64_flops") if rhs else None)}
+         "k_rhs_fp64_flops_per_launch": (rhs[0].get("fp64_flops") if rhs else None),
+         "k_rhs_insts_valu_per_launch": (rhs[0].get("insts_valu") if rhs else None),
+         "whole_rhs_insts_valu": sum(v.get("insts_valu", 0.0) for v in main.values()) or None}
 allj[key] = {"source": f"gpurun_out/prof_{tag} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; durations from the "
                        "--kernel-trace --stats pass)",
              "kernels": out, "k_rhs_hbm_bytes_per_launch": rhs[0]["hbm_bytes_per_launch"] if rhs else None,
