@@ -964,6 +964,272 @@ __global__ void kh_rhstest(int64_t n, const double* __restrict__ wJq, const doub
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+
+// =====================================================================================================================
+// Degrees N >= 4, line per lane (round 4; affine meshes: geometry modes 0 and 2; curved meshes stay with kh_rhs_g).
+// kh_rhs_g above is row-wise like the reference: twice the fluxes of a pair-once schedule.  Here, as in kt3_rhs
+// (esdg_kernels_tensor3.hip), a lane owns ONE LINE of an element -- its N1 Gauss nodes and the two face nodes at its ends --
+// and evaluates each of the line's pairs once (C(N1,2) volume-volume, 2 N1 volume-face, 2 interface fluxes) with the
+// N1 + 2 accumulators in registers: no LDS atomics, no row-wise duplicates.  A workgroup holds E elements (three at N = 4, two
+// at N = 5, one above: small workgroups overlap their load and compute phases better than full lanes pay -- at N = 4,
+// 32x32x16 elements, five elements on 384 threads at 98 % lane use took 0.226 ms, two on 192 threads at 78 % 0.153 ms,
+// three on 256 threads at 88 % 0.140 ms); lane l is line l mod (E N1^2) of direction l / (E N1^2).  A node's result is the sum of what its three lines hold for it: direction 0 writes its share to LDS,
+// directions 1 and 2 add theirs in turn (three barriers, every sum in program order: bitwise reproducible, and an
+// element's result does not depend on the group it sits in).  Node-wise work (primitives + logs, the final scaling and
+// store) runs in rounds over all threads.
+// =====================================================================================================================
+#ifndef ESDG_KHL_E5
+#define ESDG_KHL_E5 3
+#endif
+#ifndef ESDG_KHL_E6
+#define ESDG_KHL_E6 2
+#endif
+template <int N1> struct LCfg {   // elements per workgroup: its 3 E N1^2 lines fill T = 64 ceil(3 E N1^2 / 64) lanes
+  static constexpr int E = N1 == 2 ? 16 : (N1 == 3 ? 7 : (N1 == 4 ? 4 : (N1 == 5 ? ESDG_KHL_E5 : (N1 == 6 ? ESDG_KHL_E6 : 1))));
+  static constexpr int NN = N1 * N1, Nq = NN * N1, Nfq = 6 * NN, LLD = E * NN, NV = E * Nq;
+  static constexpr int T = ((3 * LLD + HW - 1) / HW) * HW;
+  static constexpr int NRN = (NV + T - 1) / T;
+};
+
+// (compiler fences of the line stage, see T3_FENCE / T3_PIN4 in esdg_kernels_tensor3.hip)
+#define KHL_FENCE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
+#define KHL_PIN5(a) asm volatile("" : "+v"((a)[0]), "+v"((a)[1]), "+v"((a)[2]), "+v"((a)[3]), "+v"((a)[4]))
+
+template <int N1, int GM>
+__global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M, Phys ph, const double* __restrict__ Q,
+                                                       const double* __restrict__ A_U, double* __restrict__ rhs, LsrkFuse lf) {
+  using C = LCfg<N1>;
+  constexpr HexLayout L(N1);
+  constexpr int E = C::E, NN = C::NN, Nq = C::Nq, Nfq = C::Nfq, T = C::T, NV = C::NV, LLD = C::LLD, NRN = C::NRN;
+  constexpr bool DELTA = GM == 2;
+  static_assert(GM == 0 || GM == 2, "affine meshes only");
+  constexpr int ND = (L.NDBL + T - 1) / T, NI = (L.NINT + T - 1) / T, NG = (E * HEX_GEO_STRIDE + T - 1) / T;
+  typedef double2 d2;
+  __shared__ __align__(16) double sTab[ND * T];
+  __shared__ int sInt[NI * T];
+  __shared__ double sGeo[NG * T];
+  __shared__ __align__(16) double arena[8 * NV];                 // records: 4 pair planes [NV]; later the results [5][NV]
+  __shared__ unsigned sD[DELTA ? 3 * NV : 1];                    // packed metric differences of the volume nodes, [op][slot]
+  d2* sP = reinterpret_cast<d2*>(arena);                         // (rho,u) (v,w) (beta,log rho) (log beta, -)
+  double* sR = arena;
+
+  const int tid = threadIdx.x;
+  const int64_t e0 = M.e_begin + (int64_t)blockIdx.x * E;
+  const int nE = (int)min((int64_t)E, M.e_begin + M.e_count - e0);
+  const int64_t KN = M.K * Nq;
+
+  // ---- this lane's line ----------------------------------------------------------------------------------------------
+  const bool lact = tid < 3 * LLD;                               // (lanes beyond the lines redo line 0: nothing of theirs is written)
+  const int gl = lact ? tid : 0;
+  const int d = gl / LLD, llc = gl - d * LLD;                    // direction, line within the direction
+  const int el = llc / NN, o = llc - el * NN;
+  const int elc = el < nE ? el : 0;                              // (elements beyond the range: the data of the first one)
+  const int64_t ec = e0 + elc;
+  int base, stride;
+  line_of<N1>(d, o, base, stride);
+  const int n0 = el * Nq + base;
+  const int opd = d == 0 ? HT.op[0] : (d == 1 ? HT.op[1] : HT.op[2]);
+  const int fA = HT.ints[L.FN + (d * 2) * NN + o], fB = HT.ints[L.FN + (d * 2 + 1) * NN + o];
+  const int64_t nmA = ec * Nfq + fA, nmB = ec * Nfq + fB;
+  const int64_t npA = M.mapP[nmA], npB = M.mapP[nmB];
+
+  // ---- global loads, unconditionally --------------------------------------------------------------------------------
+  double tabd[ND], geo_r[NG], U[NRN][HEX_NFLD];
+  int tabi[NI];
+  unsigned kvn[NRN][3];
+#pragma unroll
+  for (int r = 0; r < ND; ++r) tabd[r] = HT.dbl[min(tid + r * T, L.NDBL - 1)];
+#pragma unroll
+  for (int r = 0; r < NI; ++r) tabi[r] = HT.ints[min(tid + r * T, L.NINT - 1)];
+#pragma unroll
+  for (int r = 0; r < NG; ++r) geo_r[r] = M.geo[e0 * HEX_GEO_STRIDE + min(tid + r * T, nE * HEX_GEO_STRIDE - 1)];
+#pragma unroll
+  for (int r = 0; r < NRN; ++r) {
+    const int n = tid + r * T, nc = n < nE * Nq ? n : 0;
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) U[r][c] = Q[(int64_t)c * KN + e0 * Nq + nc];
+    if (DELTA) {
+      const int en = nc / Nq, q = nc - en * Nq;
+#pragma unroll
+      for (int o3 = 0; o3 < 3; ++o3) kvn[r][o3] = M.hdv[((e0 + en) * 3 + o3) * Nq + q];
+    }
+  }
+  double rmA[HEX_AU_NC], rpA[HEX_AU_NC], rmB[HEX_AU_NC], rpB[HEX_AU_NC];
+#pragma unroll
+  for (int c = 0; c < HEX_AU_NC; ++c) {
+    rmA[c] = A_U[nmA * HEX_AU_NC + c]; rpA[c] = A_U[npA * HEX_AU_NC + c];
+    rmB[c] = A_U[nmB * HEX_AU_NC + c]; rpB[c] = A_U[npB * HEX_AU_NC + c];
+  }
+  unsigned kfA = 0u, knA = 0u, kfB = 0u, knB = 0u;
+  if (DELTA) { kfA = M.hdf[nmA]; knA = M.hdn[nmA]; kfB = M.hdf[nmB]; knB = M.hdn[nmB]; }
+
+  // ---- staging; node rounds: primitives + logs -> records ---------------------------------------------------------------
+#pragma unroll
+  for (int r = 0; r < ND; ++r) sTab[tid + r * T] = tabd[r];
+#pragma unroll
+  for (int r = 0; r < NI; ++r) sInt[tid + r * T] = tabi[r];
+#pragma unroll
+  for (int r = 0; r < NG; ++r) sGeo[min(tid + r * T, E * HEX_GEO_STRIDE - 1)] = geo_r[r];
+#pragma unroll
+  for (int r = 0; r < NRN; ++r) {
+    const int n = tid + r * T;
+    double qv[7];
+    prim_logs3(U[r], qv);
+    if (n < NV) {
+      sP[n] = make_double2(qv[0], qv[1]); sP[NV + n] = make_double2(qv[2], qv[3]);
+      sP[2 * NV + n] = make_double2(qv[4], qv[5]); sP[3 * NV + n] = make_double2(qv[6], 0.0);
+      if (DELTA) {
+#pragma unroll
+        for (int o3 = 0; o3 < 3; ++o3) sD[o3 * NV + n] = kvn[r][o3];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- line stage ------------------------------------------------------------------------------------------------------------
+  const double* geo = sGeo + elc * HEX_GEO_STRIDE;
+  const double gx = geo[opd], gy = geo[3 + opd], gz = geo[6 + opd];
+  const double hsG = DELTA ? .5 * geo[HEX_GEO_STRIDE - 2] : 0.0, sNs = DELTA ? geo[HEX_GEO_STRIDE - 1] : 0.0;
+  double acc[N1][HEX_NFLD], GA[HEX_NFLD], GB[HEX_NFLD];
+#pragma unroll
+  for (int i = 0; i < N1; ++i)
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) acc[i][c] = 0.0;
+  auto record = [&](int slot, double* q) {
+    const d2 p0 = sP[slot], p1 = sP[NV + slot], p2 = sP[2 * NV + slot], p3 = sP[3 * NV + slot];
+    q[0] = p0.x; q[1] = p0.y; q[2] = p1.x; q[3] = p1.y; q[4] = p2.x; q[5] = p2.y; q[6] = p3.x;
+  };
+  // one face turn: surface flux of face node f (end t of the line), then its N1 volume-face pairs
+  auto face_turn = [&](int t, int f, const double* rm, const double* rp, unsigned kf, unsigned kn, double* G) {
+    double qm[7], qp[7];
+#pragma unroll
+    for (int c = 0; c < HEX_AU_NC; ++c) { qm[c] = rm[c]; qp[c] = rp[c]; }
+    qm[5] = log_pos(qm[0]); qm[6] = log_pos(qm[4]);
+    qp[5] = log_pos(qp[0]); qp[6] = log_pos(qp[4]);
+    const int face = f / NN;
+    double nx = geo[10 + 4 * face], ny = geo[11 + 4 * face], nz = geo[12 + 4 * face];
+    const double sJ = geo[13 + 4 * face];
+    if (DELTA) {   // this node's own normal = face mean + scale * packed difference
+      int a0, a1, a2;
+      unpack3(kn, a0, a1, a2);
+      nx = __builtin_fma(sNs, (double)a0, nx); ny = __builtin_fma(sNs, (double)a1, ny); nz = __builtin_fma(sNs, (double)a2, nz);
+    }
+    ec_flux_dir(qm, qp, nx, ny, nz, G);
+    if (ph.lf_scale != 0.0) {   // (uniform)
+      double UM[HEX_NFLD], UP[HEX_NFLD];
+      const double isJ = rcp_refined(sJ);
+      const double lM = lf_lambda3(qm, nx, ny, nz, isJ, UM);
+      const double lP = lf_lambda3(qp, nx, ny, nz, isJ, UP);
+      const double LFc = ph.lf_scale * fmax(lM, lP) * sJ;
+#pragma unroll
+      for (int c = 0; c < HEX_NFLD; ++c) G[c] -= LFc * (UP[c] - UM[c]);
+    }
+    const double wfac = sTab[L.WFAC + f];
+#pragma unroll
+    for (int c = 0; c < HEX_NFLD; ++c) G[c] *= wfac;
+    int f0 = 0, f1 = 0, f2 = 0;
+    if (DELTA) unpack3(kf, f0, f1, f2);   // this face node's metric differences of direction d
+    const double wtf = sTab[L.WTF + (d * 2 + t) * NN + o];
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+      const int slot = n0 + i * stride;
+      KHL_FENCE();
+      double qn[7], F[HEX_NFLD];
+      record(slot, qn);
+      if (DELTA) {
+        int b0, b1, b2;
+        unpack3(sD[opd * NV + slot], b0, b1, b2);
+        ec_flux_dir(qn, qm, __builtin_fma(hsG, (double)(f0 + b0), gx), __builtin_fma(hsG, (double)(f1 + b1), gy),
+                    __builtin_fma(hsG, (double)(f2 + b2), gz), F);
+      } else {
+        ec_flux_dir(qn, qm, gx, gy, gz, F);
+      }
+      const double W = sTab[L.SF + (d * 2 + t) * N1 + i] * wtf;
+#pragma unroll
+      for (int c = 0; c < HEX_NFLD; ++c) { acc[i][c] = __builtin_fma(W, F[c], acc[i][c]); G[c] = __builtin_fma(-W, F[c], G[c]); }
+      KHL_PIN5(acc[i]); KHL_PIN5(G);
+    }
+  };
+  face_turn(0, fA, rmA, rpA, kfA, knA, GA);
+  face_turn(1, fB, rmB, rpB, kfB, knB, GB);
+  {   // volume-volume pairs of the line, each once
+    const double wt = sTab[L.WT + d * NN + o];
+#pragma unroll
+    for (int i = 0; i < N1 - 1; ++i) {
+      const int si = n0 + i * stride;
+      KHL_FENCE();
+      double qi[7];
+      record(si, qi);
+      int a0 = 0, a1 = 0, a2 = 0;
+      if (DELTA) unpack3(sD[opd * NV + si], a0, a1, a2);
+#pragma unroll
+      for (int j = i + 1; j < N1; ++j) {
+        const int sj = n0 + j * stride;
+        KHL_FENCE();
+        double qj[7], F[HEX_NFLD];
+        record(sj, qj);
+        if (DELTA) {   // metric of the pair = average of the two nodes: record + half the scale times the two differences
+          int b0, b1, b2;
+          unpack3(sD[opd * NV + sj], b0, b1, b2);
+          ec_flux_dir(qi, qj, __builtin_fma(hsG, (double)(a0 + b0), gx), __builtin_fma(hsG, (double)(a1 + b1), gy),
+                      __builtin_fma(hsG, (double)(a2 + b2), gz), F);
+        } else {
+          ec_flux_dir(qi, qj, gx, gy, gz, F);
+        }
+        const double W = sTab[L.S + (d * N1 + i) * N1 + j] * wt;
+#pragma unroll
+        for (int c = 0; c < HEX_NFLD; ++c) { acc[i][c] = __builtin_fma(W, F[c], acc[i][c]); acc[j][c] = __builtin_fma(-W, F[c], acc[j][c]); }
+        KHL_PIN5(acc[i]); KHL_PIN5(acc[j]);
+      }
+    }
+  }
+  // ---- the line's share of Ph*QF + Lf*flux at its nodes; the three directions' shares added in turn ----------------------
+  {
+    const double ptA = sTab[L.PTF + (d * 2) * NN + o], ptB = sTab[L.PTF + (d * 2 + 1) * NN + o];
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+      const double pd = sTab[L.PD + base + i * stride];
+      const double pa = sTab[L.PF + (d * 2) * N1 + i] * ptA, pb = sTab[L.PF + (d * 2 + 1) * N1 + i] * ptB;
+#pragma unroll
+      for (int c = 0; c < HEX_NFLD; ++c) acc[i][c] = __builtin_fma(pb, GB[c], __builtin_fma(pa, GA[c], pd * acc[i][c]));
+    }
+  }
+  __syncthreads();   // every lane is past its reads of the records, whose space takes the results
+#pragma unroll 1
+  for (int step = 0; step < 3; ++step) {
+    if (d == step && lact) {
+#pragma unroll
+      for (int i = 0; i < N1; ++i) {
+        const int slot = n0 + i * stride;
+#pragma unroll
+        for (int c = 0; c < HEX_NFLD; ++c) sR[c * NV + slot] = step == 0 ? acc[i][c] : sR[c * NV + slot] + acc[i][c];
+      }
+    }
+    __syncthreads();
+  }
+  // ---- node rounds: -(.)/J, store or fused low-storage RK stage (:198-212) ------------------------------------------------
+#pragma unroll
+  for (int r = 0; r < NRN; ++r) {
+    const int n = tid + r * T;
+    if (n < nE * Nq) {
+      const int en = n / Nq;
+      const double miJ = -rcp_refined(sGeo[en * HEX_GEO_STRIDE + 9]);
+#pragma unroll
+      for (int c = 0; c < HEX_NFLD; ++c) {
+        const int64_t idx = (int64_t)c * KN + e0 * Nq + n;
+        const double out = sR[c * NV + n] * miJ;
+        if (lf.Qw) {   // (uniform) same rounding sequence as k_lsrk
+          const double rr = __builtin_fma(lf.a, lf.res[idx], lf.dt * out);
+          lf.res[idx] = rr;
+          lf.Qw[idx] = __builtin_fma(lf.b, rr, lf.Qw[idx]);
+        } else {
+          rhs[idx] = out;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace hdev
 
 // N1 = 2 ... 4: one wavefront per element (kh_project / kh_rhs); N1 = 5 ... 8: one workgroup per element (kh_*_g)
@@ -1007,6 +1273,27 @@ int launch_rhs_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phys& p
                    double* rhs, const LsrkFuse& lf, hipStream_t s) {
   if (M.e_count <= 0) return 0;
   const int remap = (ph.dbg & 16) ? 0 : 1;
+  // Affine meshes (geometry modes 0 and 2): the line-per-lane kernel kh_rhs_l at every degree (round 4: N = 3 128x128x16 1.03 vs
+  // 1.23 ms for kh_rhs; N = 1, 2: 0.65, 0.83 x kh_rhs; N = 4 ... 7: 0.47 ... 0.74 x the row-wise kh_rhs_g);
+  // ESDG_HEX_LINE=0: kh_rhs / kh_rhs_g (A/B).  Curved meshes stay with kh_rhs / kh_rhs_g.
+  if (!M.G9) {
+    static int line = -2;
+    if (line == -2) { const char* env = getenv("ESDG_HEX_LINE"); line = !env ? -1 : (env[0] == '1' ? 1 : 0); }
+    if (line != 0) {
+#define ESDG_HEXL_LAUNCH(N1c)                                                                                                 \
+  case N1c: {                                                                                                                \
+    const dim3 grid((unsigned)((M.e_count + hdev::LCfg<N1c>::E - 1) / hdev::LCfg<N1c>::E)), blk(hdev::LCfg<N1c>::T);         \
+    if (M.hdv) hipLaunchKernelGGL((hdev::kh_rhs_l<N1c, 2>), grid, blk, 0, s, HT, M, ph, Q, A_U, rhs, lf);                   \
+    else hipLaunchKernelGGL((hdev::kh_rhs_l<N1c, 0>), grid, blk, 0, s, HT, M, ph, Q, A_U, rhs, lf);                          \
+  } break;
+      switch (N1v) {
+        ESDG_HEXL_LAUNCH(2) ESDG_HEXL_LAUNCH(3) ESDG_HEXL_LAUNCH(4) ESDG_HEXL_LAUNCH(5) ESDG_HEXL_LAUNCH(6) ESDG_HEXL_LAUNCH(7) ESDG_HEXL_LAUNCH(8)
+        default: return (int)hipErrorInvalidValue;
+      }
+#undef ESDG_HEXL_LAUNCH
+      return (int)hipGetLastError();
+    }
+  }
   if (N1v > 4) {
     const dim3 grid((unsigned)M.e_count);
     if (M.G9) { ESDG_HEXG_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_rhs_g<N1, 1>), grid, dim3(hdev::GCfg<N1>::T), 0, s, HT, M, ph, Q, A_U, rhs, lf)); }
