@@ -986,10 +986,21 @@ __global__ void kh_rhstest(int64_t n, const double* __restrict__ wJq, const doub
 #endif
 template <int N1> struct LCfg {   // elements per workgroup: its 3 E N1^2 lines fill T = 64 ceil(3 E N1^2 / 64) lanes
   static constexpr int E = N1 == 2 ? 16 : (N1 == 3 ? 7 : (N1 == 4 ? 4 : (N1 == 5 ? ESDG_KHL_E5 : (N1 == 6 ? ESDG_KHL_E6 : 1))));
-  static constexpr int NN = N1 * N1, Nq = NN * N1, Nfq = 6 * NN, LLD = E * NN, NV = E * Nq;
+  static constexpr int NN = N1 * N1, Nq = NN * N1, Nfq = 6 * NN, LLD = E * NN;
+  // LDS slot of node i0 + N1 i1 + N1^2 i2: i0 + P (i1 + N1 i2) with an odd pitch P, so that the lanes of every direction --
+  // consecutive lines -- read their i-th nodes from distinct banks (measured at N1 = 4 without the padding: 60 % of the LDS
+  // cycles of the kernel were bank conflicts, the direction-0 lanes four to a bank)
+  static constexpr int P = N1 % 2 == 0 ? N1 + 1 : N1, NQP = P * NN, NV = E * NQP, NVN = E * Nq;
   static constexpr int T = ((3 * LLD + HW - 1) / HW) * HW;
-  static constexpr int NRN = (NV + T - 1) / T;
+  static constexpr int NRN = (NVN + T - 1) / T;
 };
+// slot base and stride of the line o of direction d (nodes: line_of above)
+template <int N1>
+__device__ __forceinline__ void line_slots(int d, int o, int& base, int& stride) {
+  constexpr int P = LCfg<N1>::P;
+  stride = d == 0 ? 1 : (d == 1 ? P : P * N1);
+  base = d == 0 ? P * o : (d == 1 ? (o % N1) + P * N1 * (o / N1) : (o % N1) + P * (o / N1));
+}
 
 // (compiler fences of the line stage, see T3_FENCE / T3_PIN4 in esdg_kernels_tensor3.hip)
 #define KHL_FENCE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
@@ -1000,7 +1011,7 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
                                                        const double* __restrict__ A_U, double* __restrict__ rhs, LsrkFuse lf) {
   using C = LCfg<N1>;
   constexpr HexLayout L(N1);
-  constexpr int E = C::E, NN = C::NN, Nq = C::Nq, Nfq = C::Nfq, T = C::T, NV = C::NV, LLD = C::LLD, NRN = C::NRN;
+  constexpr int E = C::E, NN = C::NN, Nq = C::Nq, Nfq = C::Nfq, T = C::T, NV = C::NV, NVN = C::NVN, NQP = C::NQP, LLD = C::LLD, NRN = C::NRN;
   constexpr bool DELTA = GM == 2;
   static_assert(GM == 0 || GM == 2, "affine meshes only");
   constexpr int ND = (L.NDBL + T - 1) / T, NI = (L.NINT + T - 1) / T, NG = (E * HEX_GEO_STRIDE + T - 1) / T;
@@ -1025,9 +1036,10 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
   const int el = llc / NN, o = llc - el * NN;
   const int elc = el < nE ? el : 0;                              // (elements beyond the range: the data of the first one)
   const int64_t ec = e0 + elc;
-  int base, stride;
-  line_of<N1>(d, o, base, stride);
-  const int n0 = el * Nq + base;
+  int base, stride, sbase, sstride;
+  line_of<N1>(d, o, base, stride);          // nodes base + i stride (for the per-node table PD)
+  line_slots<N1>(d, o, sbase, sstride);     // their LDS slots n0 + i sstride
+  const int n0 = el * NQP + sbase;
   const int opd = d == 0 ? HT.op[0] : (d == 1 ? HT.op[1] : HT.op[2]);
   const int fA = HT.ints[L.FN + (d * 2) * NN + o], fB = HT.ints[L.FN + (d * 2 + 1) * NN + o];
   const int64_t nmA = ec * Nfq + fA, nmB = ec * Nfq + fB;
@@ -1075,12 +1087,13 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
     const int n = tid + r * T;
     double qv[7];
     prim_logs3(U[r], qv);
-    if (n < NV) {
-      sP[n] = make_double2(qv[0], qv[1]); sP[NV + n] = make_double2(qv[2], qv[3]);
-      sP[2 * NV + n] = make_double2(qv[4], qv[5]); sP[3 * NV + n] = make_double2(qv[6], 0.0);
+    if (n < NVN) {
+      const int en = n / Nq, q = n - en * Nq, sl = en * NQP + q + (C::P != N1 ? q / N1 : 0);
+      sP[sl] = make_double2(qv[0], qv[1]); sP[NV + sl] = make_double2(qv[2], qv[3]);
+      sP[2 * NV + sl] = make_double2(qv[4], qv[5]); sP[3 * NV + sl] = make_double2(qv[6], 0.0);
       if (DELTA) {
 #pragma unroll
-        for (int o3 = 0; o3 < 3; ++o3) sD[o3 * NV + n] = kvn[r][o3];
+        for (int o3 = 0; o3 < 3; ++o3) sD[o3 * NV + sl] = kvn[r][o3];
       }
     }
   }
@@ -1132,7 +1145,7 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
     const double wtf = sTab[L.WTF + (d * 2 + t) * NN + o];
 #pragma unroll
     for (int i = 0; i < N1; ++i) {
-      const int slot = n0 + i * stride;
+      const int slot = n0 + i * sstride;
       KHL_FENCE();
       double qn[7], F[HEX_NFLD];
       record(slot, qn);
@@ -1156,7 +1169,7 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
     const double wt = sTab[L.WT + d * NN + o];
 #pragma unroll
     for (int i = 0; i < N1 - 1; ++i) {
-      const int si = n0 + i * stride;
+      const int si = n0 + i * sstride;
       KHL_FENCE();
       double qi[7];
       record(si, qi);
@@ -1164,7 +1177,7 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
       if (DELTA) unpack3(sD[opd * NV + si], a0, a1, a2);
 #pragma unroll
       for (int j = i + 1; j < N1; ++j) {
-        const int sj = n0 + j * stride;
+        const int sj = n0 + j * sstride;
         KHL_FENCE();
         double qj[7], F[HEX_NFLD];
         record(sj, qj);
@@ -1200,7 +1213,7 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
     if (d == step && lact) {
 #pragma unroll
       for (int i = 0; i < N1; ++i) {
-        const int slot = n0 + i * stride;
+        const int slot = n0 + i * sstride;
 #pragma unroll
         for (int c = 0; c < HEX_NFLD; ++c) sR[c * NV + slot] = step == 0 ? acc[i][c] : sR[c * NV + slot] + acc[i][c];
       }
@@ -1212,12 +1225,12 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
   for (int r = 0; r < NRN; ++r) {
     const int n = tid + r * T;
     if (n < nE * Nq) {
-      const int en = n / Nq;
+      const int en = n / Nq, q = n - en * Nq, sl = en * NQP + q + (C::P != N1 ? q / N1 : 0);
       const double miJ = -rcp_refined(sGeo[en * HEX_GEO_STRIDE + 9]);
 #pragma unroll
       for (int c = 0; c < HEX_NFLD; ++c) {
         const int64_t idx = (int64_t)c * KN + e0 * Nq + n;
-        const double out = sR[c * NV + n] * miJ;
+        const double out = sR[c * NV + sl] * miJ;
         if (lf.Qw) {   // (uniform) same rounding sequence as k_lsrk
           const double rr = __builtin_fma(lf.a, lf.res[idx], lf.dt * out);
           lf.res[idx] = rr;
