@@ -7,6 +7,7 @@
 #   abenv VAR=VAL [bench args]   same-box A/B of an environment switch of libesdg_hip.so (e.g. ESDG_V2=rhs): new/base x 3
 #   ablib alt.so [bench args]    same-box A/B of two builds (libesdg_hip.so vs esdg_cns_amd/variants/<alt.so>)
 #   testlib alt.so [pytest args] the GPU tests with esdg_cns_amd/variants/<alt.so> in place of the library
+#   round1 TAG / round2 TAG      the profile set of a round in two calls of under 20 minutes (collect with tools/collect_round.sh TAG)
 #   kstats TAG [bench args]      rocprofv3 --kernel-trace --stats of one bench run, per-kernel averages
 #   bench [bench args]           python bench.py ... > gpurun_out/bench_<n>.json
 #   py script.py [args]          python <script> (log in gpurun_out/py_<name>.log)
@@ -47,6 +48,18 @@ run_step() {
       timeout -k 10 1000 python -m pytest "${a[@]}" > gpurun_out/pytest_$alt.log 2>&1; local rc=$?
       cp /tmp/tl_new.so esdg_cns_amd/libesdg_hip.so
       tail -4 gpurun_out/pytest_$alt.log; return $rc ;;
+    round1)   # final pass of a round, part 1: GPU suite, smoke, rocprofv3 + PMC passes and the default bench line for cns (cfg3)
+      local tag=$1; local O=gpurun_out/$tag; mkdir -p $O
+      timeout -k 10 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
+      cp gpurun_out/parity_errors.json $O/parity_errors.json
+      python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
+      bash tools/run_round.sh $tag ;;
+    round2)   # part 2: Euler (cfg2) and hex (cfg5 per GPU) profile sets, SQ counters of the three workloads
+      local tag=$1; local O=gpurun_out/$tag; mkdir -p $O
+      bash tools/profile_other_configs.sh $tag
+      bash tools/pmc_sq.sh ${tag}_cns > $O/sq_counters.txt 2>&1; tail -3 $O/sq_counters.txt
+      bash tools/pmc_sq.sh ${tag}_hex --formulation hex > $O/hex_sq_counters.txt 2>&1; tail -3 $O/hex_sq_counters.txt
+      bash tools/pmc_sq.sh ${tag}_euler --formulation euler --kx 256 --ky-per-gpu 256 > $O/euler_sq_counters.txt 2>&1; tail -3 $O/euler_sq_counters.txt ;;
     kstats)
       local tag=$1; shift
       bash tools/kstats.sh "$tag" "$@" ;;

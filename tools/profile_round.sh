@@ -13,10 +13,10 @@ rm -rf $OUT && mkdir -p $OUT
 # the hash of the kernel sources these passes measure (summarize_pmc.py stamps it into pmc_traffic.json; bench.py drops the
 # PMC-derived fields when the sources have changed since)
 python3 -c "import bench; print(bench.kernel_source_hash())" > $OUT/kernel_src_sha.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline $EXTRA > $OUT/trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/valu -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/valu.log 2>&1 || echo "fp64 VALU counters unavailable"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-rough-state $EXTRA > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-rough-state $EXTRA > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-rough-state $EXTRA > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/valu -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-rough-state $EXTRA > $OUT/valu.log 2>&1 || echo "fp64 VALU counters unavailable"
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 find $OUT/fetch -name "*counter_collection.csv" -exec cp {} $OUT/fetch_counters.csv \;
 find $OUT/write -name "*counter_collection.csv" -exec cp {} $OUT/write_counters.csv \;

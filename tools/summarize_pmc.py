@@ -49,7 +49,7 @@ for k in sorted(set(f) | set(w)):
     out[k].update(valu.get(k, {}))
 dst = os.path.join(root, "profiles", "pmc_traffic.json")
 allj = json.load(open(dst)) if os.path.exists(dst) else {}
-rhs = [v for k, v in out.items() if "_rhs<" in k]
+rhs = [v for k, v in out.items() if "_rhs<" in k or "_rhs_l<" in k]
 # average kernel durations of the --kernel-trace --stats pass of the same command (profiles/<tag>_*_kernel_stats.csv)
 stats = os.path.join(src, "kernel_stats.csv")
 avg_us = {}
@@ -61,7 +61,7 @@ if os.path.exists(stats):
 for k in out:
     if k in avg_us:
         out[k]["rocprofv3_avg_us"] = avg_us[k]
-rhs_name = [k for k in out if "_rhs<" in k]
+rhs_name = [k for k in out if "_rhs<" in k or "_rhs_l<" in k]
 sys.path.insert(0, root)
 import bench  # noqa: E402
 main = {k: v for k, v in out.items() if any(t in k for t in ("kt_project", "kt2_project", "kt_sigma", "kt_rhs", "kt2_sigma", "kt2_rhs", "kt3_rhs", "kh_project", "kh_rhs"))}
