@@ -162,7 +162,8 @@ struct Phys {
   double Re, mu, lambda, Pr;
   double kappa, inv_Re;   // 1.4*mu/Pr and 1/Re, computed once on the host (a per-lane fp64 division costs ~15 instructions)
   int dbg;  // timing-ablation mask from the ESDG_DBG environment variable (1: skip the volume flux differencing, 2: skip the
-            // viscous stage, 16: hex workgroup remap off); 0 in normal use
+            // viscous stage, 16: hex workgroup remap off, 32: kt3_rhs computes every logarithm -- its smooth-wave short cut off,
+            // same results bit for bit); 0 in normal use
   double inflow_q[6];   // BCTYPE 4: Dirichlet state as a trace record (rho,u,v,beta,log rho,log beta)
   double inflow_vv[3];  //           and its entropy variables (v2,v3,v4) = v_ufun(...)[2:4]
   int parts;  // bit 0: inviscid terms (rhs_inviscid!), bit 1: viscous terms (rhs_viscous!); 3 = rhsRK!

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Wpe3<N1>::W)
     ok = ok && fabs(qMA[0] - a0) <= ta && fabs(qPA[0] - a0) <= ta && fabs(qMB[0] - a0) <= ta && fabs(qPB[0] - a0) <= ta;
     ok = ok && fabs(qMA[3] - b0) <= tb && fabs(qPA[3] - b0) <= tb && fabs(qMB[3] - b0) <= tb && fabs(qPB[3] - b0) <= tb;
   }
-  const bool smooth = ESDG_T3_LAZY_LOGS && __builtin_amdgcn_ballot_w64(ok) == __builtin_amdgcn_ballot_w64(true);   // (uniform)
+  const bool smooth = ESDG_T3_LAZY_LOGS && !(ph.dbg & 32) && __builtin_amdgcn_ballot_w64(ok) == __builtin_amdgcn_ballot_w64(true);   // (uniform)
   if (!smooth) {
 #pragma unroll
     for (int r = 0; r < NR; ++r) sRec[2 * NV + slot[r]] = make_double2(log_pos(U[r][0]), log_pos(U[r][3]));

@@ -481,3 +481,45 @@ def test_generic_fallback_refuses_wall_meshes_explicitly(E):
         del os.environ["ESDG_FORCE_GENERIC"]
     eng = E.RhsEngine(rd, md, ops, E.CNS_MODAL, BCTYPE=1)        # the tensor kernels take the same mesh
     assert eng.L.esdg_uses_tensor_kernels(eng.ctx) == 1
+
+
+@pytest.mark.parametrize("form", ["cns", "euler"])
+def test_smooth_wave_short_cut_of_the_last_phase_is_bitwise_the_general_path(E, form):
+    """kt3_rhs skips the logarithms of a wave whose densities / betas all agree to 0.49e-4 (every log-mean of such a wave is the
+    reference's series branch, logmean.jl:23-27, which reads none).  Claim: bit-identical results.  ESDG_DBG=32 switches the short
+    cut off; on the vortex box most waves of a 96x64 mesh take it (far field), the ones around the core do not, and on a state
+    with 1 % node-to-node noise none does -- all three must agree bit for bit between the two settings."""
+    import bench
+    prob = product_cns_problem if form == "cns" else product_euler_problem
+    rd, md, ops, Q = prob(4, 96, 64)
+    states = {"vortex": Q, "rough": bench.rough_state(Q)}
+    const = [np.full_like(q, v) for q, v in zip(Q, (1.3, 0.4, -0.2, 2.9))]
+    states["uniform"] = const
+    form_id = E.CNS_MODAL if form == "cns" else E.EULER_COLLOCATED
+    lazy = E.RhsEngine(rd, md, ops, form_id)
+    os.environ["ESDG_DBG"] = "32"
+    try:
+        full = E.RhsEngine(rd, md, ops, form_id)
+    finally:
+        del os.environ["ESDG_DBG"]
+    for name, S in states.items():
+        a, b = _rhs(lazy, S), _rhs(full, S)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), (form, name)
+
+
+@pytest.mark.parametrize("form,N", [("cns", 4), ("cns", 2), ("euler", 3), ("euler", 6)])
+def test_line_per_lane_and_node_per_lane_last_phase_kernels_agree(E, form, N):
+    """kt3_rhs (production) against kt2_rhs (ESDG_V2=rhs): two mappings of the same formulas -- different summation orders, so
+    round-off apart, not bitwise."""
+    prob = product_cns_problem if form == "cns" else product_euler_problem
+    rd, md, ops, Q = prob(N, 13, 9)               # 117 elements: a partial last group in both kernels
+    Qs = steep_state(md.x, md.y) if form == "cns" else steep_state(md.xq, md.yq)
+    form_id = E.CNS_MODAL if form == "cns" else E.EULER_COLLOCATED
+    v3 = E.RhsEngine(rd, md, ops, form_id)
+    os.environ["ESDG_V2"] = "rhs"
+    try:
+        v2 = E.RhsEngine(rd, md, ops, form_id)
+    finally:
+        del os.environ["ESDG_V2"]
+    assert rel_l2(_rhs(v3, Qs), _rhs(v2, Qs)) <= 1e-12

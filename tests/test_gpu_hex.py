@@ -315,3 +315,44 @@ def test_hex_per_node_geometry_of_affine_meshes_at_a_size_where_it_matters(eng_m
         assert e0 <= 20 * e_orc                # the element record filters the set-up's round-off: documented deviation
     finally:
         orc.lib().oracle_set_threads(1); orc.lib_quad().oracle_set_threads(1)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 4])
+def test_hex_line_per_lane_and_node_per_lane_kernels_agree(eng_mod, N):
+    """kh_rhs_l (production on affine meshes) against kh_rhs / the row-wise kh_rhs_g (ESDG_HEX_LINE=0), element record and per-node
+    geometry: two mappings of the same formulas, round-off apart.  (The switch is read once per process by the launcher, so the
+    second setting runs in a child process.)"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.path.join(%r, "tests")); sys.path.insert(0, %r)
+import torch
+from common import hex_random_state
+from esdg_cns_amd import engine, setup_dg as sd
+N = %d
+for per_node in (False, True):
+    VX, VY, VZ, EToV = sd.uniform_hex_mesh(5, 3, 4)
+    rd = sd.init_reference_hex(N, sd.gauss_quad(0, 0, N))
+    md = sd.init_mesh_3d((VX, VY, VZ), EToV, rd)
+    sd.make_periodic_3d(md, rd)
+    ops = sd.hex_ops(rd)
+    sd.hex_driver_geometry(md, rd, hybrid=per_node)
+    Q = hex_random_state(md.xq.shape, seed=5, vel=(0.3, 1.0, -0.2))
+    eng = engine.RhsEngine(rd, md, ops, engine.EULER_HEX_COLLOCATED, lf_scale=0.25)
+    out = eng.download(eng.rhs(eng.upload(Q)))
+    np.save(sys.argv[1] + ("_pn" if per_node else "_el") + ".npy", np.stack(out))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        res = {}
+        for tag, env in (("line", {}), ("node", {"ESDG_HEX_LINE": "0"})):
+            p = subprocess.run([sys.executable, "-c", code % (root, root, N), os.path.join(td, tag)], env=dict(os.environ, **env),
+                               capture_output=True, text=True, timeout=600)
+            assert p.returncode == 0, p.stderr[-2000:]
+            res[tag] = {k: np.load(os.path.join(td, tag + "_" + k + ".npy")) for k in ("el", "pn")}
+        for k in ("el", "pn"):
+            a, b = res["line"][k], res["node"][k]
+            assert np.linalg.norm(a - b) <= 1e-12 * np.linalg.norm(b), (N, k)
