@@ -1376,10 +1376,11 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
     if (!rhs && !lf.Qw) return fail(ESDG_ERR_ARG, "rhs output is null");
     if (lf.Qw && !ctx->use_fast) return fail(ESDG_ERR_STATE, "the fused RK update needs the tensor kernels");
     rc = -1;
-    // v3 kernel (line-per-lane flux stage, esdg_kernels_tensor3.hip): meshes without walls; ESDG_V2=rhs: the v2 kernel (A/B)
+    // v3 kernel (line-per-lane flux stage, esdg_kernels_tensor3.hip); on meshes with walls it follows kt2_sigma's protocol, so
+    // the viscous phase must be the v2 one there; ESDG_V2=rhs: the v2 kernel (A/B)
     // (ESDG_DBG bit 32: kt3_rhs takes every logarithm whatever the state -- the partner of the bitwise test of its data-dependent
     // short cut, tests/test_gpu_engine.py)
-    if (ctx->use_fast && !(ctx->ph.dbg & ~32) && !ctx->M.bc && !(ctx->v1 & 2) && !(ctx->v2 & 2))
+    if (ctx->use_fast && !(ctx->ph.dbg & ~32) && !(ctx->v1 & 2) && !(ctx->v2 & 2) && (!ctx->M.bc || v2_on_walls(ctx)))
       rc = launch_rhs_tensor3(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s);
     if (rc == -1 && ctx->use_fast && !(ctx->ph.dbg & ~32) && (ctx->M.bc ? v2_on_walls(ctx) : !(ctx->v1 & 2)))      // v2 kernel: N1 = N + 1 = 2 ... 8
       rc = launch_rhs_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s);

@@ -20,7 +20,8 @@
 //     wave with the node-per-lane layout of kt2_rhs.
 // An element's result depends on nothing but its own data and its neighbours' traces (no cross-lane reduction whose order
 // depends on the slot), so ranged, sharded and full launches agree bit for bit as before.
-// Meshes with walls stay with kt2_rhs (launch_rhs_tensor3 returns -1).
+// Meshes with walls: the WALLS instantiation applies the closures of init_BC_funs / the shock-tube driver in the face turns and
+// the nodal-basis correction of the wall elements after Pq, both as kt2_rhs does (formulas and citations there).
 #include "esdg_dev.hpp"
 #include "esdg_tensor_tables.hpp"
 #include "esdg_devmath.hpp"
@@ -81,7 +82,7 @@ template <int N1> struct Wpe3 { static constexpr int W = N1 <= 6 ? 3 : (N1 == 7 
 #else
 #define T3_VGPR_ATTR
 #endif
-template <int N1, bool MODAL, bool VISC>
+template <int N1, bool MODAL, bool VISC, bool WALLS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Wpe3<N1>::W))) T3_VGPR_ATTR void kt3_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                           const double* __restrict__ A_U, const double* __restrict__ SG,
                                                           const double* __restrict__ B, double* __restrict__ rhs, LsrkFuse lf) {
@@ -96,6 +97,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Wpe3<N1>::W)
   __shared__ __align__(16) double arena[8 * NV];
   __shared__ __align__(16) double sGeo[GPT * TW];
   __shared__ __align__(16) double sTab[TPT * TW];
+  // WALLS (CNS): the lines' shares of the lifted penalty per node, [2 directions][3][NV], and the elements that have a boundary node
+  constexpr bool WCORR = WALLS && VISC && MODAL;
+  __shared__ double sX[WCORR ? 6 * NV : 1];
+  __shared__ int sEb[WALLS ? E : 1];
   d2* sA = reinterpret_cast<d2*>(arena);                // [2][NV]
   d2* sB = reinterpret_cast<d2*>(arena + 4 * NV);       // [2][NV]
   d2* sRec = reinterpret_cast<d2*>(arena);              // [3][NV]
@@ -145,6 +150,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Wpe3<N1>::W)
     }
   }
   const float2 ndA = reinterpret_cast<const float2*>(M.fnd)[nfA], ndB = reinterpret_cast<const float2*>(M.fnd)[nfB];
+  int bcA = 0, bcB = 0;              // WALLS: boundary flag (1 wall, 2 lid, 3 inflow, 4 copy), lid velocity, sJ - face mean
+  double vlA = 1.0, vlB = 1.0;
+  float sdA = 0.f, sdB = 0.f;
+  if (WALLS) {
+    bcA = M.bc[nfA]; bcB = M.bc[nfB];
+    if (M.vlid) { vlA = M.vlid[nfA]; vlB = M.vlid[nfB]; }
+    sdA = M.fsd[nfA]; sdB = M.fsd[nfB];
+    if (tid < (unsigned)E) sEb[tid] = 0;
+  }
   double bsA[3] = {0, 0, 0}, bsB[3] = {0, 0, 0};   // central stress jump .5*((sxP-sxf)*nxJ + (syP-syf)*nyJ) of the two face nodes
   if (VISC) {
 #pragma unroll
@@ -242,6 +256,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Wpe3<N1>::W)
     ok = ok && fabs(qMA[0] - a0) <= ta && fabs(qPA[0] - a0) <= ta && fabs(qMB[0] - a0) <= ta && fabs(qPB[0] - a0) <= ta;
     ok = ok && fabs(qMA[3] - b0) <= tb && fabs(qPA[3] - b0) <= tb && fabs(qMB[3] - b0) <= tb && fabs(qPB[3] - b0) <= tb;
   }
+  if (WALLS) ok = ok && bcA != 3 && bcB != 3;   // (a Dirichlet inflow state takes the place of a neighbour's and is not part of this test)
   const bool smooth = ESDG_T3_LAZY_LOGS && !(ph.dbg & 32) && __builtin_amdgcn_ballot_w64(ok) == __builtin_amdgcn_ballot_w64(true);   // (uniform)
   if (!smooth) {
 #pragma unroll
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Wpe3<N1>::W)
   __syncthreads();
 
   // ---- line stage ----------------------------------------------------------------------------------------------------------------
-  double acc[N1][4], GfA[4], GfB[4];
+  double acc[N1][4], GfA[4], GfB[4], gpA[3] = {0, 0, 0}, gpB[3] = {0, 0, 0};   // (gp: WALLS, the penalty's share of the face totals)
 #pragma unroll
   for (int i = 0; i < N1; ++i)
 #pragma unroll
@@ -260,9 +275,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Wpe3<N1>::W)
     const int opd = d ? TT.op1 : TT.op0;
     const double gxd = 2 * g[opd], gyd = 2 * g[2 + opd];     // metric vector of the line's direction (affine: one per element)
     // one face turn: interface flux + penalty + stress jump of face node f (end t of the line), then its N1 volume-face pairs
-    auto face_turn = [&](int t, int f, double* qM, double* qP, const float2 nd, const double* bs, double* Gf) {
+    auto face_turn = [&](int t, int f, double* qM, double* qP, const float2 nd, const double* bs, double* Gf, int bc, double vlid, float sd,
+                         double* gpen) {
       const double* gm = g + 5 + 3 * (f / N1);             // face means of the record; + this node's difference = its own normal
-      const double gn[3] = {gm[0] + (double)nd.x, gm[1] + (double)nd.y, gm[2]};
+      // (sJ: the face mean unless a wall closure turns it into a unit normal -- it only scales the LF term, a small jump)
+      const double gn[3] = {gm[0] + (double)nd.x, gm[1] + (double)nd.y, WALLS ? gm[2] + (double)sd : gm[2]};
+      if (WALLS && bc) sEb[el] = 1;
       {
         const double isJm = rcp_refined(gm[2]);
         if (!smooth) { qM[4] = log_pos(qM[0]); qM[5] = log_pos(qM[3]); qP[4] = log_pos(qP[0]); qP[5] = log_pos(qP[3]); }
@@ -274,14 +292,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Wpe3<N1>::W)
       if (VISC) {   // penalty tau*[[v]] (:817-837): the projected entropy variables are those OF the trace states
         const double bM = 2 * GM1 * qM[3], bP = 2 * GM1 * qP[3];
         const double tau = ph.viscous_dissp ? -rcp_refined(-bM) * ph.inv_Re : 0.0;
-        pnr[0] = tau * (bP * qP[1] - bM * qM[1]);
-        pnr[1] = tau * (bP * qP[2] - bM * qM[2]);
-        pnr[2] = tau * (bM - bP);
+        if (WALLS && bc) {   // exterior values by the wall closure; third component overridden as in :827-837 (see kt2_rhs)
+          const double vf[3] = {bM * qM[1], bM * qM[2], -bM};
+          double vP[3];
+          t2::wall_exterior_v(vf, bc, vlid, gn, ph, vP);
+          const double dV[3] = {vP[0] - vf[0], vP[1] - vf[1], vP[2] - vf[2]};
+          const double a2 = .5 * (vP[0] + vf[0]), a3 = .5 * (vP[1] + vf[1]);
+          double sq = a2 * dV[0] + a3 * dV[1];
+          if (ph.BCTYPE != 1) sq += dV[2] * dV[2] * .5;
+          pnr[0] = tau * dV[0];
+          pnr[1] = tau * dV[1];
+          pnr[2] = -tau * sq * rcp_refined(vf[2]);
+        } else {
+          pnr[0] = tau * (bP * qP[1] - bM * qM[1]);
+          pnr[1] = tau * (bP * qP[2] - bM * qM[2]);
+          pnr[2] = tau * (bM - bP);
+        }
+      }
+      if (WALLS && bc >= 3) {   // shock-tube closures (dg2D_CNS_modalESDG.jl:168-185): Dirichlet state / copy, lam = lamP = 0
+#pragma unroll
+        for (int c = 0; c < 6; ++c) qP[c] = bc == 3 ? ph.inflow_q[c] : qM[c];
+        qM[6] = 0.0; qP[6] = 0.0;
+      } else if (WALLS && bc) {   // wall: mirror state rho+ = rho, beta+ = beta, u+ = u - 2 (u.n) n  (impose_BCs_inviscid! :157-176)
+        const double is = rcp_refined(gn[2]);
+        const double nx = gn[0] * is, ny = gn[1] * is;
+        const double un = qM[1] * nx + qM[2] * ny;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) qP[c] = qM[c];
+        qP[1] = qM[1] - 2 * un * nx;
+        qP[2] = qM[2] - 2 * un * ny;
       }
       double Fn[4];
       ec_flux_dir<MODAL>(qM, qP, gn[0], gn[1], Fn);
       const double LFc = ph.inviscid_dissp ? ph.lf_scale * fmax(qM[6], qP[6]) * gn[2] : 0.0;
-      const double dU[4] = {qP[0] - qM[0], qP[0] * qP[1] - qM[0] * qM[1], qP[0] * qP[2] - qM[0] * qM[2], qP[7] - qM[7]};
+      // (the LF jump uses Uf[mapP] - Uf, which vanishes at boundary nodes: mapP = self, cavity :511-513)
+      const double dz = (WALLS && bc) ? 0.0 : 1.0;
+      const double dU[4] = {dz * (qP[0] - qM[0]), dz * (qP[0] * qP[1] - qM[0] * qM[1]), dz * (qP[0] * qP[2] - qM[0] * qM[2]), dz * (qP[7] - qM[7])};
       const double wfac = sTab[TL.WFAC + f];
       const double wf = inviscid ? wfac : 0.0;
 #pragma unroll
@@ -290,6 +336,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Wpe3<N1>::W)
         const double Jf = g[4], ws = viscous ? wfac : 0.0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) Gf[c + 1] = __builtin_fma(-ws, __builtin_fma(Jf, pnr[c], bs[c]), Gf[c + 1]);
+        if (WALLS) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) gpen[c] = ws * Jf * pnr[c];
+        }
       }
       if (inviscid) {   // (uniform)
         const double wt = sTab[TL.WTF + (2 * d + t) * N1 + o];
@@ -310,8 +360,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Wpe3<N1>::W)
         }
       }
     };
-    face_turn(0, fA, qMA, qPA, ndA, bsA, GfA);
-    face_turn(1, fB, qMB, qPB, ndB, bsB, GfB);
+    face_turn(0, fA, qMA, qPA, ndA, bsA, GfA, bcA, vlA, sdA, gpA);
+    face_turn(1, fB, qMB, qPB, ndB, bsB, GfB, bcB, vlB, sdB, gpB);
     if (inviscid) {   // volume-volume pairs of the line, each once
       const double wt = sTab[TL.WT + d * N1 + o];
       const double gxv = gxd * wt, gyv = gyd * wt;
@@ -363,12 +413,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Wpe3<N1>::W)
       const unsigned n = n0 + i * st;
       sS[(2 * d) * NV + n] = make_double2(rr[0], rr[1]);
       sS[(2 * d + 1) * NV + n] = make_double2(rr[2], rr[3]);
+      if (WCORR) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sX[(3 * d + c) * NV + n] = __builtin_fma(pb, gpB[c], pa * gpA[c]);
+      }
     }
   }
   __syncthreads();
+  // Meshes with walls: the reference divides the nodal coefficients of everything but the penalty by J[i,e] NODE BY NODE; in the
+  // elements with a boundary node that shows and the result is corrected after Pq exactly as in kt2_rhs:
+  // out_i (1 + g_i) - g_i (Pq X)_i, g_i = J / J[i,e] - 1, X = lift of the penalty + volume divergence at the Gauss nodes.
+  const bool gb = WCORR && M.wgeo && __builtin_amdgcn_ballot_w64((bcA | bcB) != 0) != 0;   // (uniform: the workgroup is this wave)
 
   // ---- node rounds: rhs at the Gauss nodes = -(r_0 + r_1)/J (+ viscous volume divergence / J), then Pq -----------------------
-  double R[NR][4];
+  double R[NR][4], RX[WCORR ? NR : 1][4];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const unsigned s = slot[r], ev = s / Nq;
@@ -379,51 +437,73 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Wpe3<N1>::W)
       const double vs = viscous ? iJ : 0.0;
 #pragma unroll
       for (int c = 0; c < 3; ++c) R[r][c + 1] = __builtin_fma(dvs[r][c], vs, R[r][c + 1]);
+      if (WCORR && gb) {
+        RX[r][0] = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) RX[r][c + 1] = __builtin_fma(dvs[r][c], vs, (sX[c * NV + s] + sX[(3 + c) * NV + s]) * iJ);
+      }
     }
   }
   double out[NR][4];
   if (MODAL) {
-    __syncthreads();   // every lane is past its reads of the lines' results
+    // o = Pq X as in kt2_rhs: W[a + N1 b] = sum_j IP[a,j] X[b + N1 j], o[a + N1 b] = sum_i IP[b,i] W[a + N1 i]
+    auto pq_apply = [&](const double (*X)[4], double (*o)[4]) {
+      __syncthreads();   // every lane is past its reads of what the two buffers held before
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      sA[slot[r]] = make_double2(R[r][0], R[r][1]);
-      sA[NV + slot[r]] = make_double2(R[r][2], R[r][3]);
-    }
-    __syncthreads();
-    // out = Pq R as in kt2_rhs: W[a + N1 b] = sum_j IP[a,j] R[b + N1 j], out[a + N1 b] = sum_i IP[b,i] W[a + N1 i]
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const unsigned ev = slot[r] / Nq, a = nq[r] % N1, b = nq[r] / N1;
-      const double* c = sTab + TL.IP + a * N1;
-      const d2* rw = sA + ev * Nq + b;
-      d2 p = rw[0], t = rw[NV];
-      const double c0 = c[0];
-      double w0 = c0 * p.x, w1 = c0 * p.y, w2 = c0 * t.x, w3 = c0 * t.y;
-#pragma unroll
-      for (int j = 1; j < N1; ++j) {
-        p = rw[N1 * j]; t = rw[NV + N1 * j];
-        const double cj = c[j];
-        w0 = __builtin_fma(cj, p.x, w0); w1 = __builtin_fma(cj, p.y, w1);
-        w2 = __builtin_fma(cj, t.x, w2); w3 = __builtin_fma(cj, t.y, w3);
+      for (int r = 0; r < NR; ++r) {
+        sA[slot[r]] = make_double2(X[r][0], X[r][1]);
+        sA[NV + slot[r]] = make_double2(X[r][2], X[r][3]);
       }
-      sB[slot[r]] = make_double2(w0, w1);
-      sB[NV + slot[r]] = make_double2(w2, w3);
-    }
-    __syncthreads();
+      __syncthreads();
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const unsigned ev = slot[r] / Nq, a = nq[r] % N1, b = nq[r] / N1;
-      const double* c = sTab + TL.IP + b * N1;
-      const d2* rw = sB + ev * Nq + a;
-      d2 p = rw[0], t = rw[NV];
-      const double c0 = c[0];
-      out[r][0] = c0 * p.x; out[r][1] = c0 * p.y; out[r][2] = c0 * t.x; out[r][3] = c0 * t.y;
+      for (int r = 0; r < NR; ++r) {
+        const unsigned ev = slot[r] / Nq, a = nq[r] % N1, b = nq[r] / N1;
+        const double* c = sTab + TL.IP + a * N1;
+        const d2* rw = sA + ev * Nq + b;
+        d2 p = rw[0], t = rw[NV];
+        const double c0 = c[0];
+        double w0 = c0 * p.x, w1 = c0 * p.y, w2 = c0 * t.x, w3 = c0 * t.y;
 #pragma unroll
-      for (int i = 1; i < N1; ++i) {
-        p = rw[N1 * i]; t = rw[NV + N1 * i];
-        const double ci = c[i];
-        out[r][0] = __builtin_fma(ci, p.x, out[r][0]); out[r][1] = __builtin_fma(ci, p.y, out[r][1]);
-        out[r][2] = __builtin_fma(ci, t.x, out[r][2]); out[r][3] = __builtin_fma(ci, t.y, out[r][3]);
+        for (int j = 1; j < N1; ++j) {
+          p = rw[N1 * j]; t = rw[NV + N1 * j];
+          const double cj = c[j];
+          w0 = __builtin_fma(cj, p.x, w0); w1 = __builtin_fma(cj, p.y, w1);
+          w2 = __builtin_fma(cj, t.x, w2); w3 = __builtin_fma(cj, t.y, w3);
+        }
+        sB[slot[r]] = make_double2(w0, w1);
+        sB[NV + slot[r]] = make_double2(w2, w3);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const unsigned ev = slot[r] / Nq, a = nq[r] % N1, b = nq[r] / N1;
+        const double* c = sTab + TL.IP + b * N1;
+        const d2* rw = sB + ev * Nq + a;
+        d2 p = rw[0], t = rw[NV];
+        const double c0 = c[0];
+        o[r][0] = c0 * p.x; o[r][1] = c0 * p.y; o[r][2] = c0 * t.x; o[r][3] = c0 * t.y;
+#pragma unroll
+        for (int i = 1; i < N1; ++i) {
+          p = rw[N1 * i]; t = rw[NV + N1 * i];
+          const double ci = c[i];
+          o[r][0] = __builtin_fma(ci, p.x, o[r][0]); o[r][1] = __builtin_fma(ci, p.y, o[r][1]);
+          o[r][2] = __builtin_fma(ci, t.x, o[r][2]); o[r][3] = __builtin_fma(ci, t.y, o[r][3]);
+        }
+      }
+    };
+    pq_apply(R, out);
+    if (WCORR && gb) {   // (uniform) second product for the part that keeps the record's J; correction per element and node
+      double ox[NR][4];
+      pq_apply(RX, ox);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const unsigned ev = slot[r] / Nq, evc = ev < (unsigned)nE ? ev : 0u;
+        if (sEb[ev]) {
+          const double Jn = M.wgeo[((e0 + evc) * 5 + 4) * Nq + nq[r]];
+          const double gam = __builtin_fma(sGeo[ev * GEO_STRIDE + 4], rcp_refined(Jn), -1.0);
+#pragma unroll
+          for (int f = 0; f < 4; ++f) out[r][f] = __builtin_fma(gam, out[r][f] - ox[r][f], out[r][f]);
+        }
       }
     }
   } else {
@@ -476,14 +556,15 @@ static void launch_rhs3(const TensorTables& TT, const MeshDev& M, const Phys& ph
                         const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s) {
   using G = t3::G3<N1>;
   const int nb = (int)((M.e_count + G::E - 1) / G::E);
-  hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
+  if (M.bc) hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
+  else hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, false>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
 }
 
 // last phase on meshes without walls; returns -1 where the v3 kernel does not apply (caller falls back to kt2_rhs)
 int launch_rhs_tensor3(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
                        const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s) {
   if (M.e_count <= 0) return 0;
-  if (M.bc) return -1;
+  if (M.bc && N1v == 8) return -1;   // (the wall instantiation at N1 = 8 would not fit the register file)
   const bool modal = ph.formulation != 0, visc = ph.formulation == 1;
   ESDG_T3_DISPATCH(N1v, {
     if (!modal) (launch_rhs3<N1, false, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
