@@ -978,6 +978,9 @@ __global__ void kh_rhstest(int64_t n, const double* __restrict__ wJq, const doub
 // element's result does not depend on the group it sits in).  Node-wise work (primitives + logs, the final scaling and
 // store) runs in rounds over all threads.
 // =====================================================================================================================
+#ifndef ESDG_KHL_E4
+#define ESDG_KHL_E4 4
+#endif
 #ifndef ESDG_KHL_E5
 #define ESDG_KHL_E5 3
 #endif
@@ -985,7 +988,7 @@ __global__ void kh_rhstest(int64_t n, const double* __restrict__ wJq, const doub
 #define ESDG_KHL_E6 2
 #endif
 template <int N1> struct LCfg {   // elements per workgroup: its 3 E N1^2 lines fill T = 64 ceil(3 E N1^2 / 64) lanes
-  static constexpr int E = N1 == 2 ? 16 : (N1 == 3 ? 7 : (N1 == 4 ? 4 : (N1 == 5 ? ESDG_KHL_E5 : (N1 == 6 ? ESDG_KHL_E6 : 1))));
+  static constexpr int E = N1 == 2 ? 16 : (N1 == 3 ? 7 : (N1 == 4 ? ESDG_KHL_E4 : (N1 == 5 ? ESDG_KHL_E5 : (N1 == 6 ? ESDG_KHL_E6 : 1))));
   static constexpr int NN = N1 * N1, Nq = NN * N1, Nfq = 6 * NN, LLD = E * NN;
   // LDS slot of node i0 + N1 i1 + N1^2 i2: i0 + P (i1 + N1 i2) with an odd pitch P, so that the lanes of every direction --
   // consecutive lines -- read their i-th nodes from distinct banks (measured at N1 = 4 without the padding: 60 % of the LDS

@@ -70,20 +70,20 @@ __device__ __forceinline__ int64_t xcd_group3(int64_t b, int64_t n) {
 #define ESDG_T3_LAZY_LOGS 1   // (A/B hook: 0 = the logarithms of every node and trace state, always)
 #endif
 // waves per SIMD asked of the register allocator: three up to N1 = 6 (168 VGPRs: the N1 + 2 accumulators of a line take 8 (N1 + 2)
-// of them), two at N1 = 7, one at N1 = 8 (ESDG_T3_WPE overrides, A/B hook)
+// of them), two at N1 = 7 and for the CNS wall instantiation from N1 = 5 (its correction planes and penalty shares), one at
+// N1 = 8 (ESDG_T3_WPE overrides, A/B hook)
 #ifdef ESDG_T3_WPE
-template <int N1> struct Wpe3 { static constexpr int W = ESDG_T3_WPE; };
+constexpr int wpe3(int, bool) { return ESDG_T3_WPE; }
 #else
-template <int N1> struct Wpe3 { static constexpr int W = N1 <= 6 ? 3 : (N1 == 7 ? 2 : 1); };
+constexpr int wpe3(int N1, bool walls_cns) { return N1 <= 4 ? 3 : (N1 <= 6 ? (walls_cns ? 2 : 3) : (N1 == 7 ? 2 : 1)); }
 #endif
-
 #ifdef ESDG_T3_NUM_VGPR
 #define T3_VGPR_ATTR __attribute__((amdgpu_num_vgpr(ESDG_T3_NUM_VGPR)))
 #else
 #define T3_VGPR_ATTR
 #endif
 template <int N1, bool MODAL, bool VISC, bool WALLS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Wpe3<N1>::W))) T3_VGPR_ATTR void kt3_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WALLS && VISC && MODAL)))) T3_VGPR_ATTR void kt3_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                           const double* __restrict__ A_U, const double* __restrict__ SG,
                                                           const double* __restrict__ B, double* __restrict__ rhs, LsrkFuse lf) {
   using G = G3<N1>;
