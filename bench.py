@@ -448,6 +448,31 @@ def run(args):
         rough_ms = (time.perf_counter() - t0) / args.steps * 1e3
         del Qr
         eng.rhs_into(Qd, out)
+    # One low-storage RK stage (dg2D_euler_quad.jl:204-205: resQ = a resQ + dt rhsQ; Q += b resQ) on one GPU: as the library's
+    # fused stage (esdg_rhs_lsrk: the state update inside the last phase, no rhs array) and as the evaluation followed by the
+    # update kernel (esdg_rhs + esdg_lsrk_update) -- what a time loop pays per stage either way.  dt = 0 keeps the state fixed.
+    lsrk_stage_ms = lsrk_stage_unfused_ms = None
+    if world == 1:
+        Qw, res = Qd.clone(), eng.new_state()
+        res.zero_()
+
+        def _time(fn, n=20):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        lsrk_stage_ms = _time(lambda: eng.rhs_lsrk_fused(Qw, res, -0.4178904745, 0.1496590219993, 0.0))
+
+        def _unfused():
+            eng.rhs_into(Qw, out)
+            eng.lsrk_update(Qw, res, out, -0.4178904745, 0.1496590219993, 0.0)
+        lsrk_stage_unfused_ms = _time(_unfused)
+        del Qw, res
+        eng.rhs_into(Qd, out)
     alg_bytes = 16.0 * nfld * Np * K_local       # read state once + write rhs once
     achieved = alg_bytes / (kdur_ms * 1e-3) / 1e9
 
@@ -583,6 +608,7 @@ def run(args):
                                          ("per-node 10-bit differences (2)" if args.hex_geometry == "per-node" else "element record (0)")))},
         "rhs_evals_per_s": evals_per_s, "elements_per_s": K_total * evals_per_s,
         "ms_per_step_rough_state": rough_ms,
+        "lsrk_stage_ms": lsrk_stage_ms, "lsrk_stage_unfused_ms": lsrk_stage_unfused_ms,
         "ms_per_step_median": per[len(per) // 2], "ms_per_step_min": per[0], "ms_per_step_reps": [r / args.steps * 1e3 for r in reps],
         "roofline": roofline,
     }
