@@ -451,7 +451,7 @@ def run(args):
     # One low-storage RK stage (dg2D_euler_quad.jl:204-205: resQ = a resQ + dt rhsQ; Q += b resQ) on one GPU: as the library's
     # fused stage (esdg_rhs_lsrk: the state update inside the last phase, no rhs array) and as the evaluation followed by the
     # update kernel (esdg_rhs + esdg_lsrk_update) -- what a time loop pays per stage either way.  dt = 0 keeps the state fixed.
-    lsrk_stage_ms = lsrk_stage_unfused_ms = None
+    lsrk_stage_ms = lsrk_stage_unfused_ms = lsrk45_step_stage_ms = None
     if world == 1:
         Qw, res = Qd.clone(), eng.new_state()
         res.zero_()
@@ -471,6 +471,13 @@ def run(args):
             eng.rhs_into(Qw, out)
             eng.lsrk_update(Qw, res, out, -0.4178904745, 0.1496590219993, 0.0)
         lsrk_stage_unfused_ms = _time(_unfused)
+        # ... and per stage of the library's whole five-stage step (esdg_lsrk45_step), whose stages 1 ... 4 start at phase 1: the
+        # last phase of the stage before has emitted their trace records when ESDG_STAGE_FUSION=1 (cross-stage fusion, 2D unsharded;
+        # measured slower, off by default: the key then equals lsrk_stage_ms)
+        import ctypes as C2
+        if not hexw:
+            qp, rp = C2.c_void_p(Qw.data_ptr()), C2.c_void_p(res.data_ptr())
+            lsrk45_step_stage_ms = _time(lambda: engine.check(eng.L.esdg_lsrk45_step(eng.ctx, qp, rp, 0.0, eng._stream())), n=8) / 5.0
         del Qw, res
         eng.rhs_into(Qd, out)
     alg_bytes = 16.0 * nfld * Np * K_local       # read state once + write rhs once
@@ -608,7 +615,7 @@ def run(args):
                                          ("per-node 10-bit differences (2)" if args.hex_geometry == "per-node" else "element record (0)")))},
         "rhs_evals_per_s": evals_per_s, "elements_per_s": K_total * evals_per_s,
         "ms_per_step_rough_state": rough_ms,
-        "lsrk_stage_ms": lsrk_stage_ms, "lsrk_stage_unfused_ms": lsrk_stage_unfused_ms,
+        "lsrk_stage_ms": lsrk_stage_ms, "lsrk_stage_unfused_ms": lsrk_stage_unfused_ms, "lsrk45_step_stage_ms": lsrk45_step_stage_ms,
         "ms_per_step_median": per[len(per) // 2], "ms_per_step_min": per[0], "ms_per_step_reps": [r / args.steps * 1e3 for r in reps],
         "roofline": roofline,
     }

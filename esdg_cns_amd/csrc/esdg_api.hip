@@ -585,6 +585,12 @@ struct esdg_ctx {
   size_t ws_bytes = 0;
   char* ws = nullptr;
   size_t off_AU = 0, off_Av = 0, off_B = 0, off_S = 0;
+  // cross-stage fusion of esdg_lsrk45_step (LsrkFuse::AUn): a second A_U buffer (unsharded 2D tensor contexts; 0 = none), which
+  // of the two the phases read right now, and whether the last phase of the call in flight emits the next stage's traces into the other
+  size_t off_AU2 = 0;
+  int au_sel = 0;
+  bool emit_next = false;
+  bool stage_fusion = false;   // ESDG_STAGE_FUSION=1 at esdg_create (measured in round 4: 15 % slower per stage; off by default)
   int64_t int_lo = 0, int_hi = 0;   // longest run of elements [int_lo, int_hi) that touch no ghost slot
   // nested interiors: nest_lo/hi[0] = [int_lo, int_hi); nest[p] = the longest run inside nest[p-1] all of whose face
   // neighbours lie in nest[p-1] -- what phase p can compute from data the same stream produced in phase p-1
@@ -1069,6 +1075,8 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   size_t off = 0;
   // A_U: generic kernels one array of 5-double records; tensor kernels one array of 4-double records (rho, u, v, beta)
   c->off_AU = off; off = align(off + nodes * (use_fast ? FAU_NC : AU_NC) * sizeof(double));
+  if (const char* env = getenv("ESDG_STAGE_FUSION")) c->stage_fusion = env[0] == '1';
+  if (use_fast && c->nghost == 0 && c->stage_fusion) { c->off_AU2 = off; off = align(off + nodes * FAU_NC * sizeof(double)); }   // (esdg_lsrk45_step)
   c->M.trace_nodes = (int64_t)nodes;
   const bool need_Av = visc && !use_fast;   // the tensor kernels rebuild the neighbour's (v2,v3,v4) from its A_U record
   if (visc) {
@@ -1339,7 +1347,7 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
   if (!ctx->ws) return fail(ESDG_ERR_STATE, "workspace not bound (esdg_bind_workspace)");
   if (phase < 0 || phase >= ctx->nphases) return fail(ESDG_ERR_ARG, "bad phase %d", phase);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  double* A_U = reinterpret_cast<double*>(ctx->ws + ctx->off_AU);
+  double* A_U = reinterpret_cast<double*>(ctx->ws + (ctx->au_sel ? ctx->off_AU2 : ctx->off_AU));
   const bool visc = ctx->nphases == 3;
   const bool need_Av = visc && !ctx->use_fast;
   double* A_v = need_Av ? reinterpret_cast<double*>(ctx->ws + ctx->off_Av) : nullptr;
@@ -1380,8 +1388,13 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
     // the viscous phase must be the v2 one there; ESDG_V2=rhs: the v2 kernel (A/B)
     // (ESDG_DBG bit 32: kt3_rhs takes every logarithm whatever the state -- the partner of the bitwise test of its data-dependent
     // short cut, tests/test_gpu_engine.py)
-    if (ctx->use_fast && !(ctx->ph.dbg & ~32) && !(ctx->v1 & 2) && !(ctx->v2 & 2) && (!ctx->M.bc || v2_on_walls(ctx)))
-      rc = launch_rhs_tensor3(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s);
+    if (ctx->use_fast && !(ctx->ph.dbg & ~32) && !(ctx->v1 & 2) && !(ctx->v2 & 2) && (!ctx->M.bc || v2_on_walls(ctx))) {
+      LsrkFuse lfe = lf;
+      if (ctx->emit_next && lf.Qw && !ranged)   // (esdg_lsrk45_step: the next stage's traces into the buffer not being read)
+        lfe.AUn = reinterpret_cast<double*>(ctx->ws + (ctx->au_sel ? ctx->off_AU : ctx->off_AU2));
+      rc = launch_rhs_tensor3(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lfe, s);
+      if (rc == -1 && lfe.AUn) return fail(ESDG_ERR_STATE, "stage fusion asked of a context the v3 last-phase kernel does not serve");
+    }
     if (rc == -1 && ctx->use_fast && !(ctx->ph.dbg & ~32) && (ctx->M.bc ? v2_on_walls(ctx) : !(ctx->v1 & 2)))      // v2 kernel: N1 = N + 1 = 2 ... 8
       rc = launch_rhs_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s);
     if (rc == -1)
@@ -2023,9 +2036,31 @@ int esdg_lsrk45_step(esdg_ctx* ctx, double* Q, double* resQ, double dt, void* st
                                  2277821191437.0 / 14882151754819.0};
   if (!ctx || !Q || !resQ) return fail(ESDG_ERR_ARG, "null argument");
   if (!ctx->use_fast) return fail(ESDG_ERR_STATE, "esdg_lsrk45_step needs the tensor / hex kernels (fused stage)");
+  // Cross-stage fusion (opt-in: ESDG_STAGE_FUSION=1 at esdg_create): on an unsharded 2D context whose last
+  // phase is kt3_rhs, stage k's last phase -- which holds the updated state in registers -- also writes the trace records phase 0
+  // of stage k + 1 would compute from it, into the second A_U buffer (the first is still being read by the neighbours'
+  // workgroups); stages 1 ... 4 then start at phase 1.  Bitwise the unfused step (tests/test_gpu_drivers.py).  Measured in
+  // round 4 at cfg3: 0.729-0.738 ms per stage against 0.635-0.637 without it (Euler cfg2: 0.092-0.094 vs 0.090-0.096) -- kt3_rhs
+  // is bound by vector-instruction issue, and phase 0's arithmetic costs more inside it (node rounds at 78 % lane use, two more
+  // LDS exchanges per one-shot wave, 28 spilled registers) than the memory-bound kt2_project launch it saves.  Hence off.
+  const bool fuse = ctx->stage_fusion && ctx->dim == 2 && ctx->nghost == 0 && ctx->off_AU2 && !ctx->bf && !(ctx->ph.dbg & ~32) && !(ctx->v1) &&
+                    !(ctx->v2 & 2) && ctx->T.N1 >= 2 && ctx->T.N1 <= 8 && (!ctx->M.bc || (v2_on_walls(ctx) && ctx->T.N1 < 8));
+  if (!fuse) {
+    for (int k = 0; k < 5; ++k) {
+      int rc = esdg_rhs_lsrk(ctx, Q, resQ, rk4a[k], rk4b[k], dt, stream);
+      if (rc) return rc;
+    }
+    return ESDG_OK;
+  }
+  struct FuseGuard { esdg_ctx* c; ~FuseGuard() { c->au_sel = 0; c->emit_next = false; } } fg{ctx};
+  ctx->au_sel = 0;
   for (int k = 0; k < 5; ++k) {
-    int rc = esdg_rhs_lsrk(ctx, Q, resQ, rk4a[k], rk4b[k], dt, stream);
-    if (rc) return rc;
+    ctx->emit_next = k < 4;
+    for (int p = (k == 0 ? 0 : 1); p < ctx->nphases; ++p) {
+      int rc = esdg_rhs_phase_lsrk(ctx, p, Q, resQ, rk4a[k], rk4b[k], dt, stream);
+      if (rc) return rc;
+    }
+    if (k < 4) ctx->au_sel ^= 1;   // the traces just emitted are what the next stage reads
   }
   return ESDG_OK;
 }

@@ -153,6 +153,10 @@ struct LsrkFuse {
   double* Qw;   // the state, updated in place (null = plain rhs store)
   double* res;
   double a, b, dt;
+  // Cross-stage fusion (round 4, esdg_lsrk45_step on unsharded 2D contexts): non-null = the last phase also emits the NEXT stage's
+  // phase 0 from the state it has just updated -- the (rho, u, v, beta) trace records of its elements into this second trace buffer
+  // (the current one is still being read by the neighbours' workgroups) -- so the next stage starts at phase 1.  kt3_rhs only.
+  double* AUn;
 };
 
 struct Phys {

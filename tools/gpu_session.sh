@@ -14,7 +14,7 @@
 #   ubench name                  build + run tools/ubench/<name>.hip (log in gpurun_out/ubench_<name>.log)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-grepms() { grep -o '"ms_per_step": [0-9.]*\|"phase_ms": \[[^]]*\]\|"kernel_ms": [0-9.]*' | tr '\n' ' '; }
+grepms() { grep -o '"ms_per_step": [0-9.]*\|"phase_ms": \[[^]]*\]\|"kernel_ms": [0-9.]*\|"lsrk[a-z0-9_]*": [0-9.]*' | tr '\n' ' '; }
 run_step() {
   local step=$1; shift
   case $step in
