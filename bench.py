@@ -231,8 +231,9 @@ def parse_args(argv=None):
     ap.add_argument("--formulation", choices=["cns", "euler", "hex"], default="cns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rough-state", action="store_true",
-                    help="skip the extra timing on the state without smooth regions (ms_per_step_rough_state); the rocprofv3 passes "
-                         "use it so that their per-kernel averages cover the headline state only")
+                    help="skip the extra timings -- the state without smooth regions (ms_per_step_rough_state) and the RK stages "
+                         "(lsrk_*): the rocprofv3 passes use it so that their per-kernel averages and counters cover the headline "
+                         "evaluation only")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the process group (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank logic on fewer GPUs: traces are then staged through the host)")
     ap.add_argument("--transport", choices=["rccl", "torch"], default=None,
@@ -452,7 +453,7 @@ def run(args):
     # fused stage (esdg_rhs_lsrk: the state update inside the last phase, no rhs array) and as the evaluation followed by the
     # update kernel (esdg_rhs + esdg_lsrk_update) -- what a time loop pays per stage either way.  dt = 0 keeps the state fixed.
     lsrk_stage_ms = lsrk_stage_unfused_ms = lsrk45_step_stage_ms = None
-    if world == 1:
+    if world == 1 and not args.no_rough_state:
         Qw, res = Qd.clone(), eng.new_state()
         res.zero_()
 
