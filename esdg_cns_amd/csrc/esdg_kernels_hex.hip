@@ -966,7 +966,7 @@ __global__ void kh_rhstest(int64_t n, const double* __restrict__ wJq, const doub
 
 
 // =====================================================================================================================
-// Degrees N >= 4, line per lane (round 4; affine meshes: geometry modes 0 and 2; curved meshes stay with kh_rhs_g).
+// Line per lane (round 4; every degree, all three geometry modes).
 // kh_rhs_g above is row-wise like the reference: twice the fluxes of a pair-once schedule.  Here, as in kt3_rhs
 // (esdg_kernels_tensor3.hip), a lane owns ONE LINE of an element -- its N1 Gauss nodes and the two face nodes at its ends --
 // and evaluates each of the line's pairs once (C(N1,2) volume-volume, 2 N1 volume-face, 2 interface fluxes) with the
@@ -1015,8 +1015,7 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
   using C = LCfg<N1>;
   constexpr HexLayout L(N1);
   constexpr int E = C::E, NN = C::NN, Nq = C::Nq, Nfq = C::Nfq, T = C::T, NV = C::NV, NVN = C::NVN, NQP = C::NQP, LLD = C::LLD, NRN = C::NRN;
-  constexpr bool DELTA = GM == 2;
-  static_assert(GM == 0 || GM == 2, "affine meshes only");
+  constexpr bool DELTA = GM == 2, CURVED = GM == 1;   // (geometry modes: see kh_rhs)
   constexpr int ND = (L.NDBL + T - 1) / T, NI = (L.NINT + T - 1) / T, NG = (E * HEX_GEO_STRIDE + T - 1) / T;
   typedef double2 d2;
   __shared__ __align__(16) double sTab[ND * T];
@@ -1077,6 +1076,21 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
   }
   unsigned kfA = 0u, knA = 0u, kfB = 0u, knB = 0u;
   if (DELTA) { kfA = M.hdf[nmA]; knA = M.hdn[nmA]; kfB = M.hdf[nmB]; knB = M.hdn[nmB]; }
+  // curved meshes: the metric row of this line's operator at its N1 nodes and two face nodes (x, y, z components), the face nodes'
+  // own normals and sJ.  A node's row of operator op(d) is read by its direction-d line only, so nothing is shared between lanes.
+  constexpr int Nh = Nq + Nfq;
+  double Gl[CURVED ? N1 : 1][3], gfA[3] = {0, 0, 0}, gfB[3] = {0, 0, 0}, nA[4] = {0, 0, 0, 0}, nB[4] = {0, 0, 0, 0};
+  if (CURVED) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double* row = M.G9 + (ec * 9 + c * 3 + opd) * Nh;
+#pragma unroll
+      for (int i = 0; i < N1; ++i) Gl[i][c] = row[base + i * stride];
+      gfA[c] = row[Nq + fA]; gfB[c] = row[Nq + fB];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { nA[c] = M.nrm[ec * 4 * Nfq + c * Nfq + fA]; nB[c] = M.nrm[ec * 4 * Nfq + c * Nfq + fB]; }
+  }
 
   // ---- staging; node rounds: primitives + logs -> records ---------------------------------------------------------------
 #pragma unroll
@@ -1116,7 +1130,7 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
     q[0] = p0.x; q[1] = p0.y; q[2] = p1.x; q[3] = p1.y; q[4] = p2.x; q[5] = p2.y; q[6] = p3.x;
   };
   // one face turn: surface flux of face node f (end t of the line), then its N1 volume-face pairs
-  auto face_turn = [&](int t, int f, const double* rm, const double* rp, unsigned kf, unsigned kn, double* G) {
+  auto face_turn = [&](int t, int f, const double* rm, const double* rp, unsigned kf, unsigned kn, const double* gfc, const double* nc, double* G) {
     double qm[7], qp[7];
 #pragma unroll
     for (int c = 0; c < HEX_AU_NC; ++c) { qm[c] = rm[c]; qp[c] = rp[c]; }
@@ -1124,7 +1138,8 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
     qp[5] = log_pos(qp[0]); qp[6] = log_pos(qp[4]);
     const int face = f / NN;
     double nx = geo[10 + 4 * face], ny = geo[11 + 4 * face], nz = geo[12 + 4 * face];
-    const double sJ = geo[13 + 4 * face];
+    double sJ = geo[13 + 4 * face];
+    if (CURVED) { nx = nc[0]; ny = nc[1]; nz = nc[2]; sJ = nc[3]; }
     if (DELTA) {   // this node's own normal = face mean + scale * packed difference
       int a0, a1, a2;
       unpack3(kn, a0, a1, a2);
@@ -1152,7 +1167,11 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
       KHL_FENCE();
       double qn[7], F[HEX_NFLD];
       record(slot, qn);
-      if (DELTA) {
+      double W = sTab[L.SF + (d * 2 + t) * N1 + i] * wtf;
+      if (CURVED) {   // metric of the pair = average of the two nodes (dg3D_euler_hex.jl:145-151; the .5 goes into the weight)
+        W *= .5;
+        ec_flux_dir(qn, qm, gfc[0] + Gl[i][0], gfc[1] + Gl[i][1], gfc[2] + Gl[i][2], F);
+      } else if (DELTA) {
         int b0, b1, b2;
         unpack3(sD[opd * NV + slot], b0, b1, b2);
         ec_flux_dir(qn, qm, __builtin_fma(hsG, (double)(f0 + b0), gx), __builtin_fma(hsG, (double)(f1 + b1), gy),
@@ -1160,14 +1179,13 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
       } else {
         ec_flux_dir(qn, qm, gx, gy, gz, F);
       }
-      const double W = sTab[L.SF + (d * 2 + t) * N1 + i] * wtf;
 #pragma unroll
       for (int c = 0; c < HEX_NFLD; ++c) { acc[i][c] = __builtin_fma(W, F[c], acc[i][c]); G[c] = __builtin_fma(-W, F[c], G[c]); }
       KHL_PIN5(acc[i]); KHL_PIN5(G);
     }
   };
-  face_turn(0, fA, rmA, rpA, kfA, knA, GA);
-  face_turn(1, fB, rmB, rpB, kfB, knB, GB);
+  face_turn(0, fA, rmA, rpA, kfA, knA, gfA, nA, GA);
+  face_turn(1, fB, rmB, rpB, kfB, knB, gfB, nB, GB);
   {   // volume-volume pairs of the line, each once
     const double wt = sTab[L.WT + d * NN + o];
 #pragma unroll
@@ -1184,7 +1202,11 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
         KHL_FENCE();
         double qj[7], F[HEX_NFLD];
         record(sj, qj);
-        if (DELTA) {   // metric of the pair = average of the two nodes: record + half the scale times the two differences
+        double W = sTab[L.S + (d * N1 + i) * N1 + j] * wt;
+        if (CURVED) {
+          W *= .5;
+          ec_flux_dir(qi, qj, Gl[i][0] + Gl[j][0], Gl[i][1] + Gl[j][1], Gl[i][2] + Gl[j][2], F);
+        } else if (DELTA) {   // metric of the pair = average of the two nodes: record + half the scale times the two differences
           int b0, b1, b2;
           unpack3(sD[opd * NV + sj], b0, b1, b2);
           ec_flux_dir(qi, qj, __builtin_fma(hsG, (double)(a0 + b0), gx), __builtin_fma(hsG, (double)(a1 + b1), gy),
@@ -1192,7 +1214,6 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
         } else {
           ec_flux_dir(qi, qj, gx, gy, gz, F);
         }
-        const double W = sTab[L.S + (d * N1 + i) * N1 + j] * wt;
 #pragma unroll
         for (int c = 0; c < HEX_NFLD; ++c) { acc[i][c] = __builtin_fma(W, F[c], acc[i][c]); acc[j][c] = __builtin_fma(-W, F[c], acc[j][c]); }
         KHL_PIN5(acc[i]); KHL_PIN5(acc[j]);
@@ -1229,18 +1250,21 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
     const int n = tid + r * T;
     if (n < nE * Nq) {
       const int en = n / Nq, q = n - en * Nq, sl = en * NQP + q + (C::P != N1 ? q / N1 : 0);
-      const double miJ = -rcp_refined(sGeo[en * HEX_GEO_STRIDE + 9]);
+      const double miJ = -rcp_refined(CURVED ? M.Jq[e0 * Nq + n] : sGeo[en * HEX_GEO_STRIDE + 9]);
+      if (lf.Qw) {   // (uniform) fused low-storage RK stage, same rounding sequence as k_lsrk; res and Qw are distinct arrays: all
+        double ro[HEX_NFLD], qo[HEX_NFLD];   // loads first, then the stores (one round trip instead of ten)
 #pragma unroll
-      for (int c = 0; c < HEX_NFLD; ++c) {
-        const int64_t idx = (int64_t)c * KN + e0 * Nq + n;
-        const double out = sR[c * NV + sl] * miJ;
-        if (lf.Qw) {   // (uniform) same rounding sequence as k_lsrk
-          const double rr = __builtin_fma(lf.a, lf.res[idx], lf.dt * out);
+        for (int c = 0; c < HEX_NFLD; ++c) { const int64_t idx = (int64_t)c * KN + e0 * Nq + n; ro[c] = lf.res[idx]; qo[c] = lf.Qw[idx]; }
+#pragma unroll
+        for (int c = 0; c < HEX_NFLD; ++c) {
+          const int64_t idx = (int64_t)c * KN + e0 * Nq + n;
+          const double rr = __builtin_fma(lf.a, ro[c], lf.dt * (sR[c * NV + sl] * miJ));
           lf.res[idx] = rr;
-          lf.Qw[idx] = __builtin_fma(lf.b, rr, lf.Qw[idx]);
-        } else {
-          rhs[idx] = out;
+          lf.Qw[idx] = __builtin_fma(lf.b, rr, qo[c]);
         }
+      } else {
+#pragma unroll
+        for (int c = 0; c < HEX_NFLD; ++c) rhs[(int64_t)c * KN + e0 * Nq + n] = sR[c * NV + sl] * miJ;
       }
     }
   }
@@ -1289,17 +1313,18 @@ int launch_rhs_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phys& p
                    double* rhs, const LsrkFuse& lf, hipStream_t s) {
   if (M.e_count <= 0) return 0;
   const int remap = (ph.dbg & 16) ? 0 : 1;
-  // Affine meshes (geometry modes 0 and 2): the line-per-lane kernel kh_rhs_l at every degree (round 4: N = 3 128x128x16 1.03 vs
+  // The line-per-lane kernel kh_rhs_l at every degree and in every geometry mode (round 4: N = 3 128x128x16 1.03 vs
   // 1.23 ms for kh_rhs; N = 1, 2: 0.65, 0.83 x kh_rhs; N = 4 ... 7: 0.47 ... 0.74 x the row-wise kh_rhs_g);
-  // ESDG_HEX_LINE=0: kh_rhs / kh_rhs_g (A/B).  Curved meshes stay with kh_rhs / kh_rhs_g.
-  if (!M.G9) {
+  // ESDG_HEX_LINE=0: kh_rhs / kh_rhs_g (A/B).
+  {
     static int line = -2;
     if (line == -2) { const char* env = getenv("ESDG_HEX_LINE"); line = !env ? -1 : (env[0] == '1' ? 1 : 0); }
     if (line != 0) {
 #define ESDG_HEXL_LAUNCH(N1c)                                                                                                 \
   case N1c: {                                                                                                                \
     const dim3 grid((unsigned)((M.e_count + hdev::LCfg<N1c>::E - 1) / hdev::LCfg<N1c>::E)), blk(hdev::LCfg<N1c>::T);         \
-    if (M.hdv) hipLaunchKernelGGL((hdev::kh_rhs_l<N1c, 2>), grid, blk, 0, s, HT, M, ph, Q, A_U, rhs, lf);                   \
+    if (M.G9) hipLaunchKernelGGL((hdev::kh_rhs_l<N1c, 1>), grid, blk, 0, s, HT, M, ph, Q, A_U, rhs, lf);                    \
+    else if (M.hdv) hipLaunchKernelGGL((hdev::kh_rhs_l<N1c, 2>), grid, blk, 0, s, HT, M, ph, Q, A_U, rhs, lf);              \
     else hipLaunchKernelGGL((hdev::kh_rhs_l<N1c, 0>), grid, blk, 0, s, HT, M, ph, Q, A_U, rhs, lf);                          \
   } break;
       switch (N1v) {

@@ -77,13 +77,8 @@ constexpr int wpe3(int, bool) { return ESDG_T3_WPE; }
 #else
 constexpr int wpe3(int N1, bool walls_cns) { return N1 <= 4 ? 3 : (N1 <= 6 ? (walls_cns ? 2 : 3) : (N1 == 7 ? 2 : 1)); }
 #endif
-#ifdef ESDG_T3_NUM_VGPR
-#define T3_VGPR_ATTR __attribute__((amdgpu_num_vgpr(ESDG_T3_NUM_VGPR)))
-#else
-#define T3_VGPR_ATTR
-#endif
 template <int N1, bool MODAL, bool VISC, bool WALLS, bool EMIT = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WALLS && VISC && MODAL)))) T3_VGPR_ATTR void kt3_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WALLS && VISC && MODAL)))) void kt3_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                           const double* __restrict__ A_U, const double* __restrict__ SG,
                                                           const double* __restrict__ B, double* __restrict__ rhs, LsrkFuse lf) {
   using G = G3<N1>;
