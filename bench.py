@@ -481,6 +481,28 @@ def run(args):
             lsrk45_step_stage_ms = _time(lambda: engine.check(eng.L.esdg_lsrk45_step(eng.ctx, qp, rp, 0.0, eng._stream())), n=8) / 5.0
         del Qw, res
         eng.rhs_into(Qd, out)
+    # One attempted DOPRI45 step of the CNS drivers' time loop (dg2D_CNS_cavity_optimized.jl:999-1037; six right-hand sides, the
+    # stage combinations, the error norm) through esdg_dopri45_attempt -- on CNS contexts with the combinations and the norm
+    # inside the last phase of each stage (StageFuse) -- and from the library's building blocks (esdg_axpy_stages, esdg_rhs,
+    # esdg_dopri_error: 43 state-sized sweeps beside the six evaluations).  Includes the accept copy and the host's read of the estimate.
+    dopri45_attempt_ms = dopri45_attempt_pieces_ms = None
+    if world == 1 and args.formulation == "cns" and not hexw and not args.no_rough_state:
+        from esdg_cns_amd import timestep
+        for pieces in (False, True):
+            Qw = Qd.clone()
+            dp = timestep.Dopri45(eng, Qw, 1e-5, err_tol=1e-5, pieces=pieces)
+            for _ in range(3):
+                dp.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                dp.step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 10 * 1e3
+            if pieces: dopri45_attempt_pieces_ms = ms
+            else: dopri45_attempt_ms = ms
+            del dp, Qw
+        eng.rhs_into(Qd, out)
     alg_bytes = 16.0 * nfld * Np * K_local       # read state once + write rhs once
     achieved = alg_bytes / (kdur_ms * 1e-3) / 1e9
 
@@ -617,6 +639,7 @@ def run(args):
         "rhs_evals_per_s": evals_per_s, "elements_per_s": K_total * evals_per_s,
         "ms_per_step_rough_state": rough_ms,
         "lsrk_stage_ms": lsrk_stage_ms, "lsrk_stage_unfused_ms": lsrk_stage_unfused_ms, "lsrk45_step_stage_ms": lsrk45_step_stage_ms,
+        "dopri45_attempt_ms": dopri45_attempt_ms, "dopri45_attempt_pieces_ms": dopri45_attempt_pieces_ms,
         "ms_per_step_median": per[len(per) // 2], "ms_per_step_min": per[0], "ms_per_step_reps": [r / args.steps * 1e3 for r in reps],
         "roofline": roofline,
     }

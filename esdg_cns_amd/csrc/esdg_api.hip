@@ -590,6 +590,10 @@ struct esdg_ctx {
   size_t off_AU2 = 0;
   int au_sel = 0;
   bool emit_next = false;
+  int64_t stage_cursor = 0;                // partials handed out so far in the current stage
+  const StageFuse* stage_fuse = nullptr;   // set by esdg_dopri45_attempt around a last-phase launch (kt3_rhs's STG instantiation)
+  bool dopri_fusion = true;    // ESDG_DOPRI_FUSION=0 at esdg_create: the unfused attempt (A/B partner, and the bitwise test's)
+  DevBuf d_stage_partial;      // one double per kt3_rhs workgroup (error norm of the fused attempt), allocated at the first attempt
   bool stage_fusion = false;   // ESDG_STAGE_FUSION=1 at esdg_create (measured in round 4: 15 % slower per stage; off by default)
   int64_t int_lo = 0, int_hi = 0;   // longest run of elements [int_lo, int_hi) that touch no ghost slot
   // nested interiors: nest_lo/hi[0] = [int_lo, int_hi); nest[p] = the longest run inside nest[p-1] all of whose face
@@ -1076,6 +1080,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   // A_U: generic kernels one array of 5-double records; tensor kernels one array of 4-double records (rho, u, v, beta)
   c->off_AU = off; off = align(off + nodes * (use_fast ? FAU_NC : AU_NC) * sizeof(double));
   if (const char* env = getenv("ESDG_STAGE_FUSION")) c->stage_fusion = env[0] == '1';
+  if (const char* env = getenv("ESDG_DOPRI_FUSION")) c->dopri_fusion = env[0] != '0';
   if (use_fast && c->nghost == 0 && c->stage_fusion) { c->off_AU2 = off; off = align(off + nodes * FAU_NC * sizeof(double)); }   // (esdg_lsrk45_step)
   c->M.trace_nodes = (int64_t)nodes;
   const bool need_Av = visc && !use_fast;   // the tensor kernels rebuild the neighbour's (v2,v3,v4) from its A_U record
@@ -1392,9 +1397,19 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
       LsrkFuse lfe = lf;
       if (ctx->emit_next && lf.Qw && !ranged)   // (esdg_lsrk45_step: the next stage's traces into the buffer not being read)
         lfe.AUn = reinterpret_cast<double*>(ctx->ws + (ctx->au_sel ? ctx->off_AU : ctx->off_AU2));
-      rc = launch_rhs_tensor3(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lfe, s);
+      StageFuse sfl;
+      const StageFuse* sfp = ctx->stage_fuse;
+      if (sfp && sfp->err) {   // every launch of the stage (the pieces of a sharded schedule) gets its own run of partials
+        sfl = *sfp;
+        sfl.partial += ctx->stage_cursor;
+        ctx->stage_cursor += rhs_tensor3_blocks(ctx->T.N1, ranged ? e_count : ctx->K);
+        sfp = &sfl;
+      }
+      rc = launch_rhs_tensor3(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lfe, s, sfp);
+      if (rc == -1 && ctx->stage_fuse) return fail(ESDG_ERR_STATE, "DOPRI45 stage fusion asked of a context the v3 last-phase kernel does not serve");
       if (rc == -1 && lfe.AUn) return fail(ESDG_ERR_STATE, "stage fusion asked of a context the v3 last-phase kernel does not serve");
     }
+    if (rc == -1 && ctx->stage_fuse) return fail(ESDG_ERR_STATE, "DOPRI45 stage fusion asked of a context the v3 last-phase kernel does not serve");
     if (rc == -1 && ctx->use_fast && !(ctx->ph.dbg & ~32) && (ctx->M.bc ? v2_on_walls(ctx) : !(ctx->v1 & 2)))      // v2 kernel: N1 = N + 1 = 2 ... 8
       rc = launch_rhs_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s);
     if (rc == -1)
@@ -2026,6 +2041,19 @@ int esdg_dopri_error(const double* Q, const double* const* k, const double* coef
   return ESDG_OK;
 }
 
+// sum of n doubles on the device (one block, fixed order), result on the host
+static int esdg_sum_device(const double* x, int64_t n, double* result, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  double* out = nullptr;
+  HIP_TRY(hipMalloc(&out, sizeof(double)));
+  int rc = launch_sum(x, n, out, s);
+  hipError_t e = hipMemcpyAsync(result, out, sizeof(double), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(out);
+  if (rc || e != hipSuccess) return fail(ESDG_ERR_NO_DEVICE, "device sum failed");
+  return ESDG_OK;
+}
+
 // ---- whole-step entry points (unsharded meshes; sharded hosts drive the phases themselves) ------------------------
 int esdg_lsrk45_step(esdg_ctx* ctx, double* Q, double* resQ, double dt, void* stream) {
   // rk45_coeffs, src/CommonUtils.jl:29-49; loop dg2D_euler_quad.jl:200-206
@@ -2081,6 +2109,54 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
     return fail(ESDG_ERR_STATE, "esdg_dopri45_attempt on a sharded mesh needs the library's communicator (esdg_comm_init): the "
                                 "error norm is a sum over all ranks");
   const int64_t n = (int64_t)ctx->nfld * ctx->K * ctx->Np;
+  // Fused attempt (round 4; CNS contexts whose last phase is kt3_rhs, sharded ones included; ESDG_DOPRI_FUSION=0: off): the last phase of stage
+  // s holds k_s in registers and also writes the NEXT stage's state Q + dt sum_j a_{s+1,j} k_j, so the separate combination pass
+  // (read Q, k_0 ... k_s, write Qtmp) shrinks to the reads of Q, k_0 ... k_{s-1} inside the launch; stage 6 (the b row) also leaves
+  // the error combination of k_0 ... k_5 in k[6]'s array, which stage 7's launch reads back, completes with k_6 and reduces to
+  // one partial per workgroup.  Stages with a zero coefficient in both rows are not read.  Per node the same fma chains as the
+  // unfused attempt (same bits: tests/test_gpu_drivers.py); 30 instead of 43 state-sized sweeps per attempt on top of six
+  // right-hand sides.
+  const bool fuse = ctx->dopri_fusion && ctx->dim == 2 && ctx->use_fast && ctx->nphases == 3 && ctx->ph.formulation == 1 &&
+                    !ctx->bf && !(ctx->ph.dbg & ~32) && !(ctx->v1 & 2) && !(ctx->v2 & 2) && ctx->T.N1 >= 2 && ctx->T.N1 <= 8 &&
+                    (!ctx->M.bc || (v2_on_walls(ctx) && ctx->T.N1 < 8));
+  if (fuse) {
+    if (!ctx->d_stage_partial.p) {   // (a sharded schedule launches the last phase in up to three pieces, each rounding up)
+      int rc = ctx->d_stage_partial.alloc(sizeof(double) * (size_t)(rhs_tensor3_blocks(ctx->T.N1, ctx->K) + 8));
+      if (rc) return rc;
+    }
+    const LsrkFuse none{nullptr, nullptr, 0.0, 0.0, 0.0};
+    struct Guard { esdg_ctx* c; ~Guard() { c->stage_fuse = nullptr; } } g{ctx};
+    int rc = esdg_axpy_stages(Qtmp, Q, k, A[1], 1, dt, n, stream);
+    for (int s = 1; s < 7 && !rc; ++s) {
+      StageFuse sf{};
+      sf.x0 = Q;
+      if (s < 6) {
+        const bool with_err = s == 5;
+        sf.y = Qtmp; sf.dt = dt; sf.c_last = A[s + 1][s]; sf.ce_last = E[s];
+        sf.e_out = with_err ? k[6] : nullptr;
+        for (int j = 0; j < s; ++j)
+          if (A[s + 1][j] != 0.0 || (with_err && E[j] != 0.0)) {
+            sf.k[sf.ns] = k[j]; sf.c[sf.ns] = A[s + 1][j]; sf.ce[sf.ns] = with_err ? E[j] : 0.0; ++sf.ns;
+          }
+      } else {
+        sf.err = 1; sf.ce_last = E[6]; sf.tol = err_tol; sf.partial = static_cast<double*>(ctx->d_stage_partial.p);
+      }
+      ctx->stage_fuse = &sf;     // (read by the last-phase launches only)
+      ctx->stage_cursor = 0;
+      if (ctx->nghost) rc = rhs_sharded_impl(ctx, Qtmp, k[s], none, stream);
+      else
+        for (int p = 0; p < ctx->nphases && !rc; ++p) rc = esdg_rhs_phase(ctx, p, Qtmp, k[s], stream);
+      ctx->stage_fuse = nullptr;
+    }
+    if (rc) return rc;
+    double acc = 0.0;
+    rc = esdg_sum_device(static_cast<const double*>(ctx->d_stage_partial.p), ctx->stage_cursor, &acc, stream);
+    if (rc) return rc;
+    double tot[2] = {acc, (double)n};
+    if (ctx->nghost && (rc = esdg_comm_allreduce(ctx, tot, 2, 0, stream)) != 0) return rc;   // every rank gets the same estimate
+    *err_est = std::sqrt(tot[0] / tot[1]);
+    return ESDG_OK;
+  }
   for (int s = 1; s < 7; ++s) {
     int rc = esdg_axpy_stages(Qtmp, Q, k, A[s], s, dt, n, stream);
     if (!rc) rc = esdg_rhs(ctx, Qtmp, k[s], stream);

@@ -61,8 +61,10 @@ int launch_sigma_tensor2(int N1, const TensorTables& TT, const MeshDev& M, const
                          double* B, double* SG, hipStream_t s);
 int launch_project_tensor2(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, double* A_U, hipStream_t s);
 // v3 last-phase kernel (esdg_kernels_tensor3.hip); -1 where it does not apply
+struct StageFuse;
 int launch_rhs_tensor3(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
-                       const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s);
+                       const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s, const StageFuse* sf = nullptr);
+int rhs_tensor3_blocks(int N1, int64_t e_count);   // workgroups of that launch (StageFuse::partial has one entry each)
 struct LsrkFuse;
 int launch_rhs_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
                       const double* A_U, const double* SG, const double* B, double* rhs, const LsrkFuse& lf,
@@ -159,6 +161,27 @@ struct LsrkFuse {
   double* AUn;
 };
 
+// optional fusion of the DOPRI45 stage combination and error norm into the last phase (esdg_dopri45_attempt; the STG
+// instantiation of kt3_rhs, CNS contexts).  The launch stores its right-hand side k_s as always and, from the value in registers,
+//   y != null : y = x0 + dt (sum_{j<ns} c[j] k[j] + c_last k_s), the state of the next stage (y may be the state the launch read:
+//               a workgroup reads its elements' state at entry only), and with e_out != null also
+//               e_out = sum_{j<ns} ce[j] k[j] + ce_last k_s, the error combination so far;
+//   err != 0  : e = (what the rhs array held at the node: the error combination so far) + ce_last k_s, and
+//               partial[workgroup] = sum over the workgroup's nodes and fields of (|e| / (tol (1 + |x0|)))^2
+//               (dg2D_CNS_cavity_optimized.jl:1014-1021).
+// The chains are the fma chains of k_axpy_stages / k_dopri_err (esdg_kernels.hip) in the same order: same bits as the unfused
+// attempt per node; the norm's summation order differs.
+struct StageFuse {
+  double* y;
+  const double* x0;
+  const double* k[6];
+  double c[6], c_last, dt;
+  int ns, err;
+  double* e_out;
+  double ce[6], ce_last, tol;
+  double* partial;
+};
+
 struct Phys {
   int formulation;
   double lf_scale;
@@ -186,6 +209,7 @@ int launch_rhstest(const Tables& T, const MeshDev& M, const Phys& ph, const doub
 int launch_lsrk(double* Q, double* resQ, const double* rhs, double a, double b, double dt, int64_t n, hipStream_t s);
 int launch_axpy_stages(double* y, const double* x0, const double* const* k, const double* coef, int ns, double dt,
                        int64_t n, hipStream_t s);
+int launch_sum(const double* x, int64_t n, double* out, hipStream_t s);
 int launch_dopri_err(const double* Q, const double* const* k, const double* coefE, int ns, double tol, int64_t n,
                      double* partial, int nblocks, hipStream_t s);
 // error functionals (esdg_kernels_err.hip); all arrays on the device

@@ -632,8 +632,8 @@ __global__ void k_axpy_stages(double* __restrict__ y, const double* __restrict__
                               int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double k = 0.0;
-    for (int s = 0; s < ns; ++s) k = k + sp.c[s] * sp.k[s][i];
-    y[i] = x0[i] + dt * k;
+    for (int s = 0; s < ns; ++s) k = __builtin_fma(sp.c[s], sp.k[s][i], k);   // (explicit: the fused form in kt3_rhs repeats this chain)
+    y[i] = __builtin_fma(dt, k, x0[i]);
   }
 }
 
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(ESDG_TPB) void k_dopri_err(const double* __restrict
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double e = 0.0;
-    for (int s = 0; s < ns; ++s) e = e + sp.c[s] * sp.k[s][i];
+    for (int s = 0; s < ns; ++s) e = __builtin_fma(sp.c[s], sp.k[s][i], e);
     const double sc = fabs(e) / (tol * (1 + fabs(Q[i])));
     acc += sc * sc;
   }
@@ -836,6 +836,24 @@ __global__ void k_min_rho_p(const double* __restrict__ Q, int nfld, int64_t n, d
 
 int launch_min_rho_p(const double* Q, int nfld, int64_t n, double* partial, int nblocks, hipStream_t s) {
   hipLaunchKernelGGL(k_min_rho_p, dim3(nblocks), dim3(256), 0, s, Q, nfld, n, partial);
+  return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(1024) void k_sum(const double* __restrict__ x, int64_t n, double* __restrict__ out) {
+  __shared__ double red[1024];
+  double a = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) a += x[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+int launch_sum(const double* x, int64_t n, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_sum, dim3(1), dim3(1024), 0, s, x, n, out);
   return (int)hipGetLastError();
 }
 

@@ -66,6 +66,9 @@ __device__ __forceinline__ int64_t xcd_group3(int64_t b, int64_t n) {
   return x * q + (x < r ? x : r) + b / 8;
 }
 
+#ifndef ESDG_T3_PIN_OUT
+#define ESDG_T3_PIN_OUT 1   // (A/B hook: 0 = only the DOPRI45 instantiation pins its results ahead of the epilogue)
+#endif
 #ifndef ESDG_T3_LAZY_LOGS
 #define ESDG_T3_LAZY_LOGS 1   // (A/B hook: 0 = the logarithms of every node and trace state, always)
 #endif
@@ -75,12 +78,12 @@ __device__ __forceinline__ int64_t xcd_group3(int64_t b, int64_t n) {
 #ifdef ESDG_T3_WPE
 constexpr int wpe3(int, bool) { return ESDG_T3_WPE; }
 #else
-constexpr int wpe3(int N1, bool walls_cns) { return N1 <= 4 ? 3 : (N1 <= 6 ? (walls_cns ? 2 : 3) : (N1 == 7 ? 2 : 1)); }
+constexpr int wpe3(int N1, bool walls_cns) { return N1 <= 4 ? 3 : (N1 <= 6 ? (walls_cns ? 2 : 3) : (N1 == 7 || !walls_cns ? 2 : 1)); }
 #endif
-template <int N1, bool MODAL, bool VISC, bool WALLS, bool EMIT = false>
+template <int N1, bool MODAL, bool VISC, bool WALLS, bool EMIT = false, bool STG = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WALLS && VISC && MODAL)))) void kt3_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                           const double* __restrict__ A_U, const double* __restrict__ SG,
-                                                          const double* __restrict__ B, double* __restrict__ rhs, LsrkFuse lf) {
+                                                          const double* __restrict__ B, double* __restrict__ rhs, LsrkFuse lf, StageFuse sf) {
   using G = G3<N1>;
   constexpr int TW = G::TW, Nq = G::Nq, Nfq = G::Nfq, NLN = G::NLN, E = G::E, NV = G::NV, LL = G::LL, NR = G::NR;
   constexpr TensorLayout TL(N1);
@@ -508,8 +511,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
 #pragma unroll
       for (int f = 0; f < 4; ++f) out[r][f] = R[r][f];
   }
+  if (STG || ESDG_T3_PIN_OUT) {   // (the results in registers before any of the epilogue's loads is issued)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) T3_PIN4(out[r]);
+  }
   // ---- store, or fused low-storage RK stage (dg2D_euler_quad.jl:204-205) -------------------------------------------------------
   double qn[EMIT ? NR : 1][4];   // EMIT: the updated state of this lane's nodes
+  double stg_acc = 0.0;          // STG: this lane's part of the error norm
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const unsigned n = tid + r * TW;
@@ -531,6 +539,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
       }
       continue;
     }
+    if (STG) {   // DOPRI45: the store of k_s plus the next stage's state / the error norm (StageFuse, esdg_dev.hpp)
+      T3_FENCE();   // (one round's loads at a time: hoisted together they spill)
+      if (n < (unsigned)(nE * Nq)) {
+        const int64_t i0 = e0 * Nq + n;
+        if (sf.y) {   // (uniform)
+          double xo[4], kk[6][4];
+#pragma unroll
+          for (int f = 0; f < 4; ++f) xo[f] = sf.x0[f * KN + i0];
+#pragma unroll
+          for (int j = 0; j < 6; ++j)
+            if (j < sf.ns) {   // (uniform)
+#pragma unroll
+              for (int f = 0; f < 4; ++f) kk[j][f] = sf.k[j][f * KN + i0];
+            }
+#pragma unroll
+          for (int f = 0; f < 4; ++f) rhs[f * KN + i0] = out[r][f];
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            double a = 0.0, ee = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+              if (j < sf.ns) { a = __builtin_fma(sf.c[j], kk[j][f], a); ee = __builtin_fma(sf.ce[j], kk[j][f], ee); }
+            a = __builtin_fma(sf.c_last, out[r][f], a);
+            sf.y[f * KN + i0] = __builtin_fma(sf.dt, a, xo[f]);
+            if (sf.e_out) sf.e_out[f * KN + i0] = __builtin_fma(sf.ce_last, out[r][f], ee);
+          }
+        } else {
+          double xo[4], ei[4];
+#pragma unroll
+          for (int f = 0; f < 4; ++f) { xo[f] = sf.x0[f * KN + i0]; ei[f] = sf.err ? rhs[f * KN + i0] : 0.0; }
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            rhs[f * KN + i0] = out[r][f];
+            const double e = __builtin_fma(sf.ce_last, out[r][f], ei[f]);
+            const double sc = fabs(e) / (sf.tol * (1 + fabs(xo[f])));
+            stg_acc += sc * sc;
+          }
+        }
+      }
+      continue;
+    }
     if (n < (unsigned)(nE * Nq)) {
       if (lf.Qw) {   // (uniform)
         double ro[4], qo[4];
@@ -548,6 +597,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
         for (int f = 0; f < 4; ++f) rhs[f * KN + e0 * Nq + n] = out[r][f];
       }
     }
+  }
+  if (STG && sf.err) {   // (uniform) one partial per workgroup = per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) stg_acc += __shfl_xor(stg_acc, off, 64);
+    if (tid == 0) sf.partial[blockIdx.x] = stg_acc;
   }
   // ---- EMIT: phase 0 of the NEXT stage for this wave's elements, from the state just updated (LsrkFuse::AUn) -----------------------
   // The statements of kt2_project (esdg_kernels_tensor2.hip) in the same order -- Vq as above, prim_logs, v_of_prim2, the face
@@ -669,30 +723,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
 
 template <int N1, bool MODAL, bool VISC>
 static void launch_rhs3(const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U, const double* SG,
-                        const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s) {
+                        const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s, const StageFuse* sf) {
   using G = t3::G3<N1>;
   const int nb = (int)((M.e_count + G::E - 1) / G::E);
-  if (lf.AUn) {   // fused RK stage that also emits the next stage's traces (esdg_lsrk45_step)
-    if (M.bc) hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, true, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
-    else hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, false, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
+  const StageFuse sf0{};
+  if (sf) {   // DOPRI45 stage (esdg_dopri45_attempt): instantiated for the CNS formulation, which is what the reference integrates so
+    if constexpr (MODAL && VISC) {
+      if (M.bc) hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, true, false, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, *sf);
+      else hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, false, false, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, *sf);
+    }
     return;
   }
-  if (M.bc) hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
-  else hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, false>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf);
+  if (lf.AUn) {   // fused RK stage that also emits the next stage's traces (esdg_lsrk45_step)
+    if (M.bc) hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, true, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, sf0);
+    else hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, false, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, sf0);
+    return;
+  }
+  if (M.bc) hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, sf0);
+  else hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, false>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, sf0);
 }
 
 // last phase on meshes without walls; returns -1 where the v3 kernel does not apply (caller falls back to kt2_rhs)
 int launch_rhs_tensor3(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
-                       const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s) {
+                       const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s, const StageFuse* sf) {
   if (M.e_count <= 0) return 0;
   if (M.bc && N1v == 8) return -1;   // (the wall instantiation at N1 = 8 would not fit the register file)
   const bool modal = ph.formulation != 0, visc = ph.formulation == 1;
+  if (sf && !(modal && visc)) return -1;
   ESDG_T3_DISPATCH(N1v, {
-    if (!modal) (launch_rhs3<N1, false, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
-    else if (visc) (launch_rhs3<N1, true, true>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
-    else (launch_rhs3<N1, true, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
+    if (!modal) (launch_rhs3<N1, false, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s, sf);
+    else if (visc) (launch_rhs3<N1, true, true>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s, sf);
+    else (launch_rhs3<N1, true, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s, sf);
   });
   return (int)hipGetLastError();
+}
+
+int rhs_tensor3_blocks(int N1v, int64_t e_count) {
+  ESDG_T3_DISPATCH(N1v, { return (int)((e_count + t3::G3<N1>::E - 1) / t3::G3<N1>::E); });
 }
 
 }  // namespace esdg

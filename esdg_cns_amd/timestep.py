@@ -71,8 +71,12 @@ def lsrk45_run(eng, Qd, dt, nsteps, rhstest_every=0):
 class Dopri45:
     """Adaptive DOPRI45 with FSAL exactly as the CNS drivers run it."""
 
-    def __init__(self, eng, Qd, dt0, err_tol=1e-5):
+    def __init__(self, eng, Qd, dt0, err_tol=1e-5, pieces=False):
+        """pieces=True: every attempt from the library's building blocks (esdg_axpy_stages, the RHS, esdg_dopri_error) instead of
+        esdg_dopri45_attempt -- what a sharded engine on the torch transport always does, and the partner of the fused attempt
+        in the tests."""
         self.eng, self.Q, self.dt, self.dt0, self.tol = eng, Qd, float(dt0), float(dt0), float(err_tol)
+        self.pieces = bool(pieces) or not (eng.halo is None or eng.transport == "rccl")
         self.rka, self.rkE, self.rkc = sd.dopri45_coeffs()
         self.k = [torch.zeros_like(Qd) for _ in range(7)]
         self.Qtmp = torch.empty_like(Qd)
@@ -89,6 +93,15 @@ class Dopri45:
         eng, L = self.eng, self.eng.L
         n = self.Q.numel()
         s = eng._stream()
+        if not self.pieces:
+            # the library's whole attempt: on unsharded CNS contexts the stage combinations and the error norm ride in the last
+            # phase of each stage (esdg_dopri45_attempt, StageFuse); on a sharded context with the library's communicator the
+            # norm is reduced there
+            e = C.c_double(0.0)
+            check(L.esdg_dopri45_attempt(eng.ctx, C.c_void_p(self.Q.data_ptr()), C.c_void_p(self.Qtmp.data_ptr()), self._ptrs(self.k),
+                                         self.dt, self.tol, C.byref(e), s))
+            self.n_rhs += 6
+            return self._finish(e.value)
         for INTRK in range(1, 7):                       # stages 2..7 (:1002-1012)
             coef = (C.c_double * INTRK)(*[float(self.rka[INTRK, j]) for j in range(INTRK)])
             check(L.esdg_axpy_stages(C.c_void_p(self.Qtmp.data_ptr()), C.c_void_p(self.Q.data_ptr()),
@@ -106,7 +119,10 @@ class Dopri45:
             n_glob = torch.tensor([float(n)], dtype=torch.float64, device=self.Q.device)
             dist.all_reduce(n_glob)
             n = int(n_glob.item())
-        err = math.sqrt(acc.value / n)                  # sqrt(sum/(length(Q[1])*4)) (:1021)
+        return self._finish(math.sqrt(acc.value / n))   # sqrt(sum/(length(Q[1])*4)) (:1021)
+
+    def _finish(self, err):
+        L = self.eng.L
         accepted = err < 1.0
         if accepted:
             self.Q.copy_(self.Qtmp)

@@ -215,8 +215,9 @@ def test_pure_c_hex_driver(tmp_path):
 
 
 def test_whole_step_c_entry_points_match_the_python_loops():
-    """esdg_lsrk45_step / esdg_dopri45_attempt / esdg_dopri45_next_dt against timestep.lsrk45_run / timestep.Dopri45
-    (same kernels underneath): identical bits and identical step-size histories."""
+    """esdg_lsrk45_step / esdg_dopri45_attempt / esdg_dopri45_next_dt against timestep.lsrk45_run / timestep.Dopri45 from the
+    library's building blocks: identical bits and identical step-size histories.  (The attempt of an unsharded CNS context is
+    the fused one -- stage combinations and error norm inside kt3_rhs -- so this is also fused against unfused.)"""
     import ctypes as C
     import torch
     from esdg_cns_amd import engine, timestep
@@ -235,7 +236,7 @@ def test_whole_step_c_entry_points_match_the_python_loops():
     # DOPRI45
     dt0 = 0.5 * (2 / 6) / 10
     Qa = eng.upload(Q)
-    integ = timestep.Dopri45(eng, Qa, dt0)
+    integ = timestep.Dopri45(eng, Qa, dt0, pieces=True)
     hist = []
     for _ in range(6):
         ok, err = integ.step()
@@ -339,3 +340,50 @@ def test_cross_stage_fusion_of_the_lsrk45_step_is_bitwise_the_stage_by_stage_loo
     o1, o2 = eng.new_state(), eng.new_state()
     eng.rhs_into(Qa, o1); eng.rhs_into(Qb, o2)
     assert torch.equal(o1, o2)
+
+
+@pytest.mark.parametrize("case", ["cns N=4 13x9", "cns N=2 10x7", "cns N=6 5x4", "cns N=7 4x3", "cavity N=4 9x8 BCTYPE=1", "cavity N=3 8x7 BCTYPE=2",
+                                  "cavity N=1 7x6 BCTYPE=1"])
+def test_fused_dopri45_attempt_is_bitwise_the_attempt_from_building_blocks(case):
+    """esdg_dopri45_attempt on an unsharded CNS context: the last phase of every stage also forms the next stage's state from the
+    k_s it holds in registers, stage 6 leaves the error combination so far in k[6]'s array and stage 7 reduces the norm
+    (StageFuse, kt3_rhs STG).  Claim: per node the same bits as esdg_axpy_stages + RHS + esdg_dopri_error
+    (dg2D_CNS_cavity_optimized.jl:1002-1021) -- the stage state, all seven k and the accepted solution -- and the error estimate to
+    summation order; same accept / reject and step-size history.  Partial last groups, periodic and wall meshes, N1 = 2 ... 8.
+    A context created with ESDG_DOPRI_FUSION=0 takes the unfused attempt inside the library: same bits again."""
+    import torch
+    from common import product_cavity_problem
+    from esdg_cns_amd import engine, timestep
+    kind, rest = case.split(" ", 1)
+    N = int(rest.split()[0][2:]); Kx, Ky = (int(v) for v in rest.split()[1].split("x"))
+    kw = {}
+    if kind == "cns":
+        rd, md, ops, Q = product_cns_problem(N, Kx, Ky)
+    else:
+        rd, md, ops, Q = product_cavity_problem(N, Kx, Ky)
+        kw["BCTYPE"] = int(rest.split("=")[-1])
+    eng = engine.RhsEngine(rd, md, ops, engine.CNS_MODAL, **kw)
+    os.environ["ESDG_DOPRI_FUSION"] = "0"
+    try:
+        eng0 = engine.RhsEngine(rd, md, ops, engine.CNS_MODAL, **kw)
+    finally:
+        del os.environ["ESDG_DOPRI_FUSION"]
+    dt0 = 0.5 * (2 / Kx) / ((N + 1) * (N + 2) / 2)
+    runs = []
+    for e, pieces in ((eng, False), (eng, True), (eng0, False)):
+        Qd = e.upload(Q)
+        integ = timestep.Dopri45(e, Qd, dt0, err_tol=1e-7 if case == "cns N=4 13x9" else 1e-5, pieces=pieces)   # (tight: rejections first)
+        hist = []
+        for _ in range(6):
+            ok, err = integ.step()
+            hist.append((ok, err, integ.dt))
+        torch.cuda.synchronize()
+        runs.append((Qd, integ, hist))
+    Qf, fused, hf = runs[0]
+    assert torch.isfinite(Qf).all() and any(h[0] for h in hf)
+    for Qo, other, ho in runs[1:]:
+        assert torch.equal(Qf, Qo) and torch.equal(fused.Qtmp, other.Qtmp), case
+        for a, b in zip(fused.k, other.k):
+            assert torch.equal(a, b), case
+        for (ok1, e1, d1), (ok2, e2, d2) in zip(hf, ho):
+            assert ok1 == ok2 and abs(e1 - e2) <= 1e-12 * e2 and abs(d1 - d2) <= 1e-11 * d2
