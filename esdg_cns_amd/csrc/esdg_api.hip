@@ -2041,15 +2041,12 @@ int esdg_dopri_error(const double* Q, const double* const* k, const double* coef
   return ESDG_OK;
 }
 
-// sum of n doubles on the device (one block, fixed order), result on the host
-static int esdg_sum_device(const double* x, int64_t n, double* result, void* stream) {
+// sum of n doubles on the device (one block, fixed order) into x[n] (a spare slot of the caller's), result on the host
+static int esdg_sum_device(double* x, int64_t n, double* result, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  double* out = nullptr;
-  HIP_TRY(hipMalloc(&out, sizeof(double)));
-  int rc = launch_sum(x, n, out, s);
-  hipError_t e = hipMemcpyAsync(result, out, sizeof(double), hipMemcpyDeviceToHost, s);
+  int rc = launch_sum(x, n, x + n, s);
+  hipError_t e = hipMemcpyAsync(result, x + n, sizeof(double), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(out);
   if (rc || e != hipSuccess) return fail(ESDG_ERR_NO_DEVICE, "device sum failed");
   return ESDG_OK;
 }
@@ -2121,7 +2118,7 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
                     (!ctx->M.bc || (v2_on_walls(ctx) && ctx->T.N1 < 8));
   if (fuse) {
     if (!ctx->d_stage_partial.p) {   // (a sharded schedule launches the last phase in up to three pieces, each rounding up)
-      int rc = ctx->d_stage_partial.alloc(sizeof(double) * (size_t)(rhs_tensor3_blocks(ctx->T.N1, ctx->K) + 8));
+      int rc = ctx->d_stage_partial.alloc(sizeof(double) * (size_t)(rhs_tensor3_blocks(ctx->T.N1, ctx->K) + 9));
       if (rc) return rc;
     }
     const LsrkFuse none{nullptr, nullptr, 0.0, 0.0, 0.0};
@@ -2150,7 +2147,7 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
     }
     if (rc) return rc;
     double acc = 0.0;
-    rc = esdg_sum_device(static_cast<const double*>(ctx->d_stage_partial.p), ctx->stage_cursor, &acc, stream);
+    rc = esdg_sum_device(static_cast<double*>(ctx->d_stage_partial.p), ctx->stage_cursor, &acc, stream);
     if (rc) return rc;
     double tot[2] = {acc, (double)n};
     if (ctx->nghost && (rc = esdg_comm_allreduce(ctx, tot, 2, 0, stream)) != 0) return rc;   // every rank gets the same estimate

@@ -73,8 +73,8 @@ __device__ __forceinline__ int64_t xcd_group3(int64_t b, int64_t n) {
 #define ESDG_T3_LAZY_LOGS 1   // (A/B hook: 0 = the logarithms of every node and trace state, always)
 #endif
 // waves per SIMD asked of the register allocator: three up to N1 = 6 (168 VGPRs: the N1 + 2 accumulators of a line take 8 (N1 + 2)
-// of them), two at N1 = 7 and for the CNS wall instantiation from N1 = 5 (its correction planes and penalty shares), one at
-// N1 = 8 (ESDG_T3_WPE overrides, A/B hook)
+// of them), two at N1 = 7, 8 (180-196 VGPRs with Pq's results pinned, ESDG_T3_PIN_OUT) and for the CNS wall instantiation from
+// N1 = 5 (its correction planes and penalty shares; one at N1 = 8, which is not launched).  ESDG_T3_WPE overrides (A/B hook)
 #ifdef ESDG_T3_WPE
 constexpr int wpe3(int, bool) { return ESDG_T3_WPE; }
 #else
