@@ -131,6 +131,67 @@ __device__ __forceinline__ void ec_flux_dir(const double* qL, const double* qR, 
   F[4] = Ep * un;
 }
 
+// The same flux with the branch of the two log-means decided per WAVE where the wave agrees (kh_rhs_l; as ec_flux_dir of the 2D
+// tensor kernels, esdg_t2_physics.hpp): MODE 1 = every active lane takes both series (no log differences, no selects), MODE 2 =
+// no lane takes a series (no polynomials), MODE 0 = the selecting form above.  Each lane's value is the one ec_flux_dir computes.
+#ifndef ESDG_KHL_UNIFORM_LOGMEAN
+#define ESDG_KHL_UNIFORM_LOGMEAN 1   // (A/B hook: 0 = the selecting form everywhere)
+#endif
+template <int MODE>
+__device__ __forceinline__ void ec_flux_core3(const double* qL, const double* qR, double gx, double gy, double gz, double* F, double dr,
+                                              double ravg, double db, double bavg, bool ser_r, bool ser_b) {
+  double yr, yb;
+  if (MODE == 1) { yr = ravg; yb = bavg; }
+  else {
+    const double A = qL[5] - qR[5];
+    yr = MODE == 2 ? A : (ser_r ? ravg : A);
+    yb = MODE == 2 ? db : (ser_b ? bavg : db);
+  }
+  const double yp = qL[4] + qR[4];
+  const double ybp = yb * yp;
+  const double R = rcp_refined(yr * ybp);
+  const double ir = R * ybp;
+  const double ryr = R * yr;
+  const double ib = ryr * yp;
+  const double ip = ryr * yb;
+  const double fr = dr * ir;
+  const double fb = db * ib;
+  double rholog, ibetalog;
+  if (MODE == 2) {
+    rholog = -fr;
+    ibetalog = -((qL[6] - qR[6]) * ib);
+  } else {
+    const double vr = fr * fr, vb = fb * fb;
+    const double sr = ravg * (1 + vr * (-.2 - vr * (.0512 - vr * 0.026038857142857)));
+    const double sb = ib * (1 + vb * (.2 + vb * .0912));
+    if (MODE == 1) { rholog = sr; ibetalog = sb; }
+    else { rholog = ser_r ? sr : -fr; ibetalog = ser_b ? sb : -((qL[6] - qR[6]) * ib); }
+  }
+  const double ua = .5 * (qL[1] + qR[1]), va = .5 * (qL[2] + qR[2]), wa = .5 * (qL[3] + qR[3]);
+  const double unorm = qL[1] * qR[1] + qL[2] * qR[2] + qL[3] * qR[3];
+  const double pa = ravg * ip;
+  const double Ep = rholog * ibetalog * (1.0 / (2 * GM1)) + pa + .5 * rholog * unorm;
+  const double un = gx * ua + gy * va + gz * wa;
+  F[0] = rholog * un;
+  F[1] = F[0] * ua + pa * gx;
+  F[2] = F[0] * va + pa * gy;
+  F[3] = F[0] * wa + pa * gz;
+  F[4] = Ep * un;
+}
+__device__ __forceinline__ void ec_flux_dir_u(const double* qL, const double* qR, double gx, double gy, double gz, double* F) {
+#if ESDG_KHL_UNIFORM_LOGMEAN
+  const double dr = qR[0] - qL[0], ravg = .5 * (qR[0] + qL[0]);
+  const double db = qR[4] - qL[4], bavg = .5 * (qR[4] + qL[4]);
+  const bool ser_r = fabs(dr) < 1e-4 * ravg, ser_b = fabs(db) < 1e-4 * bavg;
+  const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+  if (__builtin_amdgcn_ballot_w64(ser_r || ser_b) == 0) ec_flux_core3<2>(qL, qR, gx, gy, gz, F, dr, ravg, db, bavg, ser_r, ser_b);
+  else if (__builtin_amdgcn_ballot_w64(ser_r && ser_b) == active) ec_flux_core3<1>(qL, qR, gx, gy, gz, F, dr, ravg, db, bavg, ser_r, ser_b);
+  else ec_flux_core3<0>(qL, qR, gx, gy, gz, F, dr, ravg, db, bavg, ser_r, ser_b);
+#else
+  ec_flux_dir(qL, qR, gx, gy, gz, F);
+#endif
+}
+
 // |wavespeed(rho, rhoU_n, E)| of dg3D_euler_hex.jl:190-192 (euler_variables.jl:7-10, sqrt(|u_n|) quirk Q1),
 // from a primitive record; also returns the conservative vector
 __device__ __forceinline__ double lf_lambda3(const double* q, double nx, double ny, double nz, double isJ, double* U) {
@@ -1145,7 +1206,7 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
       unpack3(kn, a0, a1, a2);
       nx = __builtin_fma(sNs, (double)a0, nx); ny = __builtin_fma(sNs, (double)a1, ny); nz = __builtin_fma(sNs, (double)a2, nz);
     }
-    ec_flux_dir(qm, qp, nx, ny, nz, G);
+    ec_flux_dir_u(qm, qp, nx, ny, nz, G);
     if (ph.lf_scale != 0.0) {   // (uniform)
       double UM[HEX_NFLD], UP[HEX_NFLD];
       const double isJ = rcp_refined(sJ);
@@ -1170,14 +1231,14 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
       double W = sTab[L.SF + (d * 2 + t) * N1 + i] * wtf;
       if (CURVED) {   // metric of the pair = average of the two nodes (dg3D_euler_hex.jl:145-151; the .5 goes into the weight)
         W *= .5;
-        ec_flux_dir(qn, qm, gfc[0] + Gl[i][0], gfc[1] + Gl[i][1], gfc[2] + Gl[i][2], F);
+        ec_flux_dir_u(qn, qm, gfc[0] + Gl[i][0], gfc[1] + Gl[i][1], gfc[2] + Gl[i][2], F);
       } else if (DELTA) {
         int b0, b1, b2;
         unpack3(sD[opd * NV + slot], b0, b1, b2);
-        ec_flux_dir(qn, qm, __builtin_fma(hsG, (double)(f0 + b0), gx), __builtin_fma(hsG, (double)(f1 + b1), gy),
+        ec_flux_dir_u(qn, qm, __builtin_fma(hsG, (double)(f0 + b0), gx), __builtin_fma(hsG, (double)(f1 + b1), gy),
                     __builtin_fma(hsG, (double)(f2 + b2), gz), F);
       } else {
-        ec_flux_dir(qn, qm, gx, gy, gz, F);
+        ec_flux_dir_u(qn, qm, gx, gy, gz, F);
       }
 #pragma unroll
       for (int c = 0; c < HEX_NFLD; ++c) { acc[i][c] = __builtin_fma(W, F[c], acc[i][c]); G[c] = __builtin_fma(-W, F[c], G[c]); }
@@ -1205,14 +1266,14 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
         double W = sTab[L.S + (d * N1 + i) * N1 + j] * wt;
         if (CURVED) {
           W *= .5;
-          ec_flux_dir(qi, qj, Gl[i][0] + Gl[j][0], Gl[i][1] + Gl[j][1], Gl[i][2] + Gl[j][2], F);
+          ec_flux_dir_u(qi, qj, Gl[i][0] + Gl[j][0], Gl[i][1] + Gl[j][1], Gl[i][2] + Gl[j][2], F);
         } else if (DELTA) {   // metric of the pair = average of the two nodes: record + half the scale times the two differences
           int b0, b1, b2;
           unpack3(sD[opd * NV + sj], b0, b1, b2);
-          ec_flux_dir(qi, qj, __builtin_fma(hsG, (double)(a0 + b0), gx), __builtin_fma(hsG, (double)(a1 + b1), gy),
+          ec_flux_dir_u(qi, qj, __builtin_fma(hsG, (double)(a0 + b0), gx), __builtin_fma(hsG, (double)(a1 + b1), gy),
                       __builtin_fma(hsG, (double)(a2 + b2), gz), F);
         } else {
-          ec_flux_dir(qi, qj, gx, gy, gz, F);
+          ec_flux_dir_u(qi, qj, gx, gy, gz, F);
         }
 #pragma unroll
         for (int c = 0; c < HEX_NFLD; ++c) { acc[i][c] = __builtin_fma(W, F[c], acc[i][c]); acc[j][c] = __builtin_fma(-W, F[c], acc[j][c]); }
