@@ -273,7 +273,7 @@ def test_pure_c_sharded_driver_over_the_library_rccl_transport(tmp_path):
     for args in (["1", "4", "32", "4"], ["1", "3", "24", "2"]):
         out = subprocess.check_output([exe] + args, text=True, timeout=300)
         print(out.strip())
-        assert "OK" in out and "RCCL comm size 1" in out
+        assert out.count("OK") == 2 and "MISMATCH" not in out and "RCCL comm size 1" in out and "DOPRI45, 6 attempts" in out
 
 
 @pytest.mark.parametrize("formulation", ["cns", "hex", "cavity"])
