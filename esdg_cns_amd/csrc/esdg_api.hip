@@ -698,7 +698,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   if (!ops || !mesh || !phys || !out) return fail(ESDG_ERR_ARG, "null argument");
   *out = nullptr;
   const int N1 = ops->N + 1, Nq = ops->Nq, Nfq = ops->Nfq, Np = ops->Np, Nh = Nq + Nfq;
-  if (!supported_degree(N1)) return fail(ESDG_ERR_ARG, "unsupported degree N=%d (need 1..7)", ops->N);
+  if (!tensor2d_supported_degree(N1)) return fail(ESDG_ERR_ARG, "unsupported degree N=%d (need 1..%d)", ops->N, ESDG_MAX_N1 - 1);
   if (Nq != N1 * N1 || Np != N1 * N1 || Nfq != 4 * N1)
     return fail(ESDG_ERR_STRUCTURE, "need tensor quad sizes Np=Nq=(N+1)^2, Nfq=4(N+1); got Np=%d Nq=%d Nfq=%d", Np, Nq,
                 Nfq);
@@ -838,6 +838,12 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
                                     modal ? &Vq : nullptr, modal ? &Pq : nullptr, th);
   if (const char* env = getenv("ESDG_FORCE_GENERIC"))
     if (env[0] == '1') use_fast = false;
+  if (N1 > 9 && mesh->NmapB > 0)
+    return fail(ESDG_ERR_ARG, "meshes with walls are served up to N=8 (the wall instantiation of the last phase is kt2_rhs from N=7 on, "
+                              "whose packed rows end at N=8); N=%d works on periodic meshes", ops->N);
+  if (!supported_degree(N1) && !use_fast)
+    return fail(ESDG_ERR_STRUCTURE, "degree N=%d is served by the tensor kernels only, and the operators passed do not factor into 1D tables "
+                                    "(the generic kernels stop at N=7)", ops->N);
   c->use_fast = use_fast;
   c->au_nc = use_fast ? FAU_NC : AU_NC;
 
@@ -912,7 +918,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   // kernel before), not by HBM.  Off unless ESDG_TRACE_LAYOUT=face.
   c->bf = false;
   if (const char* env = getenv("ESDG_TRACE_LAYOUT"))
-    c->bf = env[0] == 'f' && use_fast && c->v1 == 0 && !c->ph.dbg && N1 >= 2 && N1 <= 8 && (int64_t)K * Nfq < ((int64_t)1 << 31);
+    c->bf = env[0] == 'f' && use_fast && c->v1 == 0 && !c->ph.dbg && N1 >= 2 && N1 <= ESDG_MAX_N1 && (int64_t)K * Nfq < ((int64_t)1 << 31);
   if (c->bf) {
     const int64_t KF = (int64_t)K * Nfq, KN1 = (int64_t)K * N1;
     auto slot = [&](int32_t n) -> int32_t {
@@ -1329,7 +1335,7 @@ int esdg_num_phases(const esdg_ctx* ctx) { return ctx ? ctx->nphases : 0; }
 int esdg_uses_tensor_kernels(const esdg_ctx* ctx) { return ctx ? (int)ctx->use_fast : 0; }
 
 static bool v2_on_walls(const esdg_ctx* ctx) {
-  return (ctx->v1 & ~4) == 0 && !ctx->ph.dbg && ctx->T.N1 >= 2 && ctx->T.N1 <= 8;   // (bit 4 = phase 0 only)
+  return (ctx->v1 & ~4) == 0 && !ctx->ph.dbg && ctx->T.N1 >= 2 && ctx->T.N1 <= ESDG_MAX_N1;   // (bit 4 = phase 0 only)
 }
 
 static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs, const LsrkFuse& lf, void* stream,
@@ -1412,6 +1418,9 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
     if (rc == -1 && ctx->stage_fuse) return fail(ESDG_ERR_STATE, "DOPRI45 stage fusion asked of a context the v3 last-phase kernel does not serve");
     if (rc == -1 && ctx->use_fast && !(ctx->ph.dbg & ~32) && (ctx->M.bc ? v2_on_walls(ctx) : !(ctx->v1 & 2)))      // v2 kernel: N1 = N + 1 = 2 ... 8
       rc = launch_rhs_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s);
+    if (rc == -1 && !supported_degree(ctx->T.N1))
+      return fail(ESDG_ERR_STATE, "no last-phase kernel for this configuration at N=%d (ESDG_V1 / ESDG_V2 / ESDG_DBG select kernels that stop at N=7 or 8)",
+                  ctx->T.N1 - 1);
     if (rc == -1)
       rc = ctx->use_fast ? launch_rhs_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s)
                          : launch_rhs(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, B, rhs, s);
@@ -1748,6 +1757,8 @@ int esdg_set_parts(esdg_ctx* ctx, int parts) {
 int esdg_viscous_entropy_test(esdg_ctx* ctx, const double* Q, double* out, void* stream) {
   if (!ctx || !Q || !out) return fail(ESDG_ERR_ARG, "null argument");
   if (ctx->dim != 2 || ctx->nphases != 3 || !ctx->use_fast) return fail(ESDG_ERR_STATE, "needs a CNS context on the tensor kernels");
+  if (!supported_degree(ctx->T.N1))
+    return fail(ESDG_ERR_STATE, "the visc_test diagnostic runs on the round-1 phase-1 kernel, which stops at N=7 (this context: N=%d)", ctx->T.N1 - 1);
   if (ctx->nghost && !ctx->comm)
     return fail(ESDG_ERR_STATE, "esdg_viscous_entropy_test on a sharded mesh needs the library's communicator (esdg_comm_init)");
   if (!ctx->M.wJq) return fail(ESDG_ERR_STATE, "wJq was not supplied at esdg_create");
@@ -2069,7 +2080,7 @@ int esdg_lsrk45_step(esdg_ctx* ctx, double* Q, double* resQ, double dt, void* st
   // is bound by vector-instruction issue, and phase 0's arithmetic costs more inside it (node rounds at 78 % lane use, two more
   // LDS exchanges per one-shot wave, 28 spilled registers) than the memory-bound kt2_project launch it saves.  Hence off.
   const bool fuse = ctx->stage_fusion && ctx->dim == 2 && ctx->nghost == 0 && ctx->off_AU2 && !ctx->bf && !(ctx->ph.dbg & ~32) && !(ctx->v1) &&
-                    !(ctx->v2 & 2) && ctx->T.N1 >= 2 && ctx->T.N1 <= 8 && (!ctx->M.bc || (v2_on_walls(ctx) && ctx->T.N1 < 8));
+                    !(ctx->v2 & 2) && ctx->T.N1 >= 2 && ctx->T.N1 <= ESDG_MAX_N1 && (!ctx->M.bc || (v2_on_walls(ctx) && ctx->T.N1 < 8));
   if (!fuse) {
     for (int k = 0; k < 5; ++k) {
       int rc = esdg_rhs_lsrk(ctx, Q, resQ, rk4a[k], rk4b[k], dt, stream);
@@ -2114,7 +2125,7 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
   // unfused attempt (same bits: tests/test_gpu_drivers.py); 30 instead of 43 state-sized sweeps per attempt on top of six
   // right-hand sides.
   const bool fuse = ctx->dopri_fusion && ctx->dim == 2 && ctx->use_fast && ctx->nphases == 3 && ctx->ph.formulation == 1 &&
-                    !ctx->bf && !(ctx->ph.dbg & ~32) && !(ctx->v1 & 2) && !(ctx->v2 & 2) && ctx->T.N1 >= 2 && ctx->T.N1 <= 8 &&
+                    !ctx->bf && !(ctx->ph.dbg & ~32) && !(ctx->v1 & 2) && !(ctx->v2 & 2) && ctx->T.N1 >= 2 && ctx->T.N1 <= ESDG_MAX_N1 &&
                     (!ctx->M.bc || (v2_on_walls(ctx) && ctx->T.N1 < 8));
   if (fuse) {
     if (!ctx->d_stage_partial.p) {   // (a sharded schedule launches the last phase in up to three pieces, each rounding up)

@@ -45,6 +45,12 @@ struct Tables {
 // writes and exchanges half the bytes, the last phase reads 1280 B per element less and pays ~240 VALU instructions.
 constexpr int FAU_NC = 4;
 
+// Largest N1 = N + 1 of the 2D tensor kernels of rounds 2-4 (kt2_project, kt2_sigma, kt2_rhs, kt3_rhs).  The round-1 tensor
+// kernels, the generic pair-list kernels and the hexahedral kernels stop at N1 = 8.
+#ifndef ESDG_MAX_N1
+#define ESDG_MAX_N1 10
+#endif
+
 struct TensorTables;
 struct MeshDev;
 struct Phys;
@@ -64,7 +70,8 @@ int launch_project_tensor2(int N1, const TensorTables& TT, const MeshDev& M, con
 struct StageFuse;
 int launch_rhs_tensor3(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
                        const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s, const StageFuse* sf = nullptr);
-int rhs_tensor3_blocks(int N1, int64_t e_count);   // workgroups of that launch (StageFuse::partial has one entry each)
+int rhs_tensor3_blocks(int N1, int64_t e_count);
+inline bool tensor2d_supported_degree(int N1) { return N1 >= 2 && N1 <= ESDG_MAX_N1; }   // workgroups of that launch (StageFuse::partial has one entry each)
 struct LsrkFuse;
 int launch_rhs_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
                       const double* A_U, const double* SG, const double* B, double* rhs, const LsrkFuse& lf,

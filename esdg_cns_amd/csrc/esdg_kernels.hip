@@ -784,6 +784,16 @@ int launch_pack(const double* src, int ncomp, const int32_t* list, int64_t n, do
 int launch_rhstest(const Tables& T, const MeshDev& M, const Phys& ph, const double* Q, const double* rhs,
                    double* partial, int nblocks, hipStream_t s) {
   const bool modal = ph.formulation != 0;
+  if (T.N1 == 9 || T.N1 == 10) {   // (degrees the tensor kernels of rounds 2-4 serve beyond this file's own range)
+    if (T.N1 == 9) {
+      if (modal) hipLaunchKernelGGL((k_rhstest<9, true>), dim3(nblocks), dim3(ESDG_TPB), 0, s, T, M, Q, rhs, partial);
+      else hipLaunchKernelGGL((k_rhstest<9, false>), dim3(nblocks), dim3(ESDG_TPB), 0, s, T, M, Q, rhs, partial);
+    } else {
+      if (modal) hipLaunchKernelGGL((k_rhstest<10, true>), dim3(nblocks), dim3(ESDG_TPB), 0, s, T, M, Q, rhs, partial);
+      else hipLaunchKernelGGL((k_rhstest<10, false>), dim3(nblocks), dim3(ESDG_TPB), 0, s, T, M, Q, rhs, partial);
+    }
+    return (int)hipGetLastError();
+  }
   ESDG_DISPATCH_N1(T.N1, {
     if (modal)
       hipLaunchKernelGGL((k_rhstest<N1, true>), dim3(nblocks), dim3(ESDG_TPB), 0, s, T, M, Q, rhs, partial);

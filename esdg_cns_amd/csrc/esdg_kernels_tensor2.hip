@@ -31,6 +31,8 @@ template <> struct Cfg<5> { static constexpr int GW = 2; };
 template <> struct Cfg<6> { static constexpr int GW = 4; };
 template <> struct Cfg<7> { static constexpr int GW = 2; };   // 2 elements per group: the accumulator planes stay under 64 KB
 template <> struct Cfg<8> { static constexpr int GW = 2; };
+template <> struct Cfg<9> { static constexpr int GW = 2; };    // one element per group (81 / 100 nodes on 128 lanes)
+template <> struct Cfg<10> { static constexpr int GW = 2; };
 
 // ... and of the last-phase kernel where its measured optimum differs (N=5, 384x384, same box: kt2_rhs 0.400 ms with 4
 // waves per group -- 58 KB LDS, 2 workgroups per CU -- 0.358 ms with 2; kt2_sigma the other way round, 0.161 vs 0.179 ms)
@@ -264,7 +266,9 @@ __global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_s
   // the half jumps (pair + single, face nodes) and the geometry records of the group's elements.
   constexpr int NVP = NV + (NV & 1), NFP = NF + (NF & 1);   // single planes padded to an even length: pair planes stay 16-B aligned
   constexpr int NGEO = E * GEO_STRIDE, GPT = (NGEO + G::GT - 1) / G::GT;   // geometry doubles of a group / per thread
-  constexpr int R0 = 0, R1 = 8 * NV, RV = R1 + 2 * NV + 2 * NVP, RD = RV + 2 * NV + NVP, RG = RD + 6 * NF,
+  // (RG: from N1 = 9 on the six face planes are shorter than the three node planes the wall scratch borrows from them)
+  constexpr int R0 = 0, R1 = 8 * NV, RV = R1 + 2 * NV + 2 * NVP, RD = RV + 2 * NV + NVP,
+                RG = (RD + 6 * NF < 18 * NV) ? 18 * NV : RD + 6 * NF,
                 RE = RG + GPT * G::GT, RW = RE + (WALLS ? (E + 2) / 2 : 0), RT = RW + (WALLS ? 2 * N1 * N1 : 0);
   constexpr bool ROWS_LDS = SigmaCfg<N1, WALLS>::ROWS_LDS;
   constexpr int N1P = N1 + (N1 & 1);                   // rows padded to an even length: N1P / 2 ds_read_b128 per row
@@ -1341,6 +1345,11 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (RhsLds2<N1, MODAL, VISC>::WPE)) void
 
 }  // namespace t2
 
+#if ESDG_MAX_N1 >= 10
+#define ESDG_T2_DISPATCH_HI(...) case 9: { constexpr int N1 = 9; __VA_ARGS__; } break; case 10: { constexpr int N1 = 10; __VA_ARGS__; } break;
+#else
+#define ESDG_T2_DISPATCH_HI(...)
+#endif
 #define ESDG_T2_DISPATCH(N1v, BODY)                  \
   switch (N1v) {                                     \
     case 2: { constexpr int N1 = 2; BODY; } break;   \
@@ -1350,6 +1359,7 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (RhsLds2<N1, MODAL, VISC>::WPE)) void
     case 6: { constexpr int N1 = 6; BODY; } break;   \
     case 7: { constexpr int N1 = 7; BODY; } break;   \
     case 8: { constexpr int N1 = 8; BODY; } break;   \
+    ESDG_T2_DISPATCH_HI(BODY)                          \
     default: return (int)hipErrorInvalidValue;       \
   }
 
@@ -1417,7 +1427,7 @@ static void launch_rhs2(const TensorTables& TT, const MeshDev& M, const Phys& ph
 int launch_rhs_tensor2(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
                        const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s) {
   if (M.e_count <= 0) return 0;
-  if (N1v < 2 || N1v > 8) return -1;
+  if (N1v < 2 || N1v > 9) return -1;   // (RhsRows packs a node's NRND <= 8 partner ids into two ints: N1 = 10 has nine)
   const bool modal = ph.formulation != 0, visc = ph.formulation == 1;
   ESDG_T2_DISPATCH(N1v, {
     {
@@ -1432,7 +1442,7 @@ int launch_rhs_tensor2(int N1v, const TensorTables& TT, const MeshDev& M, const 
 // phase 0 with the v2 kernel; returns -1 where it does not cover the degree (caller falls back to kt_project)
 int launch_project_tensor2(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, double* A_U, hipStream_t s) {
   if (M.e_count <= 0) return 0;
-  if (N1v < 2 || N1v > 8) return -1;
+  if (!tensor2d_supported_degree(N1v)) return -1;
   const bool modal = ph.formulation != 0;
   ESDG_T2_DISPATCH(N1v, {
     using G = t2::Geo<N1>;

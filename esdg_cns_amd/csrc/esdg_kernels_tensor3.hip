@@ -709,6 +709,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
 
 }  // namespace t3
 
+#if ESDG_MAX_N1 >= 10
+#define ESDG_T3_DISPATCH_HI(...) case 9: { constexpr int N1 = 9; __VA_ARGS__; } break; case 10: { constexpr int N1 = 10; __VA_ARGS__; } break;
+#else
+#define ESDG_T3_DISPATCH_HI(...)
+#endif
 #define ESDG_T3_DISPATCH(N1v, BODY)                  \
   switch (N1v) {                                     \
     case 2: { constexpr int N1 = 2; BODY; } break;   \
@@ -718,6 +723,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
     case 6: { constexpr int N1 = 6; BODY; } break;   \
     case 7: { constexpr int N1 = 7; BODY; } break;   \
     case 8: { constexpr int N1 = 8; BODY; } break;   \
+    ESDG_T3_DISPATCH_HI(BODY)                          \
     default: return -1;                              \
   }
 
@@ -747,7 +753,7 @@ static void launch_rhs3(const TensorTables& TT, const MeshDev& M, const Phys& ph
 int launch_rhs_tensor3(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
                        const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s, const StageFuse* sf) {
   if (M.e_count <= 0) return 0;
-  if (M.bc && N1v == 8) return -1;   // (the wall instantiation at N1 = 8 would not fit the register file)
+  if (M.bc && N1v >= 8) return -1;   // (the wall instantiation from N1 = 8 on would not fit the register file)
   const bool modal = ph.formulation != 0, visc = ph.formulation == 1;
   if (sf && !(modal && visc)) return -1;
   ESDG_T3_DISPATCH(N1v, {

@@ -320,7 +320,7 @@ int esdg_setup_quad(int N, int formulation, const double* VX, const double* VY, 
                     int periodic, int64_t e_begin, int64_t e_end, esdg_setup** out) {
   if (!out) return sfail("null output");
   *out = nullptr;
-  if (N < 1 || N > 7 || formulation < 0 || formulation > 2 || !VX || !VY || !EToV || Kg < 1 || Nv < 4) return sfail("bad set-up arguments");
+  if (N < 1 || N > 9 || formulation < 0 || formulation > 2 || !VX || !VY || !EToV || Kg < 1 || Nv < 4) return sfail("bad set-up arguments");
   if (e_end <= 0) { e_begin = 0; e_end = Kg; }
   if (e_begin < 0 || e_end > Kg || e_begin >= e_end) return sfail("bad element range");
   esdg_setup* S = new esdg_setup();

@@ -126,7 +126,7 @@ typedef struct {
 /* Hexahedral path: operators of examples/dg3D_euler_hex.jl:34-98 (quadrature basis) and the 3D MeshData
  * fields the driver holds when it calls `rhs` (:167).  Same conventions as above. */
 typedef struct {
-  int32_t N;    /* polynomial degree, 1..7 (N <= 3: one 64-lane wavefront per element; N >= 4: one workgroup per element) */
+  int32_t N;    /* polynomial degree: quads 1..9 (N = 8, 9: tensor kernels only, no visc_test diagnostic), hexahedra 1..7 */
   int32_t Nq;   /* (N+1)^3 */
   int32_t Nfq;  /* 6 (N+1)^2 */
   const double *Qrhskew, *Qshskew, *Qthskew; /* (Nh x Nh), dg3D_euler_hex.jl:49-51 */

@@ -46,7 +46,8 @@ def _cns(p, **kw):
 PHYS = dict(Re=1000.0, mu=1e-3, lam=-2e-3 / 3, Pr=.71, BCTYPE=1)
 
 
-@pytest.mark.parametrize("N,Kx,Ky", [(3, 16, 16), (4, 12, 8), (4, 64, 64), (2, 9, 7), (1, 6, 6), (5, 5, 4), (6, 4, 3), (7, 3, 3)])
+@pytest.mark.parametrize("N,Kx,Ky", [(3, 16, 16), (4, 12, 8), (4, 64, 64), (2, 9, 7), (1, 6, 6), (5, 5, 4), (6, 4, 3), (7, 3, 3), (8, 4, 3),
+                                     (9, 3, 2)])
 def test_euler_collocated_matches_oracle(eng_mod, oracle_lib, N, Kx, Ky):
     """`rhs` of examples/dg2D_euler_quad.jl:141-194; (3, 16, 16) is BASELINE config 1 at its exact size."""
     rd, md, ops, Q = product_euler_problem(N, Kx, Ky)
@@ -81,7 +82,8 @@ def test_degenerate_periodic_meshes_match_oracle(eng_mod, oracle_lib, form, N, K
         truth_gate(f"cns N={N} {Kx}x{Ky} tiny", _gpu_rhs(eng, Qw), o.rhsRK(Qw, False)[0], q.rhsRK(Qw, False)[0])
 
 
-@pytest.mark.parametrize("N,Kx,Ky", [(4, 12, 8), (4, 64, 64), (3, 10, 10), (2, 7, 9), (1, 5, 5), (5, 4, 4), (4, 7, 3), (5, 5, 3), (6, 6, 5)])
+@pytest.mark.parametrize("N,Kx,Ky", [(4, 12, 8), (4, 64, 64), (3, 10, 10), (2, 7, 9), (1, 5, 5), (5, 4, 4), (4, 7, 3), (5, 5, 3), (6, 6, 5),
+                                     (7, 4, 3), (8, 4, 3), (9, 3, 2)])
 def test_cns_modal_matches_oracle(eng_mod, oracle_lib, N, Kx, Ky):
     """`rhsRK!` of dg2D_CNS_cavity_optimized.jl:955-972 on the periodic vortex box (BASELINE config 3's formulation)."""
     rd, md, ops, Q = product_cns_problem(N, Kx, Ky)
@@ -132,7 +134,7 @@ VISC_FACTOR = 2.0
 
 
 @pytest.mark.parametrize("BCTYPE", [1, 2, 3])
-@pytest.mark.parametrize("N,Kx,Ky", [(3, 6, 5), (4, 8, 8), (5, 4, 3), (4, 2, 2)])   # (2x2: fewer elements than one group holds)
+@pytest.mark.parametrize("N,Kx,Ky", [(3, 6, 5), (4, 8, 8), (5, 4, 3), (4, 2, 2), (8, 3, 2)])   # (2x2: fewer elements than one group holds; N=8: kt2_rhs's wall instantiation)
 def test_cns_wall_boundary_conditions_match_oracle(eng_mod, oracle_lib, BCTYPE, N, Kx, Ky):
     """Lid-driven cavity walls (init_BC_funs, dg2D_CNS_cavity_optimized.jl:135-265): adiabatic no-slip (1),
     isothermal (2), slip (3), lid on y=+1."""

@@ -10,7 +10,7 @@ from esdg_cns_amd import engine
 from esdg_cns_amd._lib import check
 
 Kx = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-for N in range(1, 8):
+for N in range(1, 10):
     rd, md, ops, Q = bench.build_problem(N, Kx, Kx, 0, Kx * Kx, "cns")
     eng = engine.RhsEngine(rd, md, ops, engine.CNS_MODAL)
     Qd, out = eng.upload(Q), eng.new_state()
