@@ -50,7 +50,7 @@ def test_uniform_quad_mesh_matches():
 
 
 @pytest.mark.parametrize("N,Kx,Ky,form,periodic", [(1, 2, 2, 0, True), (2, 3, 2, 0, True), (3, 4, 3, 1, True), (4, 3, 3, 1, False),
-                                                    (2, 5, 4, 2, True), (5, 2, 3, 0, True)])
+                                                    (2, 5, 4, 2, True), (5, 2, 3, 0, True), (8, 2, 2, 1, False), (9, 2, 2, 1, True), (9, 2, 2, 0, True)])
 def test_setup_quad_matches_python_mirror(N, Kx, Ky, form, periodic):
     VX, VY, EToV = sd.uniform_quad_mesh(Kx, Ky)
     if periodic:
