@@ -31,8 +31,17 @@ template <> struct Cfg<5> { static constexpr int GW = 2; };
 template <> struct Cfg<6> { static constexpr int GW = 4; };
 template <> struct Cfg<7> { static constexpr int GW = 2; };   // 2 elements per group: the accumulator planes stay under 64 KB
 template <> struct Cfg<8> { static constexpr int GW = 2; };
-template <> struct Cfg<9> { static constexpr int GW = 2; };    // one element per group (81 / 100 nodes on 128 lanes)
-template <> struct Cfg<10> { static constexpr int GW = 2; };
+// N1 = 9, 10 (round 4, late; only these two choices were measured): three waves hold two elements at N1 = 9 (phases 0 / 1 at 256 x 256:
+// 0.094 / 0.244 ms against 0.104 / 0.269 with two waves and one element); at N1 = 10 four waves would hold two elements but push
+// kt2_sigma past 256 registers, i.e. to one workgroup per CU -- two waves, one element (78 % of the lanes)
+#ifndef ESDG_T2_GW9
+#define ESDG_T2_GW9 3
+#endif
+#ifndef ESDG_T2_GW10
+#define ESDG_T2_GW10 2
+#endif
+template <> struct Cfg<9> { static constexpr int GW = ESDG_T2_GW9; };
+template <> struct Cfg<10> { static constexpr int GW = ESDG_T2_GW10; };
 
 // ... and of the last-phase kernel where its measured optimum differs (N=5, 384x384, same box: kt2_rhs 0.400 ms with 4
 // waves per group -- 58 KB LDS, 2 workgroups per CU -- 0.358 ms with 2; kt2_sigma the other way round, 0.161 vs 0.179 ms)
