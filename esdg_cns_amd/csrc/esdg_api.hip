@@ -2037,7 +2037,7 @@ int esdg_dopri_error(const double* Q, const double* const* k, const double* coef
                      double* result, void* stream) {
   if (!Q || !k || !coefE || !result || ns < 1 || ns > 8) return fail(ESDG_ERR_ARG, "bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int nb = 512;
+  const int nb = 4096;   // (512 until late in round 4: two workgroups per CU left the eight input streams at 2.2 TB/s -- 0.77 ms at cfg3)
   double* partial = nullptr;
   HIP_TRY(hipMalloc(&partial, sizeof(double) * nb));
   int rc = launch_dopri_err(Q, k, coefE, ns, tol, n, partial, nb, s);

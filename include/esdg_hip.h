@@ -356,7 +356,7 @@ int esdg_dopri_error(const double* Q_dev, const double* const* k_dev, const doub
  * On CNS contexts served by the tensor kernels (unsharded, or sharded with a communicator attached) the stage combinations and the
  * error norm are computed inside the last-phase launch of each stage from the k_s it holds in registers (no separate passes
  * over the state; esdg_axpy_stages / esdg_dopri_error above are then not used): per node the same bits, the estimate to summation
- * order, 4.6 instead of 5.7 ms per attempt at N=4 on 512x512.  ESDG_DOPRI_FUSION=0 at esdg_create: always the separate passes.
+ * order, 4.6 instead of 5.1 ms per attempt at N=4 on 512x512.  ESDG_DOPRI_FUSION=0 at esdg_create: always the separate passes.
  * (The accept copy Q <- Qtmp may be a pointer swap on the caller's side: the library keeps no reference to either array.) */
 int esdg_lsrk45_step(esdg_ctx* ctx, double* Q_dev, double* resQ_dev, double dt, void* stream);
 int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q_dev, double* Qtmp_dev, double* const* k_dev, double dt, double err_tol,
