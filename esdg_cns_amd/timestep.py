@@ -71,12 +71,16 @@ def lsrk45_run(eng, Qd, dt, nsteps, rhstest_every=0):
 class Dopri45:
     """Adaptive DOPRI45 with FSAL exactly as the CNS drivers run it."""
 
-    def __init__(self, eng, Qd, dt0, err_tol=1e-5, pieces=False):
-        """pieces=True: every attempt from the library's building blocks (esdg_axpy_stages, the RHS, esdg_dopri_error) instead of
+    def __init__(self, eng, Qd, dt0, err_tol=1e-5, pieces=False, swap=False):
+        """swap=True: an accepted step exchanges the roles of the state and the candidate buffer instead of copying the candidate
+        over the state (two state-sized sweeps less per accepted step); the current state is then `self.Q`, and the tensor passed
+        in is scratch from the first accepted step on.  Default: the tensor passed in is updated in place.
+        pieces=True: every attempt from the library's building blocks (esdg_axpy_stages, the RHS, esdg_dopri_error) instead of
         esdg_dopri45_attempt -- what a sharded engine on the torch transport always does, and the partner of the fused attempt
         in the tests."""
         self.eng, self.Q, self.dt, self.dt0, self.tol = eng, Qd, float(dt0), float(dt0), float(err_tol)
         self.pieces = bool(pieces) or not (eng.halo is None or eng.transport == "rccl")
+        self.swap = bool(swap)
         self.rka, self.rkE, self.rkc = sd.dopri45_coeffs()
         self.k = [torch.zeros_like(Qd) for _ in range(7)]
         self.Qtmp = torch.empty_like(Qd)
@@ -125,7 +129,10 @@ class Dopri45:
         L = self.eng.L
         accepted = err < 1.0
         if accepted:
-            self.Q.copy_(self.Qtmp)
+            if self.swap:
+                self.Q, self.Qtmp = self.Qtmp, self.Q
+            else:
+                self.Q.copy_(self.Qtmp)
             self.t += self.dt
             self.k[0], self.k[6] = self.k[6], self.k[0]  # FSAL (:1025)
         # P / PI controller (:1027-1037) in the library's guarded form: err == 0 gives Inf in the reference (then

@@ -40,12 +40,12 @@ def run_one(N, K1D, Re=100.0, T=1.0, CFL=0.01, BCTYPE=1, inviscid_dissp=True, vi
                            inviscid_dissp=inviscid_dissp, viscous_dissp=viscous_dissp, vlid=vlid)
     eng.setup_errors(rd, md, boundary=True)
     Qd = eng.upload(ph.primitive_to_conservative(rho, u, v, p))
-    integ = timestep.Dopri45(eng, Qd, dt0)
+    integ = timestep.Dopri45(eng, Qd, dt0, swap=True)       # (integ.Q is the state; an accepted step swaps buffers)
     while integ.t < T:
         ok, err = integ.step()
         if verbose and integ.i % 5 == 0:                             # interval = 5, :977
             print(f"i = {integ.i}, t = {integ.t}, dt = {integ.dt}, errEst = {err}")
-    executed, written, _ = eng.boundary_velocity_error(Qd, 2.0 / K1D)  # Jf = 2.0/K1D, :1073
+    executed, written, _ = eng.boundary_velocity_error(integ.Q, 2.0 / K1D)  # Jf = 2.0/K1D, :1073
     return executed, written, integ
 
 

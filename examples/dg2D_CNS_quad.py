@@ -36,14 +36,14 @@ def run(case="cavity", N=3, K1D=16, T=0.1, BCTYPE=2, Re=1000.0, CFL=0.5, verbose
     eng = engine.RhsEngine(rd, md, ops, engine.CNS_MODAL, Re=Re, mu=mu, lam=lam, Pr=Pr, BCTYPE=BCTYPE,
                            inviscid_dissp=True, viscous_dissp=True)
     Qd = eng.upload(Q)
-    integ = timestep.Dopri45(eng, Qd, dt0)
+    integ = timestep.Dopri45(eng, Qd, dt0, swap=True)       # (integ.Q is the state; an accepted step swaps buffers)
     while integ.t < T:
         ok, err = integ.step()
         if verbose and integ.i % 5 == 0:
             print(f"i = {integ.i}, t = {integ.t}, dt = {integ.dt}, errEst = {err}")
     if verbose:
         print(f"done: t = {integ.t}, {integ.i} attempted steps, {integ.n_rhs} RHS evaluations")
-    return eng.download(Qd), integ
+    return eng.download(integ.Q), integ
 
 
 if __name__ == "__main__":

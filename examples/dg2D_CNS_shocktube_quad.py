@@ -72,7 +72,7 @@ def run(N=2, K1D=32, T=0.2, CFL=0.05, Ky=None, verbose=True):
     eng = engine.RhsEngine(rd, md, ops, engine.CNS_MODAL, BCTYPE=4, inviscid_dissp=True, viscous_dissp=False, Re=10000.0,
                            mu=MU, lam=LAM, Pr=PR, inflow=(RHOL, UL, 0.0, PL))
     Qd = eng.upload(Q)
-    integ = timestep.Dopri45(eng, Qd, dt0)
+    integ = timestep.Dopri45(eng, Qd, dt0, swap=True)       # (integ.Q is the state; an accepted step swaps buffers)
     while integ.t < T:
         ok, err = integ.step()
         if verbose and integ.i % 20 == 0:
@@ -82,8 +82,8 @@ def run(N=2, K1D=32, T=0.2, CFL=0.05, Ky=None, verbose=True):
     par = (V0, V1, V01, M0, KAPPA / M0 / CV, V_INF)
     Vq2, wq2 = sd.error_quadrature(N)
     eng.setup_errors(rd, md, Vq2, wq2)
-    L1, Linf, _ = eng.nodal_error(Qd, integ.t, exact=1, par=par)
-    L2, _ = eng.l2_error(Qd, integ.t, exact=1, par=par)
+    L1, Linf, _ = eng.nodal_error(integ.Q, integ.t, exact=1, par=par)
+    L2, _ = eng.l2_error(integ.Q, integ.t, exact=1, par=par)
     if verbose:
         print(f"N = {N}, K = {md.K}\nL1 error is {L1}\nLinf error is {Linf}")
         print(f"t = {integ.t}: L2 error {L2:.3e} ({integ.i} attempted steps, {integ.n_rhs} RHS evaluations)")
