@@ -5,28 +5,6 @@
 namespace esdg {
 namespace devmath {
 
-// Streams: arrays a launch reads or writes exactly once (the state, the stored volume divergence, the result).  Non-temporal
-// accesses keep them from displacing the trace records in L2, which two workgroups read (the owner and the neighbour).  Used by
-// kt3_rhs only: measured at cfg3, same box, alternating: 0.319-0.324 against 0.326-0.329 ms, and 0.311-0.315 against 0.315-0.320 on
-// another box; in kt2_project (+2.7 %) and kt2_sigma (+1 %) the same hint costs time.  ESDG_NT_STREAMS=0: plain accesses (A/B hook).
-#ifndef ESDG_NT_STREAMS
-#define ESDG_NT_STREAMS 1
-#endif
-__device__ __forceinline__ double ld_stream(const double* p) {
-#if ESDG_NT_STREAMS
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
-}
-__device__ __forceinline__ void st_stream(double* p, double v) {
-#if ESDG_NT_STREAMS
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
-}
-
 // Accuracy-attribution builds (tools/parity_truth.py): -DESDG_IEEE_DIV makes every quotient an
 // IEEE division, -DESDG_LIBM_LOG uses the device library's log; neither is a product configuration.
 __device__ __forceinline__ double rcp_refined(double x) {

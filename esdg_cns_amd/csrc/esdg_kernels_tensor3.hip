@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
   for (int r = 0; r < NR; ++r) {
     const unsigned n = tid + r * TW, s = n < (unsigned)NV ? n : n - NV, sl = s < (unsigned)(nE * Nq) ? s : 0u;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) x[r][f] = ld_stream(&Q[f * KN + e0 * Nq + sl]);
+    for (int f = 0; f < 4; ++f) x[r][f] = Q[f * KN + e0 * Nq + sl];
   }
 #pragma unroll
   for (int i = 0; i < GPT; ++i) { const unsigned n = tid + i * TW; geo[i] = M.geo[e0 * GEO_STRIDE + (n < (unsigned)(nE * GEO_STRIDE) ? n : 0u)]; }
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
     for (int r = 0; r < NR; ++r) {
       const unsigned sl = slot[r] < (unsigned)(nE * Nq) ? slot[r] : 0u;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) dvs[r][c] = ld_stream(&SG[c * KN + e0 * Nq + sl]);
+      for (int c = 0; c < 3; ++c) dvs[r][c] = SG[c * KN + e0 * Nq + sl];
     }
   }
   __syncthreads();   // every lane is past its reads of the records, whose space takes the lines' results
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
         }
       } else {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) st_stream(&rhs[f * KN + e0 * Nq + n], out[r][f]);
+        for (int f = 0; f < 4; ++f) rhs[f * KN + e0 * Nq + n] = out[r][f];
       }
     }
   }
