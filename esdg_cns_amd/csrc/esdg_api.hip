@@ -2113,6 +2113,14 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
                                  {35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0}};
   static const double E[7] = {71.0 / 57600.0, 0.0, -71.0 / 16695.0, 71.0 / 1920.0, -17253.0 / 339200.0, 22.0 / 525.0, -1.0 / 40.0};
   if (!ctx || !Q || !Qtmp || !k || !err_est) return fail(ESDG_ERR_ARG, "null argument");
+  {   // nine distinct arrays: the stages read Q and the earlier k while they write Qtmp and their own k
+    const void* a[9] = {Q, Qtmp, k[0], k[1], k[2], k[3], k[4], k[5], k[6]};
+    for (int i = 0; i < 9; ++i) {
+      if (!a[i]) return fail(ESDG_ERR_ARG, "k[%d] is null", i - 2);
+      for (int j = 0; j < i; ++j)
+        if (a[i] == a[j]) return fail(ESDG_ERR_ARG, "Q, Qtmp and k[0..6] must be nine distinct arrays (entries %d and %d coincide)", j, i);
+    }
+  }
   if (ctx->nghost && !ctx->comm)
     return fail(ESDG_ERR_STATE, "esdg_dopri45_attempt on a sharded mesh needs the library's communicator (esdg_comm_init): the "
                                 "error norm is a sum over all ranks");

@@ -545,6 +545,12 @@ def test_degree_limits_are_refused_with_a_reason(E):
     v = C.c_double(0.0)
     with pytest.raises(Exception, match="visc_test diagnostic"):
         E.check(eng.L.esdg_viscous_entropy_test(eng.ctx, C.c_void_p(Qd.data_ptr()), C.byref(v), eng._stream()))
+    # ... and an attempt whose arrays coincide is refused before anything is launched
+    k = [torch.zeros_like(Qd) for _ in range(7)]
+    err = C.c_double(0.0)
+    ptrs = (C.c_void_p * 7)(*[t.data_ptr() for t in k[:6]], k[0].data_ptr())
+    with pytest.raises(Exception, match="nine distinct arrays"):
+        E.check(eng.L.esdg_dopri45_attempt(eng.ctx, C.c_void_p(Qd.data_ptr()), C.c_void_p(k[6].data_ptr()), ptrs, 1e-3, 1e-5, C.byref(err), eng._stream()))
     os.environ["ESDG_FORCE_GENERIC"] = "1"
     try:
         with pytest.raises(Exception, match="tensor kernels only"):
