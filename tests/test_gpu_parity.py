@@ -109,6 +109,16 @@ def test_oracle_built_inputs_give_the_same_verdict(eng_mod, oracle_lib):
     f64, truth = _euler(pe)
     eng = eng_mod.RhsEngine(pe.rd, pe.md, pe.ops, eng_mod.EULER_COLLOCATED)
     truth_gate("euler N=3 16x16 vortex (oracle-built inputs)", _gpu_rhs(eng, pe.Q), f64(pe.Q), truth(pe.Q))
+    # ... the lid-driven cavity (walls, all three BC types) and the hexahedral box the same way
+    for bct in (1, 2, 3):
+        pc = orc.build_cns_problem(4, 6, 5, bc="cavity", BCTYPE=bct)
+        o, q = _cns(pc)
+        eng = eng_mod.RhsEngine(pc.rd, pc.md, pc.ops, eng_mod.CNS_MODAL, Re=pc.Re, mu=pc.mu, lam=pc.lam, Pr=pc.Pr, BCTYPE=bct)
+        truth_gate(f"cavity BCTYPE={bct} N=4 6x5 (oracle-built inputs)", _gpu_rhs(eng, pc.Q), o.rhsRK(pc.Q, False)[0], q.rhsRK(pc.Q, False)[0])
+    ph = orc.build_hex_problem(3, 3, 2, 2)
+    ho, hq = orc.HexOracle(ph, 0.25), orc.HexOracle(ph, 0.25, quad=True)
+    eng = eng_mod.RhsEngine(ph.rd, ph.md, ph.ops, eng_mod.EULER_HEX_COLLOCATED, lf_scale=0.25)
+    truth_gate("hex N=3 (3, 2, 2) lf=0.25 (oracle-built inputs)", _gpu_rhs(eng, ph.Q), ho.rhs(ph.Q)[0], hq.rhs(ph.Q)[0])
 
 
 def test_modal_euler_matches_oracle_inviscid(eng_mod, oracle_lib):
