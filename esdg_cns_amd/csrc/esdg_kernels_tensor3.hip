@@ -44,6 +44,18 @@ template <int N1> struct G3 {
   static_assert(E >= 1, "a wave holds an element");
 };
 
+// The directional flux.  `series` (wave-uniform): the wave is known to be smooth (every pair all-series, see the kernel's smooth-wave
+// test) -- the series variant directly, without ec_flux_dir's per-flux series tests and ballots (which in such a wave would pick
+// the same variant flux by flux: same bits).
+template <bool MODAL>
+__device__ __forceinline__ void flux_dir(bool series, const double* qL, const double* qR, double gx, double gy, double* F, const t2::SeriesK& sk) {
+  if (series) {
+    t2::ec_flux_core<MODAL, 1>(qL, qR, gx, gy, F, qR[0] - qL[0], qR[0] + qL[0], qR[3] - qL[3], qR[3] + qL[3], true, true, sk);
+  } else {
+    ec_flux_dir<MODAL>(qL, qR, gx, gy, F, sk);
+  }
+}
+
 // Compiler-only memory fence in front of every record read of the line stage: the records are read-only there, so without it
 // hipcc merges the repeated reads of a node's record (the node is a partner in N1 + 1 pairs) and keeps all N1 records of the
 // line -- 12 VGPRs each -- live across the whole stage on top of the accumulators: 284 registers at N1 = 5, spills under any cap.
@@ -80,8 +92,13 @@ constexpr int wpe3(int, bool) { return ESDG_T3_WPE; }
 #else
 constexpr int wpe3(int N1, bool walls_cns) { return N1 <= 4 ? 3 : (N1 <= 6 ? (walls_cns ? 2 : 3) : (N1 == 7 || !walls_cns ? 2 : 1)); }
 #endif
+#ifdef ESDG_T3_NVGPR   // (experiment hook: a hard register cap, e.g. 128 for four waves per SIMD)
+#define T3_NVGPR_ATTR __attribute__((amdgpu_num_vgpr(ESDG_T3_NVGPR)))
+#else
+#define T3_NVGPR_ATTR
+#endif
 template <int N1, bool MODAL, bool VISC, bool WALLS, bool EMIT = false, bool STG = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WALLS && VISC && MODAL)))) void kt3_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
+__global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_eu(wpe3(N1, WALLS && VISC && MODAL)))) void kt3_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                           const double* __restrict__ A_U, const double* __restrict__ SG,
                                                           const double* __restrict__ B, double* __restrict__ rhs, LsrkFuse lf, StageFuse sf) {
   using G = G3<N1>;
@@ -109,7 +126,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
   const int nE = (int)min((int64_t)E, M.e_begin + M.e_count - e0r);
   const int64_t e0 = ESDG_EW(e0r);
   const int64_t KN = M.K * Nq;
+#ifdef ESDG_T3_ATTR   // ISA-attribution builds only (tools/isa_buckets.py): the uniform switches as constants -> straight-line code
+  const bool inviscid = true, viscous = VISC;
+  lf.Qw = nullptr;
+#else
   const bool inviscid = (ph.parts & 1) != 0, viscous = VISC && (ph.parts & 2) != 0;
+#endif
 
   // ---- this lane's line: element el, direction d, transverse index o; nodes n0 + i st; face nodes fA (end 0), fB (end 1) ----
   const unsigned ln = tid < (unsigned)LL ? tid : tid - LL;   // (lanes beyond the lines duplicate a line: same LDS writes)
@@ -166,6 +188,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
     }
   }
 
+#ifndef ESDG_T3_PREFETCH
+#define ESDG_T3_PREFETCH 0
+#endif
+  // Experiment hook (ESDG_T3_PREFETCH = distance in workgroups, a multiple of 8 so that the target runs on the same XCD and shares
+  // this L2; 0 = off): one dword of every 128-byte line of the contiguous inputs of workgroup blockIdx + distance -- state, own
+  // trace records, own stress traces, stored divergence, neighbour index -- is requested here, behind this wave's own loads, so that
+  // the later workgroup finds its lines in L2 instead of waiting ~2 us for HBM at its entry.  The values are consumed by a
+  // comparison that is never true at the very end of the kernel (compiler-managed loads: no register is reused before the wait).
+  int pfv[ESDG_T3_PREFETCH ? 5 : 1] = {0};
+  if (ESDG_T3_PREFETCH) {
+    const int64_t bt = (int64_t)blockIdx.x + ESDG_T3_PREFETCH;
+    const int64_t et = M.e_begin + (bt < (int64_t)gridDim.x ? bt : (int64_t)blockIdx.x) * E;   // (beyond the grid: this workgroup's own lines again)
+    const int64_t ec = et + E <= M.K ? et : M.K - E;
+    const unsigned l = tid;
+    {   // state: 4 fields x E Nq doubles each, lines of 16 doubles
+      constexpr unsigned LPF = (E * Nq + 15) / 16;   // lines per field
+      const unsigned f = l / LPF < 4 ? l / LPF : 3, k = l % LPF;
+      const unsigned o = k * 16 < (unsigned)(E * Nq) ? k * 16 : 0;
+      pfv[0] = reinterpret_cast<const int*>(Q + f * KN + ec * Nq + o)[0];
+    }
+    {   // own trace records: E Nfq records of 4 doubles = lines of 4 records
+      constexpr unsigned NL = (E * Nfq * FAU_NC + 15) / 16;
+      const unsigned k = l < NL ? l : 0;
+      pfv[1] = reinterpret_cast<const int*>(A_U + (ec * Nfq) * FAU_NC + k * 16)[0];
+    }
+    if (VISC) {
+      constexpr unsigned NLB = (E * Nfq * B_NC + 15) / 16, NLS = (E * Nq + 15) / 16;
+      const unsigned k = l < NLB ? l : 0;
+      pfv[2] = reinterpret_cast<const int*>(B + (ec * Nfq) * B_NC + k * 16)[0];
+      const unsigned c = l / NLS < 3 ? l / NLS : 2, k2 = l % NLS;
+      pfv[3] = reinterpret_cast<const int*>(SG + c * KN + ec * Nq + (k2 * 16 < (unsigned)(E * Nq) ? k2 * 16 : 0))[0];
+    }
+    {   // neighbour index: E Nfq ints, lines of 32
+      constexpr unsigned NLM = (E * Nfq + 31) / 32;
+      const unsigned k = l < NLM ? l : 0;
+      pfv[4] = M.mapP[ec * Nfq + k * 32];
+    }
+  }
   constexpr int NF = G::NF, NFR = (NF + TW - 1) / TW;   // (EMIT: face nodes of the wave, rounds of the face-node layout)
   // ---- staging: geometry, tables, nodal values ------------------------------------------------------------------------------
 #pragma unroll
@@ -256,7 +316,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
     ok = ok && fabs(qMA[3] - b0) <= tb && fabs(qPA[3] - b0) <= tb && fabs(qMB[3] - b0) <= tb && fabs(qPB[3] - b0) <= tb;
   }
   if (WALLS) ok = ok && bcA != 3 && bcB != 3;   // (a Dirichlet inflow state takes the place of a neighbour's and is not part of this test)
-  const bool smooth = ESDG_T3_LAZY_LOGS && !(ph.dbg & 32) && __builtin_amdgcn_ballot_w64(ok) == __builtin_amdgcn_ballot_w64(true);   // (uniform)
+#ifdef ESDG_T3_ATTR
+  const bool smooth = ESDG_T3_ATTR == 1 && (ok || !ok);
+#else
+  // (through readfirstlane: a scalar the compiler KNOWS to be uniform -- as a lane mask it came back through a v_cndmask / v_cmp pair in
+  // front of every flux)
+  const bool smooth = __builtin_amdgcn_readfirstlane(
+      (int)(ESDG_T3_LAZY_LOGS && !(ph.dbg & 32) && __builtin_amdgcn_ballot_w64(ok) == __builtin_amdgcn_ballot_w64(true))) != 0;
+#endif
   if (!smooth) {
 #pragma unroll
     for (int r = 0; r < NR; ++r) sRec[2 * NV + slot[r]] = make_double2(log_pos(U[r][0]), log_pos(U[r][3]));
@@ -271,6 +338,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
     for (int c = 0; c < 4; ++c) acc[i][c] = 0.0;
   const double* g = sGeo + el * GEO_STRIDE;
   {
+    const t2::SeriesK sk = t2::series_k_pinned();   // (the two series constants that must sit in VGPRs, held for the stage)
     const int opd = d ? TT.op1 : TT.op0;
     const double gxd = 2 * g[opd], gyd = 2 * g[2 + opd];     // metric vector of the line's direction (affine: one per element)
     // one face turn: interface flux + penalty + stress jump of face node f (end t of the line), then its N1 volume-face pairs
@@ -322,7 +390,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
         qP[2] = qM[2] - 2 * un * ny;
       }
       double Fn[4];
-      ec_flux_dir<MODAL>(qM, qP, gn[0], gn[1], Fn);
+      flux_dir<MODAL>(smooth, qM, qP, gn[0], gn[1], Fn, sk);
       const double LFc = ph.inviscid_dissp ? ph.lf_scale * fmax(qM[6], qP[6]) * gn[2] : 0.0;
       // (the LF jump uses Uf[mapP] - Uf, which vanishes at boundary nodes: mapP = self, cavity :511-513)
       const double dz = (WALLS && bc) ? 0.0 : 1.0;
@@ -351,7 +419,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
           const d2 p0 = sRec[n], p1 = sRec[NV + n], p2 = sRec[2 * NV + n];
           const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
           double F[4];
-          ec_flux_dir<MODAL>(qj, qM, gxf, gyf, F);
+          flux_dir<MODAL>(smooth, qj, qM, gxf, gyf, F, sk);
           const double c = SFk[j];
 #pragma unroll
           for (int k = 0; k < 4; ++k) { acc[j][k] = __builtin_fma(c, F[k], acc[j][k]); Gf[k] = __builtin_fma(-c, F[k], Gf[k]); }
@@ -378,7 +446,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
           const d2 p0 = sRec[n], p1 = sRec[NV + n], p2 = sRec[2 * NV + n];
           const double qj[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
           double F[4];
-          ec_flux_dir<MODAL>(qi, qj, gxv, gyv, F);
+          flux_dir<MODAL>(smooth, qi, qj, gxv, gyv, F, sk);
           const double c = Sd[i * N1 + j];
 #pragma unroll
           for (int k = 0; k < 4; ++k) { acc[i][k] = __builtin_fma(c, F[k], acc[i][k]); acc[j][k] = __builtin_fma(-c, F[k], acc[j][k]); }
@@ -387,6 +455,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
       }
     }
   }
+  // The node-layout ids pass through an empty asm statement: what the compiler derived from them before the line stage (LDS byte
+  // addresses of the Vq / Pq rounds, element and row ids -- some twenty VGPRs it kept alive across the stage, one of them spilled once
+  // the series constants were pinned) is derived again behind it from these six registers.
+#pragma unroll
+  for (int r = 0; r < NR; ++r) asm volatile("" : "+v"(slot[r]), "+v"(nq[r]));
   // viscous volume divergence of the wave's nodes (phase 1): requested here, consumed after the exchange below
   double dvs[NR][3];
   if (VISC) {
@@ -598,6 +671,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
       }
     }
   }
+  if (ESDG_T3_PREFETCH) {   // (never true: the loaded ints are finite data; keeps the prefetch loads alive without a wait before here)
+    if ((pfv[0] ^ pfv[1] ^ pfv[2] ^ pfv[3] ^ pfv[4]) == 0x7fc01234 && M.K < 0) rhs[tid] = 0.0;
+  }
   if (STG && sf.err) {   // (uniform) one partial per workgroup = per wave
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) stg_acc += __shfl_xor(stg_acc, off, 64);
@@ -709,6 +785,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
 
 }  // namespace t3
 
+#ifndef ESDG_T3_NO_DISPATCH   // (tools/isa_buckets.py includes this file for one explicit instantiation)
 #if ESDG_MAX_N1 >= 10
 #define ESDG_T3_DISPATCH_HI(...) case 9: { constexpr int N1 = 9; __VA_ARGS__; } break; case 10: { constexpr int N1 = 10; __VA_ARGS__; } break;
 #else
@@ -767,5 +844,6 @@ int launch_rhs_tensor3(int N1v, const TensorTables& TT, const MeshDev& M, const 
 int rhs_tensor3_blocks(int N1v, int64_t e_count) {
   ESDG_T3_DISPATCH(N1v, { return (int)((e_count + t3::G3<N1>::E - 1) / t3::G3<N1>::E); });
 }
+#endif  // ESDG_T3_NO_DISPATCH
 
 }  // namespace esdg

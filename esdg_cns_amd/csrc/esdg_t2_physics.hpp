@@ -45,63 +45,92 @@ template <bool MODAL> struct Gas2 { static constexpr double GM1 = MODAL ? 0.4 : 
 // half is not computed at all -- 13-15 of ~64 VALU instructions per flux.  The three variants evaluate the same
 // expressions with explicit FMAs, so a lane's result does not depend on which variant its wave ran (the ranged-launch
 // and shard tests compare bit for bit across different wave compositions).
-__device__ __forceinline__ double logmean_series_rho(double ravg, double vr) {
-  return ravg * __builtin_fma(vr, __builtin_fma(vr, __builtin_fma(vr, 0.026038857142857, -.0512), -.2), 1.0);
+//
+// Round 5 -- the same values from SUMS instead of averages.  Every .5 of the formulas (the four averages, the half of the kinetic
+// term) is a power of two and commutes with rounding, so it can ride in a constant instead of costing an instruction: the cores
+// take srho = rho_L + rho_R and sbeta = beta_L + beta_R (= the reference's yp, which the pressure average needs anyway), run the
+// series polynomials on (f/2)^2 with coefficients scaled by exact powers of two, keep 2 pa and 2 f4aux, and absorb the halves in
+// the metric vector (.5 gx, .5 gy: loop invariants of the callers) -- rholog, 1/betalog and the four flux components are BIT FOR BIT
+// those of the formulation with averages (every intermediate is the old one times an exact power of two), at 3 instructions
+// less per flux.
+// The innermost step of either Horner chain has two non-inline constants, and gfx950 VOP3 reads at most one operand from the
+// constant bus (an SGPR pair; there are no 64-bit literals): the other must sit in VGPRs.  Left to itself hipcc rematerialises it in
+// front of every flux that sits behind a branch (two v_mov_b32 + a v_mov_b64 copy for the destructive v_fmac: ~8 of a flux's ~50
+// instructions in kt3_rhs).  SeriesK carries the two constants; a kernel that evaluates many fluxes passes a pinned copy
+// (series_k_pinned: opaque to the compiler, so they stay in six VGPRs for the stage), the others the literals.
+struct SeriesK { double r2, r1, b1; };
+__device__ __forceinline__ SeriesK series_k() { return {8 * -.0512, 2 * -.2, 8 * .2}; }
+__device__ __forceinline__ SeriesK series_k_pinned() {
+  SeriesK k = series_k();
+  asm volatile("" : "+v"(k.r2), "+v"(k.r1), "+v"(k.b1));
+  return k;
 }
-__device__ __forceinline__ double logmean_series_ibeta(double ib, double vb) {
-  return ib * __builtin_fma(vb, __builtin_fma(vb, .0912, .2), 1.0);
+// half of the rho series in w = (f/2)^2:  .5 (1 + 4w (-.2 + 4w (-.0512 + 4w c3)))
+__device__ __forceinline__ double logmean_series_rho_h(double w, const SeriesK& k) {
+  return __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 32 * 0.026038857142857, k.r2), k.r1), .5);
 }
+// twice the 1/beta series in w = (f/2)^2:  2 (1 + 4w (.2 + 4w .0912))
+__device__ __forceinline__ double logmean_series_ibeta_2(double w, const SeriesK& k) {
+  return __builtin_fma(w, __builtin_fma(w, 32 * .0912, k.b1), 2.0);
+}
+// dr = rho_R - rho_L, sr = rho_R + rho_L, db, sb likewise; ser_r / ser_b: this lane takes the series for rho / beta (MODE 0)
 template <bool MODAL, int MODE>
-__device__ __forceinline__ void ec_flux_core(const double* qL, const double* qR, double gx, double gy, double* F, double dr, double ravg,
-                                             double db, double bavg, bool ser_r, bool ser_b) {
+__device__ __forceinline__ void ec_flux_core(const double* qL, const double* qR, double gx, double gy, double* F, double dr, double sr,
+                                             double db, double sb, bool ser_r, bool ser_b, const SeriesK& sk = series_k()) {
   constexpr double GM1 = Gas2<MODAL>::GM1;
+  // yr: 2 rho_avg (series) or log rho_L - log rho_R; yb: 2 beta_avg (series) or beta_R - beta_L; yp = beta_L + beta_R
   double yr, yb;
-  if (MODE == 1) { yr = ravg; yb = bavg; }
+  if (MODE == 1) { yr = sr; yb = sb; }
   else {
     const double A = qL[4] - qR[4];
-    yr = MODE == 2 ? A : (ser_r ? ravg : A);
-    yb = MODE == 2 ? db : (ser_b ? bavg : db);
+    yr = MODE == 2 ? A : (ser_r ? sr : A);
+    yb = MODE == 2 ? db : (ser_b ? sb : db);
   }
-  const double yp = qL[3] + qR[3];
-  const double ybp = yb * yp;
+  const double ybp = yb * sb;
   const double R = rcp_refined(yr * ybp);
-  const double ir = R * ybp;
+  const double ir = R * ybp;     // 1 / yr
   const double ryr = R * yr;
-  const double ib = ryr * yp;
-  const double ip = ryr * yb;
-  const double fr = dr * ir;
+  const double ib = ryr * sb;    // 1 / yb
+  const double ip = ryr * yb;    // 1 / (beta_L + beta_R)
+  const double fr = dr * ir;     // series lanes: f / 2
   const double fb = db * ib;
   double rholog, ibetalog;
   if (MODE == 2) {
     rholog = -fr;
     ibetalog = -((qL[5] - qR[5]) * ib);
   } else {
-    const double sr = logmean_series_rho(ravg, fr * fr), sb = logmean_series_ibeta(ib, fb * fb);
-    if (MODE == 1) { rholog = sr; ibetalog = sb; }
-    else { rholog = ser_r ? sr : -fr; ibetalog = ser_b ? sb : -((qL[5] - qR[5]) * ib); }
+    const double srs = sr * logmean_series_rho_h(fr * fr, sk), sbs = ib * logmean_series_ibeta_2(fb * fb, sk);
+    if (MODE == 1) { rholog = srs; ibetalog = sbs; }
+    else { rholog = ser_r ? srs : -fr; ibetalog = ser_b ? sbs : -((qL[5] - qR[5]) * ib); }
   }
-  const double uavg = .5 * (qL[1] + qR[1]), vavg = .5 * (qL[2] + qR[2]);
+  const double su = qL[1] + qR[1], sv = qL[2] + qR[2];
   const double unorm = __builtin_fma(qL[2], qR[2], qL[1] * qR[1]);
-  const double pa = ravg * ip;
-  const double f4aux = __builtin_fma(.5 * rholog, unorm, __builtin_fma(rholog * ibetalog, 1.0 / (2 * GM1), pa));
-  const double un = __builtin_fma(gy, vavg, gx * uavg);
+  const double pa2 = sr * ip;                                                                   // 2 pa
+  const double f4aux2 = __builtin_fma(rholog, __builtin_fma(ibetalog, 1.0 / GM1, unorm), pa2);   // 2 f4aux = rholog (1/(g-1) / betalog + uL.uR) + 2 pa
+  const double hgx = .5 * gx, hgy = .5 * gy;
+  const double un = __builtin_fma(hgy, sv, hgx * su);
   F[0] = rholog * un;
-  F[1] = __builtin_fma(F[0], uavg, pa * gx);
-  F[2] = __builtin_fma(F[0], vavg, pa * gy);
-  F[3] = f4aux * un;
+  const double hF0 = .5 * F[0];
+  F[1] = __builtin_fma(hF0, su, pa2 * hgx);
+  F[2] = __builtin_fma(hF0, sv, pa2 * hgy);
+  F[3] = f4aux2 * (.5 * un);
 }
 template <bool MODAL>
-__device__ __forceinline__ void ec_flux_dir(const double* qL, const double* qR, double gx, double gy, double* F) {
-  const double dr = qR[0] - qL[0], ravg = .5 * (qR[0] + qL[0]);
-  const double db = qR[3] - qL[3], bavg = .5 * (qR[3] + qL[3]);
-  const bool ser_r = fabs(dr) < 1e-4 * ravg, ser_b = fabs(db) < 1e-4 * bavg;
-#ifdef ESDG_T2_NO_UNIFORM_LOGMEAN
-  ec_flux_core<MODAL, 0>(qL, qR, gx, gy, F, dr, ravg, db, bavg, ser_r, ser_b);
+__device__ __forceinline__ void ec_flux_dir(const double* qL, const double* qR, double gx, double gy, double* F, const SeriesK& sk = series_k()) {
+  const double dr = qR[0] - qL[0], sr = qR[0] + qL[0];
+  const double db = qR[3] - qL[3], sb = qR[3] + qL[3];
+  const bool ser_r = fabs(dr) < (.5 * 1e-4) * sr, ser_b = fabs(db) < (.5 * 1e-4) * sb;
+#if defined(ESDG_T2_FORCE_MODE)   // ISA-attribution builds only (tools/isa_buckets.py): one variant, no ballots -- straight-line code
+  ec_flux_core<MODAL, ESDG_T2_FORCE_MODE>(qL, qR, gx, gy, F, dr, sr, db, sb, ser_r, ser_b, sk);
+#elif defined(ESDG_T2_NO_UNIFORM_LOGMEAN)
+  ec_flux_core<MODAL, 0>(qL, qR, gx, gy, F, dr, sr, db, sb, ser_r, ser_b, sk);
 #else
-  const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
-  if (__builtin_amdgcn_ballot_w64(ser_r && ser_b) == active) ec_flux_core<MODAL, 1>(qL, qR, gx, gy, F, dr, ravg, db, bavg, ser_r, ser_b);
-  else if (__builtin_amdgcn_ballot_w64(ser_r || ser_b) == 0) ec_flux_core<MODAL, 2>(qL, qR, gx, gy, F, dr, ravg, db, bavg, ser_r, ser_b);
-  else ec_flux_core<MODAL, 0>(qL, qR, gx, gy, F, dr, ravg, db, bavg, ser_r, ser_b);
+  // (one ballot per comparison -- the v_cmp's own lane mask -- and scalar logic on the masks: the ballot of `ser_r && ser_b` made hipcc
+  // turn the combined mask into a VGPR and compare it again, twice per flux)
+  const unsigned long long active = __builtin_amdgcn_ballot_w64(true), br = __builtin_amdgcn_ballot_w64(ser_r), bb = __builtin_amdgcn_ballot_w64(ser_b);
+  if ((br & bb) == active) ec_flux_core<MODAL, 1>(qL, qR, gx, gy, F, dr, sr, db, sb, ser_r, ser_b, sk);
+  else if ((br | bb) == 0) ec_flux_core<MODAL, 2>(qL, qR, gx, gy, F, dr, sr, db, sb, ser_r, ser_b, sk);
+  else ec_flux_core<MODAL, 0>(qL, qR, gx, gy, F, dr, sr, db, sb, ser_r, ser_b, sk);
 #endif
 }
 

@@ -11,6 +11,7 @@
 #   kstats TAG [bench args]      rocprofv3 --kernel-trace --stats of one bench run, per-kernel averages
 #   bench [bench args]           python bench.py ... > gpurun_out/bench_<n>.json
 #   py script.py [args]          python <script> (log in gpurun_out/py_<name>.log)
+#   sq TAG [bench args]          SQ instruction-mix / LDS counters per kernel (tools/pmc_sq.sh), gpurun_out/sq_TAG.txt
 #   ubench name                  build + run tools/ubench/<name>.hip (log in gpurun_out/ubench_<name>.log)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
@@ -33,21 +34,21 @@ run_step() {
         else timeout -k 10 300 python bench.py --no-cpu-baseline "$@" 2>/dev/null | grepms; fi
         echo
       done ;;
-    ablib)
-      local alt=$1; shift
-      cp esdg_cns_amd/libesdg_hip.so /tmp/ab_new.so
+    ablib)   # (the base build is selected through ESDG_HIP_LIB: the in-tree library is never overwritten)
+      local alt=esdg_cns_amd/variants/$1; shift
+      [ -f "$alt" ] || { echo "missing variant $alt"; return 2; }
       for v in new base new base new base; do
-        if [ $v = base ]; then cp esdg_cns_amd/variants/$alt esdg_cns_amd/libesdg_hip.so; else cp /tmp/ab_new.so esdg_cns_amd/libesdg_hip.so; fi
-        echo -n "$v: "; timeout -k 10 300 python bench.py --no-cpu-baseline "$@" 2>/dev/null | grepms; echo
-      done
-      cp /tmp/ab_new.so esdg_cns_amd/libesdg_hip.so ;;
+        echo -n "$v: "
+        if [ $v = base ]; then (export ESDG_HIP_LIB=$PWD/$alt; timeout -k 10 300 python bench.py --no-cpu-baseline "$@" 2>/dev/null | grepms)
+        else timeout -k 10 300 python bench.py --no-cpu-baseline "$@" 2>/dev/null | grepms; fi
+        echo
+      done ;;
     testlib)
-      local alt=$1; shift
+      local alt=esdg_cns_amd/variants/$1; local nm=$1; shift
+      [ -f "$alt" ] || { echo "missing variant $alt"; return 2; }
       local a=("$@"); [ ${#a[@]} -eq 0 ] && a=(tests -m gpu -q)
-      cp esdg_cns_amd/libesdg_hip.so /tmp/tl_new.so; cp esdg_cns_amd/variants/$alt esdg_cns_amd/libesdg_hip.so
-      timeout -k 10 1000 python -m pytest "${a[@]}" > gpurun_out/pytest_$alt.log 2>&1; local rc=$?
-      cp /tmp/tl_new.so esdg_cns_amd/libesdg_hip.so
-      tail -4 gpurun_out/pytest_$alt.log; return $rc ;;
+      (export ESDG_HIP_LIB=$PWD/$alt; timeout -k 10 1000 python -m pytest "${a[@]}" > gpurun_out/pytest_$nm.log 2>&1); local rc=$?
+      tail -4 gpurun_out/pytest_$nm.log; return $rc ;;
     round1)   # final pass of a round, part 1: GPU suite, smoke, rocprofv3 + PMC passes and the default bench line for cns (cfg3)
       local tag=$1; local O=gpurun_out/$tag; mkdir -p $O
       timeout -k 10 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
@@ -71,6 +72,10 @@ run_step() {
       local s=$1; shift
       timeout -k 10 900 python "$s" "$@" > gpurun_out/py_$(basename $s .py).log 2>&1; local rc=$?
       tail -25 gpurun_out/py_$(basename $s .py).log; return $rc ;;
+    sq)      # SQ instruction-mix counters of one bench run: sq TAG [bench args]
+      local tag=$1; shift
+      bash tools/pmc_sq.sh "$tag" "$@" > gpurun_out/sq_$tag.txt 2>&1; local rc=$?
+      tail -12 gpurun_out/sq_$tag.txt; return $rc ;;
     ubench)
       local n=$1; shift
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/ub_$n tools/ubench/$n.hip || return 1
