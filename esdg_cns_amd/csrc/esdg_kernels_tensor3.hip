@@ -188,44 +188,6 @@ __global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_e
     }
   }
 
-#ifndef ESDG_T3_PREFETCH
-#define ESDG_T3_PREFETCH 0
-#endif
-  // Experiment hook (ESDG_T3_PREFETCH = distance in workgroups, a multiple of 8 so that the target runs on the same XCD and shares
-  // this L2; 0 = off): one dword of every 128-byte line of the contiguous inputs of workgroup blockIdx + distance -- state, own
-  // trace records, own stress traces, stored divergence, neighbour index -- is requested here, behind this wave's own loads, so that
-  // the later workgroup finds its lines in L2 instead of waiting ~2 us for HBM at its entry.  The values are consumed by a
-  // comparison that is never true at the very end of the kernel (compiler-managed loads: no register is reused before the wait).
-  int pfv[ESDG_T3_PREFETCH ? 5 : 1] = {0};
-  if (ESDG_T3_PREFETCH) {
-    const int64_t bt = (int64_t)blockIdx.x + ESDG_T3_PREFETCH;
-    const int64_t et = M.e_begin + (bt < (int64_t)gridDim.x ? bt : (int64_t)blockIdx.x) * E;   // (beyond the grid: this workgroup's own lines again)
-    const int64_t ec = et + E <= M.K ? et : M.K - E;
-    const unsigned l = tid;
-    {   // state: 4 fields x E Nq doubles each, lines of 16 doubles
-      constexpr unsigned LPF = (E * Nq + 15) / 16;   // lines per field
-      const unsigned f = l / LPF < 4 ? l / LPF : 3, k = l % LPF;
-      const unsigned o = k * 16 < (unsigned)(E * Nq) ? k * 16 : 0;
-      pfv[0] = reinterpret_cast<const int*>(Q + f * KN + ec * Nq + o)[0];
-    }
-    {   // own trace records: E Nfq records of 4 doubles = lines of 4 records
-      constexpr unsigned NL = (E * Nfq * FAU_NC + 15) / 16;
-      const unsigned k = l < NL ? l : 0;
-      pfv[1] = reinterpret_cast<const int*>(A_U + (ec * Nfq) * FAU_NC + k * 16)[0];
-    }
-    if (VISC) {
-      constexpr unsigned NLB = (E * Nfq * B_NC + 15) / 16, NLS = (E * Nq + 15) / 16;
-      const unsigned k = l < NLB ? l : 0;
-      pfv[2] = reinterpret_cast<const int*>(B + (ec * Nfq) * B_NC + k * 16)[0];
-      const unsigned c = l / NLS < 3 ? l / NLS : 2, k2 = l % NLS;
-      pfv[3] = reinterpret_cast<const int*>(SG + c * KN + ec * Nq + (k2 * 16 < (unsigned)(E * Nq) ? k2 * 16 : 0))[0];
-    }
-    {   // neighbour index: E Nfq ints, lines of 32
-      constexpr unsigned NLM = (E * Nfq + 31) / 32;
-      const unsigned k = l < NLM ? l : 0;
-      pfv[4] = M.mapP[ec * Nfq + k * 32];
-    }
-  }
   constexpr int NF = G::NF, NFR = (NF + TW - 1) / TW;   // (EMIT: face nodes of the wave, rounds of the face-node layout)
   // ---- staging: geometry, tables, nodal values ------------------------------------------------------------------------------
 #pragma unroll
@@ -670,9 +632,6 @@ __global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_e
         for (int f = 0; f < 4; ++f) rhs[f * KN + e0 * Nq + n] = out[r][f];
       }
     }
-  }
-  if (ESDG_T3_PREFETCH) {   // (never true: the loaded ints are finite data; keeps the prefetch loads alive without a wait before here)
-    if ((pfv[0] ^ pfv[1] ^ pfv[2] ^ pfv[3] ^ pfv[4]) == 0x7fc01234 && M.K < 0) rhs[tid] = 0.0;
   }
   if (STG && sf.err) {   // (uniform) one partial per workgroup = per wave
 #pragma unroll
