@@ -24,6 +24,7 @@
 #include "esdg_dev.hpp"
 #include "esdg_devmath.hpp"
 #include "esdg_hex_tables.hpp"
+#include "esdg_t2_physics.hpp"   // SeriesK and the series polynomials shared with the 2D flux
 
 namespace esdg {
 namespace hdev {
@@ -97,62 +98,29 @@ __device__ __forceinline__ void prim_of_v3(const double* V, double* q) {
   q[4] = V[4] * (-1.0 / (2 * GM1));
 }
 
-// g . (Fx,Fy,Fz) of the entropy-conservative flux (euler_fluxes.jl:51-89), q = (rho,u,v,w,beta,lrho,lbeta).
-// One reciprocal serves the rho log-mean, 1/(beta log-mean) and pa; logmean's |f| < 1e-4 series branch is
-// selected, not branched (same construction as ec_flux of the 2D tensor kernels).
-__device__ __forceinline__ void ec_flux_dir(const double* qL, const double* qR, double gx, double gy, double gz,
-                                            double* F) {
-  const double dr = qR[0] - qL[0], ravg = .5 * (qR[0] + qL[0]);
-  const double db = qR[4] - qL[4], bavg = .5 * (qR[4] + qL[4]);
-  const double A = qL[5] - qR[5], B = qL[6] - qR[6];
-  const bool ser_r = fabs(dr) < 1e-4 * ravg, ser_b = fabs(db) < 1e-4 * bavg;
-  const double yr = ser_r ? ravg : A;
-  const double yb = ser_b ? bavg : db;
-  const double yp = qL[4] + qR[4];
-  const double ybp = yb * yp;
-  const double R = rcp_refined(yr * ybp);
-  const double ir = R * ybp;
-  const double ryr = R * yr;
-  const double ib = ryr * yp;
-  const double ip = ryr * yb;
-  const double fr = dr * ir, vr = fr * fr;
-  const double rholog = ser_r ? ravg * (1 + vr * (-.2 - vr * (.0512 - vr * 0.026038857142857))) : -fr;
-  const double fb = db * ib, vb = fb * fb;
-  const double ibetalog = ser_b ? ib * (1 + vb * (.2 + vb * .0912)) : -(B * ib);
-  const double ua = .5 * (qL[1] + qR[1]), va = .5 * (qL[2] + qR[2]), wa = .5 * (qL[3] + qR[3]);
-  const double unorm = qL[1] * qR[1] + qL[2] * qR[2] + qL[3] * qR[3];
-  const double pa = ravg * ip;
-  const double Ep = rholog * ibetalog * (1.0 / (2 * GM1)) + pa + .5 * rholog * unorm;
-  const double un = gx * ua + gy * va + gz * wa;
-  F[0] = rholog * un;
-  F[1] = F[0] * ua + pa * gx;
-  F[2] = F[0] * va + pa * gy;
-  F[3] = F[0] * wa + pa * gz;
-  F[4] = Ep * un;
-}
-
-// The same flux with the branch of the two log-means decided per WAVE where the wave agrees (kh_rhs_l; as ec_flux_dir of the 2D
-// tensor kernels, esdg_t2_physics.hpp): MODE 1 = every active lane takes both series (no log differences, no selects), MODE 2 =
-// no lane takes a series (no polynomials), MODE 0 = the selecting form above.  Each lane's value is the one ec_flux_dir computes.
-#ifndef ESDG_KHL_UNIFORM_LOGMEAN
-#define ESDG_KHL_UNIFORM_LOGMEAN 1   // (A/B hook: 0 = the selecting form everywhere)
-#endif
+// g . (Fx,Fy,Fz) of the entropy-conservative flux (euler_fluxes.jl:51-89), q = (rho,u,v,w,beta,lrho,lbeta), for the metric vector
+// g = 2 (hgx, hgy, hgz): the callers pass HALF the metric vector (a loop invariant, or a half scale of their packed differences).
+// One reciprocal serves the rho log-mean, 1/(beta log-mean) and pa.  Same construction as ec_flux_core of the 2D tensor kernels
+// (esdg_t2_physics.hpp, round 5): sums instead of averages with every 1/2 folded into a constant by exact power-of-two scaling,
+// explicit FMAs throughout -- so the three variants below give every lane the same bits whichever its wave runs (the sharded and
+// ranged tests compare across wave compositions) --, and the series constants that must sit in VGPRs passed in by the kernel.
+// MODE 1 = every active lane takes both series (no log differences, no selects), MODE 2 = no lane takes a series (no
+// polynomials), MODE 0 = per-lane selection (logmean.jl:23-27 as written).
 template <int MODE>
-__device__ __forceinline__ void ec_flux_core3(const double* qL, const double* qR, double gx, double gy, double gz, double* F, double dr,
-                                              double ravg, double db, double bavg, bool ser_r, bool ser_b) {
+__device__ __forceinline__ void ec_flux_core3(const double* qL, const double* qR, double hgx, double hgy, double hgz, double* F, double dr,
+                                              double sr, double db, double sb, bool ser_r, bool ser_b, const t2::SeriesK& sk) {
   double yr, yb;
-  if (MODE == 1) { yr = ravg; yb = bavg; }
+  if (MODE == 1) { yr = sr; yb = sb; }
   else {
     const double A = qL[5] - qR[5];
-    yr = MODE == 2 ? A : (ser_r ? ravg : A);
-    yb = MODE == 2 ? db : (ser_b ? bavg : db);
+    yr = MODE == 2 ? A : (ser_r ? sr : A);
+    yb = MODE == 2 ? db : (ser_b ? sb : db);
   }
-  const double yp = qL[4] + qR[4];
-  const double ybp = yb * yp;
+  const double ybp = yb * sb;
   const double R = rcp_refined(yr * ybp);
   const double ir = R * ybp;
   const double ryr = R * yr;
-  const double ib = ryr * yp;
+  const double ib = ryr * sb;
   const double ip = ryr * yb;
   const double fr = dr * ir;
   const double fb = db * ib;
@@ -161,34 +129,46 @@ __device__ __forceinline__ void ec_flux_core3(const double* qL, const double* qR
     rholog = -fr;
     ibetalog = -((qL[6] - qR[6]) * ib);
   } else {
-    const double vr = fr * fr, vb = fb * fb;
-    const double sr = ravg * (1 + vr * (-.2 - vr * (.0512 - vr * 0.026038857142857)));
-    const double sb = ib * (1 + vb * (.2 + vb * .0912));
-    if (MODE == 1) { rholog = sr; ibetalog = sb; }
-    else { rholog = ser_r ? sr : -fr; ibetalog = ser_b ? sb : -((qL[6] - qR[6]) * ib); }
+    const double srs = sr * t2::logmean_series_rho_h(fr * fr, sk), sbs = ib * t2::logmean_series_ibeta_2(fb * fb, sk);
+    if (MODE == 1) { rholog = srs; ibetalog = sbs; }
+    else { rholog = ser_r ? srs : -fr; ibetalog = ser_b ? sbs : -((qL[6] - qR[6]) * ib); }
   }
-  const double ua = .5 * (qL[1] + qR[1]), va = .5 * (qL[2] + qR[2]), wa = .5 * (qL[3] + qR[3]);
-  const double unorm = qL[1] * qR[1] + qL[2] * qR[2] + qL[3] * qR[3];
-  const double pa = ravg * ip;
-  const double Ep = rholog * ibetalog * (1.0 / (2 * GM1)) + pa + .5 * rholog * unorm;
-  const double un = gx * ua + gy * va + gz * wa;
+  const double su = qL[1] + qR[1], sv = qL[2] + qR[2], sw = qL[3] + qR[3];
+  const double unorm = __builtin_fma(qL[3], qR[3], __builtin_fma(qL[2], qR[2], qL[1] * qR[1]));
+  const double pa2 = sr * ip;                                                                    // 2 pa
+  const double Ep2 = __builtin_fma(rholog, __builtin_fma(ibetalog, 1.0 / GM1, unorm), pa2);      // 2 (rholog / (2 (g-1) betalog) + pa + rholog uL.uR / 2)
+  const double un = __builtin_fma(hgz, sw, __builtin_fma(hgy, sv, hgx * su));
   F[0] = rholog * un;
-  F[1] = F[0] * ua + pa * gx;
-  F[2] = F[0] * va + pa * gy;
-  F[3] = F[0] * wa + pa * gz;
-  F[4] = Ep * un;
+  const double hF0 = .5 * F[0];
+  F[1] = __builtin_fma(hF0, su, pa2 * hgx);
+  F[2] = __builtin_fma(hF0, sv, pa2 * hgy);
+  F[3] = __builtin_fma(hF0, sw, pa2 * hgz);
+  F[4] = Ep2 * (.5 * un);
 }
-__device__ __forceinline__ void ec_flux_dir_u(const double* qL, const double* qR, double gx, double gy, double gz, double* F) {
+// per-lane selection (kh_rhs, kh_rhs_g, the interface fluxes of kh_project-side checks): full metric vector in
+__device__ __forceinline__ void ec_flux_dir(const double* qL, const double* qR, double gx, double gy, double gz, double* F) {
+  const double dr = qR[0] - qL[0], sr = qR[0] + qL[0];
+  const double db = qR[4] - qL[4], sb = qR[4] + qL[4];
+  const bool ser_r = fabs(dr) < (.5 * 1e-4) * sr, ser_b = fabs(db) < (.5 * 1e-4) * sb;
+  ec_flux_core3<0>(qL, qR, .5 * gx, .5 * gy, .5 * gz, F, dr, sr, db, sb, ser_r, ser_b, t2::series_k());
+}
+
+// The branch of the two log-means decided per WAVE where the wave agrees (kh_rhs_l; as ec_flux_dir of the 2D tensor kernels): one
+// ballot per comparison -- the v_cmp's own lane mask -- and scalar logic on the masks.  HALF metric vector in.
+#ifndef ESDG_KHL_UNIFORM_LOGMEAN
+#define ESDG_KHL_UNIFORM_LOGMEAN 1   // (A/B hook: 0 = the selecting form everywhere)
+#endif
+__device__ __forceinline__ void ec_flux_dir_u(const double* qL, const double* qR, double hgx, double hgy, double hgz, double* F, const t2::SeriesK& sk) {
+  const double dr = qR[0] - qL[0], sr = qR[0] + qL[0];
+  const double db = qR[4] - qL[4], sb = qR[4] + qL[4];
+  const bool ser_r = fabs(dr) < (.5 * 1e-4) * sr, ser_b = fabs(db) < (.5 * 1e-4) * sb;
 #if ESDG_KHL_UNIFORM_LOGMEAN
-  const double dr = qR[0] - qL[0], ravg = .5 * (qR[0] + qL[0]);
-  const double db = qR[4] - qL[4], bavg = .5 * (qR[4] + qL[4]);
-  const bool ser_r = fabs(dr) < 1e-4 * ravg, ser_b = fabs(db) < 1e-4 * bavg;
-  const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
-  if (__builtin_amdgcn_ballot_w64(ser_r || ser_b) == 0) ec_flux_core3<2>(qL, qR, gx, gy, gz, F, dr, ravg, db, bavg, ser_r, ser_b);
-  else if (__builtin_amdgcn_ballot_w64(ser_r && ser_b) == active) ec_flux_core3<1>(qL, qR, gx, gy, gz, F, dr, ravg, db, bavg, ser_r, ser_b);
-  else ec_flux_core3<0>(qL, qR, gx, gy, gz, F, dr, ravg, db, bavg, ser_r, ser_b);
+  const unsigned long long active = __builtin_amdgcn_ballot_w64(true), br = __builtin_amdgcn_ballot_w64(ser_r), bb = __builtin_amdgcn_ballot_w64(ser_b);
+  if ((br | bb) == 0) ec_flux_core3<2>(qL, qR, hgx, hgy, hgz, F, dr, sr, db, sb, ser_r, ser_b, sk);
+  else if ((br & bb) == active) ec_flux_core3<1>(qL, qR, hgx, hgy, hgz, F, dr, sr, db, sb, ser_r, ser_b, sk);
+  else ec_flux_core3<0>(qL, qR, hgx, hgy, hgz, F, dr, sr, db, sb, ser_r, ser_b, sk);
 #else
-  ec_flux_dir(qL, qR, gx, gy, gz, F);
+  ec_flux_core3<0>(qL, qR, hgx, hgy, hgz, F, dr, sr, db, sb, ser_r, ser_b, sk);
 #endif
 }
 
@@ -1179,8 +1159,10 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
 
   // ---- line stage ------------------------------------------------------------------------------------------------------------
   const double* geo = sGeo + elc * HEX_GEO_STRIDE;
-  const double gx = geo[opd], gy = geo[3 + opd], gz = geo[6 + opd];
-  const double hsG = DELTA ? .5 * geo[HEX_GEO_STRIDE - 2] : 0.0, sNs = DELTA ? geo[HEX_GEO_STRIDE - 1] : 0.0;
+  // (the flux takes HALF the metric vector, ec_flux_core3: halves of the record's row and of the difference scale)
+  const double hgx = .5 * geo[opd], hgy = .5 * geo[3 + opd], hgz = .5 * geo[6 + opd];
+  const double qsG = DELTA ? .25 * geo[HEX_GEO_STRIDE - 2] : 0.0, sNs = DELTA ? geo[HEX_GEO_STRIDE - 1] : 0.0;
+  const t2::SeriesK sk = t2::series_k_pinned();
   double acc[N1][HEX_NFLD], GA[HEX_NFLD], GB[HEX_NFLD];
 #pragma unroll
   for (int i = 0; i < N1; ++i)
@@ -1206,7 +1188,7 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
       unpack3(kn, a0, a1, a2);
       nx = __builtin_fma(sNs, (double)a0, nx); ny = __builtin_fma(sNs, (double)a1, ny); nz = __builtin_fma(sNs, (double)a2, nz);
     }
-    ec_flux_dir_u(qm, qp, nx, ny, nz, G);
+    ec_flux_dir_u(qm, qp, .5 * nx, .5 * ny, .5 * nz, G, sk);
     if (ph.lf_scale != 0.0) {   // (uniform)
       double UM[HEX_NFLD], UP[HEX_NFLD];
       const double isJ = rcp_refined(sJ);
@@ -1229,16 +1211,16 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
       double qn[7], F[HEX_NFLD];
       record(slot, qn);
       double W = sTab[L.SF + (d * 2 + t) * N1 + i] * wtf;
-      if (CURVED) {   // metric of the pair = average of the two nodes (dg3D_euler_hex.jl:145-151; the .5 goes into the weight)
-        W *= .5;
-        ec_flux_dir_u(qn, qm, gfc[0] + Gl[i][0], gfc[1] + Gl[i][1], gfc[2] + Gl[i][2], F);
+      if (CURVED) {   // metric of the pair = average of the two nodes (dg3D_euler_hex.jl:145-151); the sum goes in as the HALF metric,
+        W *= .25;     // i.e. four times the half average: the factor rides in the weight
+        ec_flux_dir_u(qn, qm, gfc[0] + Gl[i][0], gfc[1] + Gl[i][1], gfc[2] + Gl[i][2], F, sk);
       } else if (DELTA) {
         int b0, b1, b2;
         unpack3(sD[opd * NV + slot], b0, b1, b2);
-        ec_flux_dir_u(qn, qm, __builtin_fma(hsG, (double)(f0 + b0), gx), __builtin_fma(hsG, (double)(f1 + b1), gy),
-                    __builtin_fma(hsG, (double)(f2 + b2), gz), F);
+        ec_flux_dir_u(qn, qm, __builtin_fma(qsG, (double)(f0 + b0), hgx), __builtin_fma(qsG, (double)(f1 + b1), hgy),
+                    __builtin_fma(qsG, (double)(f2 + b2), hgz), F, sk);
       } else {
-        ec_flux_dir_u(qn, qm, gx, gy, gz, F);
+        ec_flux_dir_u(qn, qm, hgx, hgy, hgz, F, sk);
       }
 #pragma unroll
       for (int c = 0; c < HEX_NFLD; ++c) { acc[i][c] = __builtin_fma(W, F[c], acc[i][c]); G[c] = __builtin_fma(-W, F[c], G[c]); }
@@ -1265,15 +1247,15 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
         record(sj, qj);
         double W = sTab[L.S + (d * N1 + i) * N1 + j] * wt;
         if (CURVED) {
-          W *= .5;
-          ec_flux_dir_u(qi, qj, Gl[i][0] + Gl[j][0], Gl[i][1] + Gl[j][1], Gl[i][2] + Gl[j][2], F);
+          W *= .25;
+          ec_flux_dir_u(qi, qj, Gl[i][0] + Gl[j][0], Gl[i][1] + Gl[j][1], Gl[i][2] + Gl[j][2], F, sk);
         } else if (DELTA) {   // metric of the pair = average of the two nodes: record + half the scale times the two differences
           int b0, b1, b2;
           unpack3(sD[opd * NV + sj], b0, b1, b2);
-          ec_flux_dir_u(qi, qj, __builtin_fma(hsG, (double)(a0 + b0), gx), __builtin_fma(hsG, (double)(a1 + b1), gy),
-                      __builtin_fma(hsG, (double)(a2 + b2), gz), F);
+          ec_flux_dir_u(qi, qj, __builtin_fma(qsG, (double)(a0 + b0), hgx), __builtin_fma(qsG, (double)(a1 + b1), hgy),
+                      __builtin_fma(qsG, (double)(a2 + b2), hgz), F, sk);
         } else {
-          ec_flux_dir_u(qi, qj, gx, gy, gz, F);
+          ec_flux_dir_u(qi, qj, hgx, hgy, hgz, F, sk);
         }
 #pragma unroll
         for (int c = 0; c < HEX_NFLD; ++c) { acc[i][c] = __builtin_fma(W, F[c], acc[i][c]); acc[j][c] = __builtin_fma(-W, F[c], acc[j][c]); }
