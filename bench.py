@@ -39,6 +39,12 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 fp64 lanes x 2 flop x 2.4 G
 PRACTICAL_HBM_GBS = 4700.0    # round 4: a hand-written float4 / double copy (read + write) on this pool, tools/ubench/fetch_calib.hip ->
                               # profiles/r04_fetch_calibration.txt: 4.6-4.8 TB/s; read-only streams 6.2, write-only 6.5-6.9 (round 3
                               # used a torch copy_ measured at 5.3 on other boxes of the pool)
+# Read- and write-only streams on the same boxes (profiles/r04_fetch_calibration.txt): a kernel's HBM floor uses a rate weighted
+# by ITS read share f = reads / (reads + writes), piecewise linear through the three calibrated points f = 0 (write-only), 0.5
+# (the copy), 1 (read-only) -- the plain copy rate made a stream that is 84 % reads look memory-bound when it is not
+READ_ONLY_HBM_GBS = 6200.0
+WRITE_ONLY_HBM_GBS = 6700.0   # 6.5-6.9 measured
+NORTH_STAR_TARGET_FRAC = 0.40  # BASELINE.json: ">= 40 % of MI355X fp64 HBM roofline" on cfg3 (whole RHS, algorithmic bytes)
 MEASURED_FP64_TFLOPS = 66.5
 VALU_CYCLES_PER_INST = 4.7    # measured issue cost of one fp64 wave-instruction per SIMD (tools/ubench/fma64.hip, 4 waves x 8 chains)
 N_SIMD = 1024                 # 256 CUs x 4
@@ -201,6 +207,54 @@ def cpu_baseline(N, formulation, lf, rd, md, ops, Q, hexw):
             "rhs_evals_per_s": 1.0 / med,
             "all_cores": {"value": dof / float(np.median(tm)), "cores": nthr, "ms_per_eval": float(np.median(tm)) * 1e3,
                           "evals": len(tm)}}
+
+
+def mix_rate_gbs(read_bytes, write_bytes):
+    """Practical HBM rate for a stream with the given read / write mix (see READ_ONLY_HBM_GBS above)."""
+    tot = float(read_bytes) + float(write_bytes)
+    if tot <= 0:
+        return PRACTICAL_HBM_GBS
+    f = float(read_bytes) / tot
+    if f >= 0.5:
+        return PRACTICAL_HBM_GBS + (READ_ONLY_HBM_GBS - PRACTICAL_HBM_GBS) * (f - 0.5) / 0.5
+    return WRITE_ONLY_HBM_GBS + (PRACTICAL_HBM_GBS - WRITE_ONLY_HBM_GBS) * f / 0.5
+
+
+GATHER_OVERFETCH = 1.6   # neighbour-trace gathers: 160-byte runs inside 640-byte blocks fetch two 128-byte lines per run
+                         # (profiles/r04_fetch_calibration.txt, trace_nbr32 0.800 of the x2-corrected FETCH_SIZE)
+
+
+def design_bytes(formulation, Np, Nfq, hexw=False, hex_delta=False):
+    """Design bytes per element and evaluation, by array family and phase: what every phase reads (r) and writes (w) once, no
+    cache reuse assumed; `g` marks the reads that are neighbour gathers (counted x GATHER_OVERFETCH in `with_overfetch`).
+    DESIGN.md sections 3-4 (quads), 9 (hexahedra)."""
+    if hexw:
+        ph = [{"Q": ("r", 40 * Np), "A_U": ("w", 40 * Nfq)},
+              {"Q": ("r", 40 * Np), "A_U": ("r", 40 * Nfq), "A_U(nbr)": ("g", 40 * Nfq), "rhs": ("w", 40 * Np),
+               "geometry+mapP": ("r", 36 * 8 + 8 * Nfq + ((12 * Np + 8 * Nfq) if hex_delta else 0))}]
+    elif formulation == "cns":
+        ph = [{"Q": ("r", 32 * Np), "A_U": ("w", 32 * Nfq)},
+              {"Q": ("r", 32 * Np), "A_U(nbr)": ("g", 32 * Nfq), "SG": ("w", 24 * Np), "B": ("w", 24 * Nfq),
+               "geometry+mapP": ("r", 17 * 8 + 4 * Nfq + 8 * Nfq)},
+              {"Q": ("r", 32 * Np), "A_U": ("r", 32 * Nfq), "A_U(nbr)": ("g", 32 * Nfq), "SG": ("r", 24 * Np), "B": ("r", 24 * Nfq),
+               "B(nbr)": ("g", 24 * Nfq), "rhs": ("w", 32 * Np), "geometry+mapP": ("r", 17 * 8 + 4 * Nfq + 8 * Nfq)}]
+    else:
+        ph = [{"Q": ("r", 32 * Np), "A_U": ("w", 32 * Nfq)},
+              {"Q": ("r", 32 * Np), "A_U": ("r", 32 * Nfq), "A_U(nbr)": ("g", 32 * Nfq), "rhs": ("w", 32 * Np),
+               "geometry+mapP": ("r", 17 * 8 + 4 * Nfq + 8 * Nfq)}]
+    fam = {}
+    per_phase = []
+    for d in ph:
+        r = sum(b for k, (m, b) in d.items() if m in "rg")
+        w = sum(b for k, (m, b) in d.items() if m == "w")
+        g = sum(b for k, (m, b) in d.items() if m == "g")
+        per_phase.append({"read": r, "write": w, "gathered": g, "with_overfetch": r + w + (GATHER_OVERFETCH - 1.0) * g})
+        for k, (m, b) in d.items():
+            name = k.replace("(nbr)", "")
+            e = fam.setdefault(name, {"read": 0.0, "write": 0.0, "with_overfetch": 0.0})
+            e["write" if m == "w" else "read"] += b
+            e["with_overfetch"] += b * (GATHER_OVERFETCH if m == "g" else 1.0)
+    return fam, per_phase
 
 
 def kernel_source_hash():
@@ -511,9 +565,9 @@ def run(args):
     pmc_stale = None
     rec = {}
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    key = f"hex_N{N}_{Kx}x{Kx}x{args.kz_per_gpu}" if hexw else f"{args.formulation}_N{N}_{Kx}x{kyr}"
     if os.path.exists(pmc):
         try:
-            key = f"hex_N{N}_{Kx}x{Kx}x{args.kz_per_gpu}" if hexw else f"{args.formulation}_N{N}_{Kx}x{kyr}"
             rec = json.load(open(pmc)).get(key, {})
             pmc_stale = bool(rec) and rec.get("kernel_src_sha") != kernel_source_hash()
             if rec and not pmc_stale:
@@ -535,42 +589,71 @@ def run(args):
     # Bytes: the PMC traffic of this command where the committed profile is current, else the design bytes per element
     # (what each phase reads and writes once, no cache reuse assumed).
     Nfq_ = eng.Nfq if hasattr(eng, "Nfq") else (6 * (N + 1) ** 2 if hexw else 4 * (N + 1))
-    if hexw:
-        design_k = 80.0 * Np + 80.0 * Nfq_                        # Q r + rhs w, own + neighbour trace (5 doubles per node)
-        if args.hex_geometry == "per-node" and not args.hex_curve:
-            design_k += 12.0 * Np + 8.0 * Nfq_                    # 10-bit geometry differences: 3 words per volume node, 2 per face node
-        design_whole = design_k + 40.0 * Np + 40.0 * Nfq_         # + phase 0: Q r, trace w
-    elif args.formulation == "cns":
-        # Q, rhs | A_U own+nbr (32-B records) | SG | B own+nbr | per-node normal differences
-        design_k = 64.0 * Np + 64.0 * Nfq_ + 24.0 * Np + 48.0 * Nfq_ + 8.0 * Nfq_
-        # + phase 0 (Q r, A_U w) + phase 1 (Q r, A_U nbr r, SG w, B w, normal differences)
-        design_whole = design_k + (32.0 * Np + 32.0 * Nfq_) + (32.0 * Np + 32.0 * Nfq_ + 24.0 * Np + 24.0 * Nfq_ + 8.0 * Nfq_)
+    fam, per_phase = design_bytes(args.formulation, Np, Nfq_, hexw, hexw and args.hex_geometry == "per-node" and not args.hex_curve)
+    design_k = per_phase[-1]["read"] + per_phase[-1]["write"]
+    design_whole = sum(p_["read"] + p_["write"] for p_ in per_phase)
+    # reads / writes of the dominant kernel and of the evaluation: PMC (x2-corrected FETCH_SIZE, WRITE_SIZE) where current
+    kern = (rec.get("kernels") or {}) if (rec and not pmc_stale) else {}
+    krec = next((v for k_, v in kern.items() if "_rhs<" in k_ or "_rhs_l<" in k_), None)
+    if krec:
+        rd_k, wr_k = krec["fetch_bytes_x2"], krec["write_bytes"]
+        mains = [v for k_, v in kern.items() if any(t in k_ for t in ("project", "sigma", "_rhs"))]
+        rd_w, wr_w = sum(v["fetch_bytes_x2"] for v in mains), sum(v["write_bytes"] for v in mains)
     else:
-        design_k = 64.0 * Np + 64.0 * Nfq_ + 8.0 * Nfq_
-        design_whole = design_k + 32.0 * Np + 32.0 * Nfq_
-    bytes_k = traffic if traffic else design_k * K_local
-    bytes_whole = whole_traffic if whole_traffic else design_whole * K_local
+        rd_k, wr_k = per_phase[-1]["read"] * K_local, per_phase[-1]["write"] * K_local
+        rd_w, wr_w = sum(p_["read"] for p_ in per_phase) * K_local, sum(p_["write"] for p_ in per_phase) * K_local
+    bytes_k, bytes_whole = rd_k + wr_k, rd_w + wr_w
+    rate_k, rate_whole = mix_rate_gbs(rd_k, wr_k), mix_rate_gbs(rd_w, wr_w)
     whole_flops = rec.get("whole_rhs_fp64_flops") if (rec and not pmc_stale) else None
+    # compute-only time (every global address folded into an L2-resident window, same instruction stream: tools/compute_only.sh ->
+    # profiles/compute_only.json; valid for the kernel sources it was measured on)
+    compute_only = None
+    cof = os.path.join(ROOT, "profiles", "compute_only.json")
+    if os.path.exists(cof):
+        try:
+            c_ = json.load(open(cof)).get(key, {})
+            if c_.get("kernel_src_sha") == kernel_source_hash():
+                compute_only = c_.get("phase_ms")
+        except Exception:
+            pass
     # compute-side floor: ALL vector instructions the kernel issues (SQ_INSTS_VALU: fp64 arithmetic, logs, reciprocals, selects,
     # integer and address work alike) at the measured issue cost of one wave-instruction per SIMD -- the fp64-flop floor alone
     # ignored a quarter of the instruction stream
     def _issue_ms(n):
         return None if not n else n * VALU_CYCLES_PER_INST / (N_SIMD * SCLK_HZ) * 1e3
-    floors = {"hbm_kernel": bytes_k / (PRACTICAL_HBM_GBS * 1e9) * 1e3,
+    floors = {"hbm_kernel": bytes_k / (rate_k * 1e9) * 1e3,
+              "hbm_kernel_at_copy_rate": bytes_k / (PRACTICAL_HBM_GBS * 1e9) * 1e3,
               "fp64_kernel": None if not fp64_flops else fp64_flops / (MEASURED_FP64_TFLOPS * 1e12) * 1e3,
               "valu_issue_kernel": _issue_ms(insts_k),
-              "hbm_whole_rhs": bytes_whole / (PRACTICAL_HBM_GBS * 1e9) * 1e3,
+              "hbm_whole_rhs": bytes_whole / (rate_whole * 1e9) * 1e3,
+              "hbm_whole_rhs_at_copy_rate": bytes_whole / (PRACTICAL_HBM_GBS * 1e9) * 1e3,
               "fp64_whole_rhs": None if not whole_flops else whole_flops / (MEASURED_FP64_TFLOPS * 1e12) * 1e3,
               "valu_issue_whole_rhs": _issue_ms(insts_whole),
-              "bytes_basis": "pmc" if traffic else "design"}
+              "bytes_basis": "pmc" if krec else "design",
+              "mix_rate_gbs": {"kernel": rate_k, "whole_rhs": rate_whole, "read_share_kernel": rd_k / max(bytes_k, 1.0),
+                               "read_share_whole_rhs": rd_w / max(bytes_whole, 1.0),
+                               "calibration": {"read_only": READ_ONLY_HBM_GBS, "copy": PRACTICAL_HBM_GBS, "write_only": WRITE_ONLY_HBM_GBS}}}
+    bytes_by_array = {
+        "unit": "bytes per element and evaluation",
+        "design": {k_: v for k_, v in sorted(fam.items())},
+        "design_by_phase": per_phase,
+        "design_total": design_whole, "design_total_with_gather_overfetch": sum(p_["with_overfetch"] for p_ in per_phase),
+        "gather_overfetch": GATHER_OVERFETCH,
+        # PMC can be split by kernel and direction, not by array: x2-corrected FETCH_SIZE and WRITE_SIZE per kernel
+        "pmc_by_kernel": None if not kern else {k_.replace("esdg::", ""): {"read": v["fetch_bytes_x2"] / K_local, "write": v["write_bytes"] / K_local}
+                                                 for k_, v in kern.items() if any(t in k_ for t in ("project", "sigma", "_rhs"))},
+        "pmc_total": None if not kern else bytes_whole / K_local,
+        "algorithmic": 16.0 * nfld * Np}
 
     def _bound(h, f):
         # no counted instruction stream for this build (stale or absent PMC file): no claim
         return None if f is None else ("hbm" if h >= f else "valu-issue")
+    whole_alg_frac = (alg_bytes * evals_per_s / 1e9) / HBM_PEAK_GBS
     roofline = {
-        # `bound`: the larger floor of the dominant kernel (see floors_ms); `frac` stays the HBM figure the north star names
-        # (algorithmic bytes / kernel time / 8 TB/s), `valu_frac` the counted fp64 flops of the same kernel against the fp64
-        # vector peak; `whole_rhs_bound` the same comparison over all phases of one evaluation
+        # `bound`: the larger floor of the dominant kernel (see floors_ms: HBM floor = PMC bytes at the rate its own read / write mix
+        # reaches on this pool; VALU-issue floor = all vector instructions at the measured issue cost); `frac` stays the HBM figure
+        # the north star names (algorithmic bytes / kernel time / 8 TB/s), `valu_frac` the counted fp64 flops of the same kernel
+        # against the fp64 vector peak; `whole_rhs_bound` the same comparison over all phases of one evaluation
         "bound": _bound(floors["hbm_kernel"], floors["valu_issue_kernel"]), "kernel": kname,
         "whole_rhs_bound": _bound(floors["hbm_whole_rhs"], floors["valu_issue_whole_rhs"]),
         # measured time over each floor (1 = at the floor)
@@ -578,11 +661,22 @@ def run(args):
                               "valu_issue": None if not floors["valu_issue_kernel"] else kdur_ms / floors["valu_issue_kernel"]},
         "floors_ms": floors, "practical_hbm_gbs": PRACTICAL_HBM_GBS, "measured_fp64_tflops": MEASURED_FP64_TFLOPS,
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": traffic, "kernel_ms": kdur_ms, "phase_ms": phase_ms,
+        "traffic": traffic,
+        "traffic_note": "FETCH_SIZE x2 + WRITE_SIZE per launch (rocprofv3 --pmc, separate passes): requests that reach the fabric, "
+                        "Infinity-Cache hits included -- an upper bound on HBM bytes, not HBM bytes",
+        "kernel_ms": kdur_ms, "phase_ms": phase_ms,
+        # every phase with the memory system taken out (addresses folded into an L2-resident window; null when not measured on
+        # these kernel sources): what is left of a phase when HBM costs nothing
+        "compute_only_ms": None if not compute_only else compute_only[-1], "compute_only_phase_ms": compute_only,
         # the same kernel's average under rocprofv3 --kernel-trace --stats (committed profile of this command)
         "kernel_ms_rocprofv3": None if prof_us is None else prof_us / 1e3,
-        "whole_rhs_frac": (alg_bytes * evals_per_s / 1e9) / HBM_PEAK_GBS,
+        "whole_rhs_frac": whole_alg_frac,
+        # what the algorithm's counted fp64 work allows: algorithmic bytes / (counted fp64 flops at 100 % of the vector peak) /
+        # 8 TB/s -- the north star's 0.40 lies above it, so valu_frac / bytes per element are the bars that can move
+        "whole_rhs_fp64_ceiling_frac": None if not whole_flops else (alg_bytes / (whole_flops / (FP64_VALU_PEAK_TFLOPS * 1e12)) / 1e9) / HBM_PEAK_GBS,
+        "north_star_target_frac": NORTH_STAR_TARGET_FRAC,
         "whole_rhs_traffic": whole_traffic,
+        "bytes_by_array": bytes_by_array,
         "valu_peak_tflops": FP64_VALU_PEAK_TFLOPS, "fp64_flops_per_launch": fp64_flops, "valu_frac": valu_frac,
         "whole_rhs_valu_frac": whole_valu_frac, "pmc_stale": pmc_stale, "kernel_src_sha": kernel_source_hash()}
 
