@@ -1316,7 +1316,7 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
 }  // namespace hdev
 
 // N1 = 2 ... 4: one wavefront per element (kh_project / kh_rhs); N1 = 5 ... 8: one workgroup per element (kh_*_g)
-bool hex_supported_degree(int N1) { return N1 >= 2 && N1 <= 8; }
+bool hex_supported_degree(int N1) { return N1 >= 2 && N1 <= 10; }
 
 #define ESDG_HEX_DISPATCH(N1v, STMT)   \
   switch (N1v) {                        \
@@ -1333,6 +1333,18 @@ bool hex_supported_degree(int N1) { return N1 >= 2 && N1 <= 8; }
     case 8: { constexpr int N1 = 8; STMT; } break; \
     default: return (int)hipErrorInvalidValue;     \
   }
+// (phase 0 goes two degrees further than the row-wise kh_rhs_g, whose curved instantiation would need 200 KB of LDS at N1 = 9: the
+// last phase of N1 = 9, 10 is kh_rhs_l only)
+#define ESDG_HEXP_DISPATCH(N1v, STMT)  \
+  switch (N1v) {                        \
+    case 5: { constexpr int N1 = 5; STMT; } break; \
+    case 6: { constexpr int N1 = 6; STMT; } break; \
+    case 7: { constexpr int N1 = 7; STMT; } break; \
+    case 8: { constexpr int N1 = 8; STMT; } break; \
+    case 9: { constexpr int N1 = 9; STMT; } break; \
+    case 10: { constexpr int N1 = 10; STMT; } break; \
+    default: return (int)hipErrorInvalidValue;     \
+  }
 
 static inline unsigned hex_grid(int64_t K, bool remap) {
   const int64_t nblk = (K + hdev::HNWV - 1) / hdev::HNWV;
@@ -1345,7 +1357,7 @@ int launch_project_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phy
   if (M.e_count <= 0) return 0;
   const int remap = (ph.dbg & 16) ? 0 : 1;
   if (N1v > 4) {
-    ESDG_HEXG_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_project_g<N1>), dim3((unsigned)M.e_count), dim3(hdev::GCfg<N1>::T), 0, s, HT, M, Q, A_U));
+    ESDG_HEXP_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_project_g<N1>), dim3((unsigned)M.e_count), dim3(hdev::GCfg<N1>::T), 0, s, HT, M, Q, A_U));
     return (int)hipGetLastError();
   }
   ESDG_HEX_DISPATCH(N1v, hipLaunchKernelGGL((hdev::kh_project<N1>), dim3(hex_grid(M.e_count, remap)), dim3(hdev::HW * hdev::HNWV), 0, s, HT, M, remap, Q, A_U));
@@ -1371,7 +1383,7 @@ int launch_rhs_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phys& p
     else hipLaunchKernelGGL((hdev::kh_rhs_l<N1c, 0>), grid, blk, 0, s, HT, M, ph, Q, A_U, rhs, lf);                          \
   } break;
       switch (N1v) {
-        ESDG_HEXL_LAUNCH(2) ESDG_HEXL_LAUNCH(3) ESDG_HEXL_LAUNCH(4) ESDG_HEXL_LAUNCH(5) ESDG_HEXL_LAUNCH(6) ESDG_HEXL_LAUNCH(7) ESDG_HEXL_LAUNCH(8)
+        ESDG_HEXL_LAUNCH(2) ESDG_HEXL_LAUNCH(3) ESDG_HEXL_LAUNCH(4) ESDG_HEXL_LAUNCH(5) ESDG_HEXL_LAUNCH(6) ESDG_HEXL_LAUNCH(7) ESDG_HEXL_LAUNCH(8) ESDG_HEXL_LAUNCH(9) ESDG_HEXL_LAUNCH(10)
         default: return (int)hipErrorInvalidValue;
       }
 #undef ESDG_HEXL_LAUNCH

@@ -883,9 +883,9 @@ typedef struct {
 
 /* sparse_hadamard_sum, dg3D_euler_hex.jl:122-164 (metric of a pair = average of the two nodes, :145-146) */
 static void sparse_hadamard_sum_hex(const oracle_hex_t* c, const real* Qhe /*[5][Nh]*/, const real* ge /*[9][Nh]*/,
-                                    real* out /*[5][Nh]*/) {
+                                    real* out /*[5][Nh] + 2 Nh of scratch*/) {
   const int Nh = c->Nq + c->Nfq;
-  real lrho[1024], lbeta[1024];   /* Nh <= 1024: degrees N <= 7 (checked in hex_rhs_r) */
+  real *lrho = out + 5 * Nh, *lbeta = out + 6 * Nh;   /* scratch behind the result: the caller's buffer is [5 + 2][Nh] (any degree) */
   for (int i = 0; i < Nh; ++i) {
     lrho[i] = R_(log)(Qhe[i]);
     lbeta[i] = R_(log)(Qhe[4 * Nh + i]);
@@ -914,7 +914,6 @@ static void sparse_hadamard_sum_hex(const oracle_hex_t* c, const real* Qhe /*[5]
 static real hex_rhs_r(const oracle_hex_t* c, const real* Q, int compute_rhstest, real* rhs) {
   const int K = c->K, Nq = c->Nq, Nfq = c->Nfq, Nh = Nq + Nfq;
   const size_t KNq = (size_t)K * Nq, KNf = (size_t)K * Nfq, KNh = (size_t)K * Nh;
-  if (Nh > 1024) return NAN;
   real* VU = (real*)malloc(5 * KNq * sizeof(real));
   real* VUf = (real*)malloc(5 * KNf * sizeof(real));
   real* Uf = (real*)malloc(5 * KNf * sizeof(real));
@@ -980,7 +979,7 @@ static real hex_rhs_r(const oracle_hex_t* c, const real* Q, int compute_rhstest,
   /* :200-210 volume loop */
 #pragma omp parallel for num_threads(g_threads) schedule(static)
   for (int e = 0; e < K; ++e) {
-    real* Qhe = (real*)malloc((size_t)(5 + 9 + 5) * Nh * sizeof(real));
+    real* Qhe = (real*)malloc((size_t)(5 + 9 + 5 + 2) * Nh * sizeof(real));   /* + 2 Nh: logs of the element's hybrid nodes */
     real* ge = Qhe + 5 * Nh;
     real* QFe = ge + 9 * Nh;
     for (int f = 0; f < 5; ++f)

@@ -22,7 +22,8 @@ def _gpu_rhs(eng, Q):
 
 
 # (N >= 4: more than one wavefront of Gauss nodes per element -> the degree-generic kernels kh_project_g / kh_rhs_g)
-@pytest.mark.parametrize("N,K3", [(3, (4, 4, 4)), (3, (5, 3, 2)), (2, (3, 4, 5)), (1, (4, 3, 3)), (4, (3, 2, 2)), (5, (2, 2, 3)), (6, (2, 2, 2)), (7, (2, 2, 2))])
+@pytest.mark.parametrize("N,K3", [(3, (4, 4, 4)), (3, (5, 3, 2)), (2, (3, 4, 5)), (1, (4, 3, 3)), (4, (3, 2, 2)), (5, (2, 2, 3)), (6, (2, 2, 2)), (7, (2, 2, 2)),
+                                  (8, (2, 2, 2)), (9, (2, 2, 2))])   # (N = 8, 9: round 5, kh_project_g + kh_rhs_l; one element per workgroup)
 @pytest.mark.parametrize("lf", [0.0, 0.25])
 def test_hex_matches_oracle(eng_mod, oracle_lib, N, K3, lf):
     from oracle import oracle as orc
