@@ -10,7 +10,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["csrc/esdg_kernels.hip", "csrc/esdg_kernels_tensor.hip", "csrc/esdg_kernels_tensor2.hip", "csrc/esdg_kernels_tensor3.hip", "csrc/esdg_kernels_hex.hip", "csrc/esdg_kernels_err.hip",
+SOURCES = ["csrc/esdg_kernels.hip", "csrc/esdg_kernels_tensor2.hip", "csrc/esdg_kernels_tensor3.hip", "csrc/esdg_kernels_hex.hip", "csrc/esdg_kernels_err.hip",
            "csrc/esdg_api.hip", "csrc/esdg_setup.cpp"]
 HEADERS = ["csrc/esdg_dev.hpp", "csrc/esdg_devmath.hpp", "csrc/esdg_t2_physics.hpp", "csrc/esdg_tensor_tables.hpp", "csrc/esdg_hex_tables.hpp",
            "../include/esdg_hip.h"]

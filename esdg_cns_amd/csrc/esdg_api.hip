@@ -556,10 +556,8 @@ struct esdg_ctx {
   bool use_fast = false;
   bool bf = false;         // trace buffers laid out by mesh face (MeshDev::bf): 2D contexts whose phases all run v2 / v3 kernels;
                            // ESDG_TRACE_LAYOUT=face in the environment: on (A/B; measured slower, off by default)
-  bool force_linear = false;   // ... switched off for the calls that mix in a round-1 kernel (esdg_viscous_entropy_test)
+  double* vt_partial = nullptr;   // set by esdg_viscous_entropy_test around its phase-1 call: kt2_sigma also reduces visc_test
   int v2 = 0;              // ESDG_V2=1 | rhs in the environment: the v2 kernel where a v3 kernel exists (A/B; bit 1: last phase)
-  int v1 = 0;              // ESDG_V1=1 in the environment: round-1 tensor kernels only (A/B against esdg_kernels_tensor2.hip);
-                           // ESDG_V1=sigma / ESDG_V1=rhs: for that phase only (bit 0: phase 1, bit 1: last phase)
   int dim = 2, nfld = 4;   // 3 / 5 on the hexahedral path
   HexTables HT{};
   int au_nc = AU_NC;
@@ -754,7 +752,6 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   c->ph.dbg = 0;
   if (const char* env = getenv("ESDG_DBG")) c->ph.dbg = atoi(env);
   if (const char* env = getenv("ESDG_V2")) c->v2 = env[0] == '1' ? 7 : env[0] == 'r' ? 2 : env[0] == 's' ? 1 : 0;
-  if (const char* env = getenv("ESDG_V1")) c->v1 = env[0] == '1' ? 7 : env[0] == 's' ? 1 : env[0] == 'r' ? 2 : env[0] == 'p' ? 4 : env[0] == 'w' ? 8 : 0;
 
   // ---- collocated sparse operators -------------------------------------------------------
   Mat EfD, PhC, LfC, DrC, DsC, Vq, Pq;
@@ -918,7 +915,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   // kernel before), not by HBM.  Off unless ESDG_TRACE_LAYOUT=face.
   c->bf = false;
   if (const char* env = getenv("ESDG_TRACE_LAYOUT"))
-    c->bf = env[0] == 'f' && use_fast && c->v1 == 0 && !c->ph.dbg && N1 >= 2 && N1 <= ESDG_MAX_N1 && (int64_t)K * Nfq < ((int64_t)1 << 31);
+    c->bf = env[0] == 'f' && use_fast && !c->ph.dbg && N1 >= 2 && N1 <= ESDG_MAX_N1 && (int64_t)K * Nfq < ((int64_t)1 << 31);
   if (c->bf) {
     const int64_t KF = (int64_t)K * Nfq, KN1 = (int64_t)K * N1;
     auto slot = [&](int32_t n) -> int32_t {
@@ -1334,10 +1331,6 @@ int esdg_bind_workspace(esdg_ctx* ctx, void* dev_ptr, size_t bytes) {
 int esdg_num_phases(const esdg_ctx* ctx) { return ctx ? ctx->nphases : 0; }
 int esdg_uses_tensor_kernels(const esdg_ctx* ctx) { return ctx ? (int)ctx->use_fast : 0; }
 
-static bool v2_on_walls(const esdg_ctx* ctx) {
-  return (ctx->v1 & ~4) == 0 && !ctx->ph.dbg && ctx->T.N1 >= 2 && ctx->T.N1 <= ESDG_MAX_N1;   // (bit 4 = phase 0 only)
-}
-
 static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs, const LsrkFuse& lf, void* stream,
                           int64_t e_begin = 0, int64_t e_count = -1, int role = 0) {
   if (!ctx || !Q) return fail(ESDG_ERR_ARG, "null argument");
@@ -1353,7 +1346,7 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
     ~RangeGuard() { M.e_begin = 0; M.e_count = K; M.launch_role = 0; M.mapP = mapP; M.bf = 0; }
   } rg{ctx->M, ctx->K, ctx->M.mapP};
   if (ranged) { ctx->M.e_begin = e_begin; ctx->M.e_count = e_count; ctx->M.launch_role = role; }
-  const bool bf = ctx->bf && !ctx->force_linear;   // traces by mesh face: the kernels below see slots in mapP
+  const bool bf = ctx->bf;   // traces by mesh face: the kernels below see slots in mapP
   if (bf) { ctx->M.mapP = ctx->d_mapP_s.as<int32_t>(); ctx->M.bf = 1; }
   if (!ctx->ws) return fail(ESDG_ERR_STATE, "workspace not bound (esdg_bind_workspace)");
   if (phase < 0 || phase >= ctx->nphases) return fail(ESDG_ERR_ARG, "bad phase %d", phase);
@@ -1374,23 +1367,14 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
       rc = launch_rhs_hex(ctx->T.N1, ctx->HT, ctx->M, ctx->ph, Q, A_U, rhs, lf, s);
     }
   } else if (phase == 0) {
-    rc = -1;
-    if (ctx->use_fast && !(ctx->v1 & 4))   // v2 kernel (ESDG_V1=1 / ESDG_V1=project: the round-1 kt_project, A/B)
-      rc = launch_project_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, s);
-    if (rc == -1)
-      rc = ctx->use_fast ? launch_project_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, A_v, s)
-                         : launch_project(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, s);
+    rc = ctx->use_fast ? launch_project_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, s)
+                       : launch_project(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, s);
+    if (rc == -1) return fail(ESDG_ERR_STATE, "no phase-0 kernel at N=%d", ctx->T.N1 - 1);
   } else if (visc && phase == 1) {
-    // v2 kernel (the visc_test reduction stays with kt_sigma); ESDG_V1=1: A/B.  On meshes with walls the two viscous phases
-    // must come from the same set (kt_sigma stores sigma for kt_rhs, kt2_sigma the volume divergence and, at boundary
-    // nodes, minus the prescribed stress jump for kt2_rhs): v2 only if neither phase is forced to v1; ESDG_V1=walls: v1 there
     // (a v3 phase-1 kernel -- one wave per workgroup, line per lane like kt3_rhs -- was built and measured in round 4: correct,
     // 0.240 vs 0.185 ms; commit 1e0619c, profiles/experiments/README.md)
-    if (ctx->use_fast && (ctx->M.bc ? v2_on_walls(ctx) : !(ctx->v1 & 1)))
-      rc = launch_sigma_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, SG, s);
-    else
-      rc = ctx->use_fast ? launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, SG, nullptr, s)
-                         : launch_sigma(ctx->T, ctx->M, ctx->ph, Q, A_v, B, s);
+    rc = ctx->use_fast ? launch_sigma_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, SG, s, ctx->vt_partial)
+                       : launch_sigma(ctx->T, ctx->M, ctx->ph, Q, A_v, B, s);
   } else {
     if (!rhs && !lf.Qw) return fail(ESDG_ERR_ARG, "rhs output is null");
     if (lf.Qw && !ctx->use_fast) return fail(ESDG_ERR_STATE, "the fused RK update needs the tensor kernels");
@@ -1399,7 +1383,7 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
     // the viscous phase must be the v2 one there; ESDG_V2=rhs: the v2 kernel (A/B)
     // (ESDG_DBG bit 32: kt3_rhs takes every logarithm whatever the state -- the partner of the bitwise test of its data-dependent
     // short cut, tests/test_gpu_engine.py)
-    if (ctx->use_fast && !(ctx->ph.dbg & ~32) && !(ctx->v1 & 2) && !(ctx->v2 & 2) && (!ctx->M.bc || v2_on_walls(ctx))) {
+    if (ctx->use_fast && !(ctx->v2 & 2)) {
       LsrkFuse lfe = lf;
       if (ctx->emit_next && lf.Qw && !ranged)   // (esdg_lsrk45_step: the next stage's traces into the buffer not being read)
         lfe.AUn = reinterpret_cast<double*>(ctx->ws + (ctx->au_sel ? ctx->off_AU : ctx->off_AU2));
@@ -1416,14 +1400,11 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
       if (rc == -1 && lfe.AUn) return fail(ESDG_ERR_STATE, "stage fusion asked of a context the v3 last-phase kernel does not serve");
     }
     if (rc == -1 && ctx->stage_fuse) return fail(ESDG_ERR_STATE, "DOPRI45 stage fusion asked of a context the v3 last-phase kernel does not serve");
-    if (rc == -1 && ctx->use_fast && !(ctx->ph.dbg & ~32) && (ctx->M.bc ? v2_on_walls(ctx) : !(ctx->v1 & 2)))      // v2 kernel: N1 = N + 1 = 2 ... 8
+    if (rc == -1 && ctx->use_fast)      // v2 kernel (N1 = 2 ... 9): wall meshes from N1 = 8 on, and the A/B partner of kt3_rhs (ESDG_V2=rhs)
       rc = launch_rhs_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s);
-    if (rc == -1 && !supported_degree(ctx->T.N1))
-      return fail(ESDG_ERR_STATE, "no last-phase kernel for this configuration at N=%d (ESDG_V1 / ESDG_V2 / ESDG_DBG select kernels that stop at N=7 or 8)",
-                  ctx->T.N1 - 1);
-    if (rc == -1)
-      rc = ctx->use_fast ? launch_rhs_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s)
-                         : launch_rhs(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, B, rhs, s);
+    if (rc == -1 && ctx->use_fast)
+      return fail(ESDG_ERR_STATE, "no last-phase kernel for this configuration at N=%d (kt2_rhs, which ESDG_V2=rhs selects, stops at N=8)", ctx->T.N1 - 1);
+    if (rc == -1) rc = launch_rhs(ctx->T, ctx->M, ctx->ph, Q, A_U, A_v, B, rhs, s);
   }
   // pack what this phase produced for the off-rank neighbours (ranged launches leave that to esdg_halo_pack)
   if (!rc && ctx->nsend && !ranged)
@@ -1476,7 +1457,7 @@ int esdg_halo_pack(esdg_ctx* ctx, int xch, void* stream) {
   if (!ctx->ws) return fail(ESDG_ERR_STATE, "workspace not bound (esdg_bind_workspace)");
   if (!ctx->nsend) return ESDG_OK;
   const Exchange& x = ctx->xch[xch];
-  const bool bf = ctx->bf && !ctx->force_linear;
+  const bool bf = ctx->bf;
   int rc = launch_pack(reinterpret_cast<const double*>(ctx->ws + x.buf_off), x.ncomp,
                        bf ? ctx->d_sendlist_s.as<int32_t>() : ctx->d_sendlist.as<int32_t>(), ctx->nsend,
                        reinterpret_cast<double*>(ctx->ws + x.send_off), static_cast<hipStream_t>(stream));
@@ -1757,16 +1738,11 @@ int esdg_set_parts(esdg_ctx* ctx, int parts) {
 int esdg_viscous_entropy_test(esdg_ctx* ctx, const double* Q, double* out, void* stream) {
   if (!ctx || !Q || !out) return fail(ESDG_ERR_ARG, "null argument");
   if (ctx->dim != 2 || ctx->nphases != 3 || !ctx->use_fast) return fail(ESDG_ERR_STATE, "needs a CNS context on the tensor kernels");
-  if (!supported_degree(ctx->T.N1))
-    return fail(ESDG_ERR_STATE, "the visc_test diagnostic runs on the round-1 phase-1 kernel, which stops at N=7 (this context: N=%d)", ctx->T.N1 - 1);
   if (ctx->nghost && !ctx->comm)
     return fail(ESDG_ERR_STATE, "esdg_viscous_entropy_test on a sharded mesh needs the library's communicator (esdg_comm_init)");
   if (!ctx->M.wJq) return fail(ESDG_ERR_STATE, "wJq was not supplied at esdg_create");
   if (!ctx->ws) return fail(ESDG_ERR_STATE, "workspace not bound (esdg_bind_workspace)");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // (phase 1 below is the round-1 kt_sigma, which reads the linear trace layout: phase 0 and its pack write that one here)
-  struct LinearGuard { esdg_ctx* c; ~LinearGuard() { c->force_linear = false; } } lg{ctx};
-  ctx->force_linear = true;
   int rc = esdg_rhs_phase(ctx, 0, Q, nullptr, stream);   // (packs what the neighbours need)
   if (rc) return rc;
   if (ctx->nghost) {   // sharded: the neighbours' traces of phase 0, then this rank's share of the sum (like esdg_rhstest)
@@ -1774,15 +1750,15 @@ int esdg_viscous_entropy_test(esdg_ctx* ctx, const double* Q, double* out, void*
     if ((rc = post_exchanges(ctx, 0, s)) != 0) return rc;
     if ((rc = wait_exchanges(ctx, 1, s)) != 0) return rc;
   }
-  const int nb = sigma_tensor_blocks(ctx->T.N1, ctx->K);
+  // phase 1 (kt2_sigma) with its visc_test reduction switched on: one partial per workgroup of the persistent launch
   DevBuf part;
-  if ((rc = part.alloc(sizeof(double) * (size_t)nb)) != 0) return rc;
-  double* A_U = reinterpret_cast<double*>(ctx->ws + ctx->off_AU);
-  double* B = reinterpret_cast<double*>(ctx->ws + ctx->off_B);
-  rc = launch_sigma_tensor(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, B, reinterpret_cast<double*>(ctx->ws + ctx->off_S),
-                           static_cast<double*>(part.p), s);
-  if (rc) return fail(ESDG_ERR_NO_DEVICE, "kt_sigma launch: %s", hipGetErrorString((hipError_t)rc));
-  std::vector<double> h((size_t)nb);
+  if ((rc = part.alloc(sizeof(double) * (size_t)SIGMA2_MAX_PARTIALS)) != 0) return rc;
+  HIP_TRY(hipMemsetAsync(part.p, 0, sizeof(double) * (size_t)SIGMA2_MAX_PARTIALS, s));
+  struct VtGuard { esdg_ctx* c; ~VtGuard() { c->vt_partial = nullptr; } } vg{ctx};
+  ctx->vt_partial = static_cast<double*>(part.p);
+  rc = esdg_rhs_phase(ctx, 1, Q, nullptr, stream);
+  if (rc) return rc;
+  std::vector<double> h((size_t)SIGMA2_MAX_PARTIALS);
   HIP_TRY(hipMemcpyAsync(h.data(), part.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   double t = 0.0;
@@ -2079,8 +2055,8 @@ int esdg_lsrk45_step(esdg_ctx* ctx, double* Q, double* resQ, double dt, void* st
   // round 4 at cfg3: 0.729-0.738 ms per stage against 0.635-0.637 without it (Euler cfg2: 0.092-0.094 vs 0.090-0.096) -- kt3_rhs
   // is bound by vector-instruction issue, and phase 0's arithmetic costs more inside it (node rounds at 78 % lane use, two more
   // LDS exchanges per one-shot wave, 28 spilled registers) than the memory-bound kt2_project launch it saves.  Hence off.
-  const bool fuse = ctx->stage_fusion && ctx->dim == 2 && ctx->nghost == 0 && ctx->off_AU2 && !ctx->bf && !(ctx->ph.dbg & ~32) && !(ctx->v1) &&
-                    !(ctx->v2 & 2) && ctx->T.N1 >= 2 && ctx->T.N1 <= ESDG_MAX_N1 && (!ctx->M.bc || (v2_on_walls(ctx) && ctx->T.N1 < 8));
+  const bool fuse = ctx->stage_fusion && ctx->dim == 2 && ctx->nghost == 0 && ctx->off_AU2 && !ctx->bf && !(ctx->ph.dbg & ~32) &&
+                    !(ctx->v2 & 2) && ctx->T.N1 >= 2 && ctx->T.N1 <= ESDG_MAX_N1 && (!ctx->M.bc || ctx->T.N1 < 8);
   if (!fuse) {
     for (int k = 0; k < 5; ++k) {
       int rc = esdg_rhs_lsrk(ctx, Q, resQ, rk4a[k], rk4b[k], dt, stream);
@@ -2133,8 +2109,8 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
   // unfused attempt (same bits: tests/test_gpu_drivers.py); 30 instead of 43 state-sized sweeps per attempt on top of six
   // right-hand sides.
   const bool fuse = ctx->dopri_fusion && ctx->dim == 2 && ctx->use_fast && ctx->nphases == 3 && ctx->ph.formulation == 1 &&
-                    !ctx->bf && !(ctx->ph.dbg & ~32) && !(ctx->v1 & 2) && !(ctx->v2 & 2) && ctx->T.N1 >= 2 && ctx->T.N1 <= ESDG_MAX_N1 &&
-                    (!ctx->M.bc || (v2_on_walls(ctx) && ctx->T.N1 < 8));
+                    !ctx->bf && !(ctx->ph.dbg & ~32) && !(ctx->v2 & 2) && ctx->T.N1 >= 2 && ctx->T.N1 <= ESDG_MAX_N1 &&
+                    (!ctx->M.bc || ctx->T.N1 < 8);
   if (fuse) {
     if (!ctx->d_stage_partial.p) {   // (a sharded schedule launches the last phase in up to three pieces, each rounding up)
       int rc = ctx->d_stage_partial.alloc(sizeof(double) * (size_t)(rhs_tensor3_blocks(ctx->T.N1, ctx->K) + 9));

@@ -45,8 +45,8 @@ struct Tables {
 // writes and exchanges half the bytes, the last phase reads 1280 B per element less and pays ~240 VALU instructions.
 constexpr int FAU_NC = 4;
 
-// Largest N1 = N + 1 of the 2D tensor kernels of rounds 2-4 (kt2_project, kt2_sigma, kt2_rhs, kt3_rhs).  The round-1 tensor
-// kernels, the generic pair-list kernels and the hexahedral kernels stop at N1 = 8.
+// Largest N1 = N + 1 of the 2D tensor kernels (kt2_project, kt2_sigma, kt3_rhs; kt2_rhs stops at 9).  The generic pair-list
+// kernels stop at N1 = 8, the hexahedral kernels at 10 (the row-wise kh_rhs_g at 8).
 #ifndef ESDG_MAX_N1
 #define ESDG_MAX_N1 10
 #endif
@@ -54,17 +54,13 @@ constexpr int FAU_NC = 4;
 struct TensorTables;
 struct MeshDev;
 struct Phys;
-int launch_project_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
-                          double* A_U, double* A_v, hipStream_t s);
-int launch_sigma_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
-                        const double* A_U, double* B, double* SG, double* visc_test_partial, hipStream_t s);
-int sigma_tensor_blocks(int N1, int64_t K);
 // v2 tensor kernels (esdg_kernels_tensor2.hip)
 struct LsrkFuse;
 int launch_rhs_tensor2(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
                        const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s);
+constexpr int SIGMA2_MAX_PARTIALS = 8192;   // >= the persistent grid of kt2_sigma (CUs x resident workgroups per CU)
 int launch_sigma_tensor2(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
-                         double* B, double* SG, hipStream_t s);
+                         double* B, double* SG, hipStream_t s, double* vt_partial = nullptr);
 int launch_project_tensor2(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, double* A_U, hipStream_t s);
 // v3 last-phase kernel (esdg_kernels_tensor3.hip); -1 where it does not apply
 struct StageFuse;
@@ -72,10 +68,6 @@ int launch_rhs_tensor3(int N1, const TensorTables& TT, const MeshDev& M, const P
                        const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s, const StageFuse* sf = nullptr);
 int rhs_tensor3_blocks(int N1, int64_t e_count);
 inline bool tensor2d_supported_degree(int N1) { return N1 >= 2 && N1 <= ESDG_MAX_N1; }   // workgroups of that launch (StageFuse::partial has one entry each)
-struct LsrkFuse;
-int launch_rhs_tensor(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q,
-                      const double* A_U, const double* SG, const double* B, double* rhs, const LsrkFuse& lf,
-                      hipStream_t s);
 
 struct MeshDev {
   int64_t K;               // local elements

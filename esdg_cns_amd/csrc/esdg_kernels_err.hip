@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include "esdg_dev.hpp"
+#include "esdg_devmath.hpp"
 
 namespace esdg {
 
@@ -190,6 +191,17 @@ int launch_err_nodal(const ErrDev& E, const double* Q, int kind, const double* p
 int launch_err_boundary(const ErrDev& E, const uint8_t* bc, const double* vlid, const double* Q, double Jf, double* partial,
                         int nblocks, hipStream_t s) {
   hipLaunchKernelGGL(k_err_boundary, dim3(nblocks), dim3(ERR_TPB), 0, s, E, bc, vlid, Q, Jf, partial);
+  return (int)hipGetLastError();
+}
+
+// the kernels' logarithm on an array (esdg_debug_log; tools/logtest.py compares it with numpy.log)
+__global__ void k_log_test(const double* __restrict__ x, double* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = devmath::log_pos(x[i]);
+}
+
+int launch_log_test(const double* x, double* y, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_log_test, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n);
   return (int)hipGetLastError();
 }
 

@@ -1,11 +1,26 @@
-// esdg_kernels_tensor2.hip -- second generation of the tensor-product kernels for gfx950 (MI355X / CDNA4).
+// esdg_kernels_tensor2.hip -- tensor-product kernels of the 2D path for gfx950 (MI355X / CDNA4): phase 0 (kt2_project), phase 1
+// (kt2_sigma) and the node-per-lane last phase (kt2_rhs: wall meshes from N = 7 on, A/B partner of kt3_rhs).  They run whenever
+// the driver's operators factor into 1D tables (esdg_tensor_tables.hpp; always the case for init_reference_quad with a Gauss
+// rule -- verified entry by entry in esdg_api.hip, otherwise the generic pair-list kernels of esdg_kernels.hip run).
 //
-// Same algorithm, face-trace protocol and lane mapping as esdg_kernels_tensor.hip (reference citations there): a group of
-// GW waves owns E elements, lane t of the group is Gauss node t % Nq of element t / Nq and face node t % Nfq of element
-// t / Nfq.  What changed is everything around the arithmetic.  The round-1 kernels were bound by instruction issue with
-// only half of their VALU instructions doing fp64 math (SQ_INSTS_VALU_*_F64: 795 of 1543 per wave in kt_rhs, 384 of 776
-// in kt_sigma); the rest was index arithmetic on the 1D tables, 64-bit address formation, runtime-direction selects and
-// the EXEC bookkeeping of many small divergent regions.  Here
+// Reference: `rhs` / sparse_hadamard_sum of examples/dg2D_euler_quad.jl:102-194; rhs_inviscid! :447-528, update_flux! :308-324,
+// flux_differencing! :326-348, rhs_viscous! :749-849, dg_grad! :548-569, dg_div! :590-611, viscous_matrices! :613-645 and the wall
+// closures init_BC_funs :135-265 of examples/CompressibleNS/dg2D_CNS_cavity_optimized.jl; pointwise physics
+// examples/EntropyStableEuler/{logmean,euler_fluxes,euler_variables}.jl (cited at each device function, esdg_t2_physics.hpp).
+//
+// Algorithm and face-trace protocol (shared with the generic kernels and kt3_rhs): phase 0 projects the entropy variables to the
+// faces and writes one (rho, u, v, beta) record per face node (A_U); phase 1 (CNS) forms sigma = K(v) grad v with the BR1
+// gradient, writes the normal-stress traces B and the volume part of div sigma (SG); the last phase evaluates every unordered
+// flux pair of the 2 N1 tensor lines once (200 EC fluxes per element at N = 4, the reference visits 825 / 400), the interface
+// fluxes with the LF penalty, lifts, the viscous divergence and Pq.  Mapping: a group of GW waves owns E elements, lane t of the
+// group is Gauss node t % Nq of element t / Nq and face node t % Nfq of element t / Nfq (elements may straddle the waves of
+// their group: all cross-lane traffic goes through LDS between workgroup barriers); Vq / Pq by sum factorisation.  One refined
+// v_rcp_f64 serves the three quotients of an EC flux; pointwise work stays in (rho,u,v,beta,log rho,log beta).
+//
+// What the kernels of this file do about everything around the arithmetic (the round-1 kernels -- in the history up to round 4,
+// esdg_kernels_tensor.hip -- were bound by instruction issue with only half of their VALU instructions doing fp64 math, the rest
+// index arithmetic on the 1D tables, 64-bit address formation, runtime-direction selects and the EXEC bookkeeping of many small
+// divergent regions):
 //   * every per-node quantity (operator rows, lift / projection / SBP weights, partner and face ids) comes from ONE row of
 //     host-built per-node tables (NodeLayout / FaceLayout, esdg_tensor_tables.hpp), loaded straight into registers;
 //   * both tensor directions are compile-time: LDS addresses are a per-lane base plus an immediate offset;
@@ -25,7 +40,7 @@ using namespace devmath;
 
 constexpr int TW = 64;
 
-// waves per group by degree (same choices as TCfg in esdg_kernels_tensor.hip, measured there)
+// waves per group by degree (measured with the round-1 kernels, kept)
 template <int N1> struct Cfg { static constexpr int GW = 1; };
 template <> struct Cfg<5> { static constexpr int GW = 2; };
 template <> struct Cfg<6> { static constexpr int GW = 4; };
@@ -174,7 +189,7 @@ __device__ unsigned long long g_stamp[16];
 
 // ---------------------------------------------------------------------------------------------------------------------
 // phase 1 (CNS, meshes without walls): sigma = K(v) grad v -> normal-stress traces B and the volume part of div sigma
-// (rhs_viscous! :749-815 in collocated form, dg_grad! :548-569; see kt_sigma in esdg_kernels_tensor.hip)
+// (rhs_viscous! :749-815 in collocated form, dg_grad! :548-569)
 // ---------------------------------------------------------------------------------------------------------------------
 // wall_stress_jump: the stress jump impose_BCs_stress! (:218-262; modalESDG :205-216) prescribes at a boundary face node,
 // from the own face values of sigma_x (fx), sigma_y (fy) and their normal component sn
@@ -265,11 +280,14 @@ template <int N1, bool WALLS> struct SigmaCfg {
 template <int N1, bool FULL, bool WALLS>
 __global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_sigma(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                         const double* __restrict__ A_U, double* __restrict__ B,
-                                                        double* __restrict__ SG) {
+                                                        double* __restrict__ SG, double* __restrict__ vt_partial) {
   using G = Geo<N1>;
   constexpr int Nq = G::Nq, Nfq = G::Nfq, E = G::E, NV = G::NV, NF = G::NF;
   constexpr NodeLayout NL(N1);
   constexpr FaceLayout FL(N1);
+  // vt_partial != null (uniform; esdg_viscous_entropy_test only): the launch also reduces rhs_viscous!'s second return,
+  // visc_test = sum(wJq .* (VUx .* sigma_x + VUy .* sigma_y)) (:802-806), over the elements it owns -- one partial per workgroup,
+  // summed in a fixed order (lane, then the workgroup's waves), so a context's value is reproducible run to run.
   // LDS arena in doubles.  R0: Vq scratch A|B (4 pair planes), later sigma (3 pair planes: (sx0,sx1) (sx2,sy0) (sy1,sy2))
   // and the pair plane of S^0; R1: pair plane of S^1, single planes S^0_2, S^1_2; then V (pair (v2,v3) + single v4),
   // the half jumps (pair + single, face nodes) and the geometry records of the group's elements.
@@ -407,6 +425,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_s
     static_assert(TL.IP == TL.IQ + N1 * N1, "IQ and IP are adjacent in the 1D tables");
     for (int i = tid; i < 2 * N1 * N1; i += G::GT) sW[i] = TT.dbl[TL.IQ + i];
   }
+  double vt = 0.0;   // this lane's share of visc_test
   double cdv[3] = {0, 0, 0}, csn[3] = {0, 0, 0};
   int64_t ce0 = 0;
   bool cva = false, cfa = false;
@@ -617,6 +636,15 @@ __global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_s
         }
       }
       viscous_stress(V, tx, ty, -ph.lambda, ph.mu, ph.kappa, sgx, sgy);
+      if (vt_partial) {   // (uniform) every element once: not the duplicate lanes, not the elements a shifted last group repeats
+        const int64_t ee = e0 + ev, enom = FULL ? M.e_begin + grp * E : e0;
+        if (tid < (unsigned)NV && ee >= enom && (FULL || ev < (unsigned)nE)) {
+          double t = tx[0] * sgx[0];
+          t = __builtin_fma(tx[1], sgx[1], t); t = __builtin_fma(tx[2], sgx[2], t);
+          t = __builtin_fma(ty[0], sgy[0], t); t = __builtin_fma(ty[1], sgy[1], t); t = __builtin_fma(ty[2], sgy[2], t);
+          vt = __builtin_fma(M.wJq[ESDG_EW(ee) * Nq + q], t, vt);
+        }
+      }
     }
     {
       sSg[tv] = make_double2(sgx[0], sgx[1]);
@@ -747,6 +775,16 @@ __global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_s
       for (int r = 0; r < BPT; ++r) { const int idx = (int)tid + r * G::GT; if (idx < cnb) bb[idx] = sBs[idx]; }
     } else if (cfa) { double* bb = B + trace_slot<N1>(M, ESDG_EW(ce0) + ef, fn) * B_NC; bb[0] = csn[0]; bb[1] = csn[1]; bb[2] = csn[2]; }
   }
+  if (vt_partial) {   // (uniform) lanes of a wave in lane order, then the waves in order
+    __syncthreads();
+    lds[tid] = vt;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int i = 0; i < G::GT; ++i) t += lds[i];
+      vt_partial[blockIdx.x] = t;
+    }
+  }
   T2_STAMP_FLUSH;
 }
 
@@ -754,7 +792,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_s
 // ---------------------------------------------------------------------------------------------------------------------
 // last phase (meshes without walls): interface + volume flux differencing (+ viscous divergence and penalty) -> rhs
 // (euler_quad.jl:141-194 / rhs_inviscid! :447-528, update_flux! :308-324, flux_differencing! :326-348, dg_div! :590-611;
-// see kt_rhs in esdg_kernels_tensor.hip for the formulas)
+// formulas at the statements below)
 //
 // Flux pairs.  Volume-volume pairs: circulant rounds, each unordered pair once, by the volume lanes (the partner's share
 // goes to an LDS accumulator with ds_add_f64).  Volume-face pairs: by the FACE lanes, which walk the N1 volume nodes
@@ -767,7 +805,7 @@ __global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_s
 // ---------------------------------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------------------------------
 // phase 0: entropy projection to the faces -> the (rho, u, v, beta) trace records A_U
-// (euler_quad.jl:141-157 / rhs_inviscid! :447-495: VU = v(Vq u), Uf = u(Vf Pq VU); see kt_project in esdg_kernels_tensor.hip)
+// (euler_quad.jl:141-157 / rhs_inviscid! :447-495: VU = v(Vq u), Uf = u(Vf Pq VU))
 // One workgroup per group of E elements (one-shot), pair planes, per-node table rows.  The round-1 kernel kept its LDS
 // arrays as [element][component][node] planes of doubles: a wave waited 38 % of its life on LDS instructions, a third of its
 // LDS cycles were bank conflicts (profiles/r03u_sq_counters.txt).
@@ -1383,7 +1421,7 @@ extern "C" int esdg_debug_stamps(unsigned long long* out16, int reset) {
 
 template <int N1, bool WALLS>
 static void launch_sigma2w(const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U, double* B,
-                           double* SG, hipStream_t s) {
+                           double* SG, double* vt, hipStream_t s) {
   using G = t2::Geo<N1>;
   const int64_t nfull = M.e_count >= G::E ? (M.e_count + G::E - 1) / G::E : 0;   // complete groups, the last one shifted back
   if (nfull > 0) {
@@ -1404,22 +1442,23 @@ static void launch_sigma2w(const TensorTables& TT, const MeshDev& M, const Phys&
     }
     MeshDev Ml = M;
     Ml.wall_rot = (WALLS && M.wgeo) ? 1 : 0;   // spread the costly wall groups over the workgroups (MeshDev::wall_rot)
-    hipLaunchKernelGGL((t2::kt2_sigma<N1, true, WALLS>), dim3(nb), dim3(G::GT), 0, s, TT, Ml, ph, Q, A_U, B, SG);
+    hipLaunchKernelGGL((t2::kt2_sigma<N1, true, WALLS>), dim3(nb), dim3(G::GT), 0, s, TT, Ml, ph, Q, A_U, B, SG, vt);
   }
-  else hipLaunchKernelGGL((t2::kt2_sigma<N1, false, WALLS>), dim3(1), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG);   // fewer than E elements
+  else hipLaunchKernelGGL((t2::kt2_sigma<N1, false, WALLS>), dim3(1), dim3(G::GT), 0, s, TT, M, ph, Q, A_U, B, SG, vt);   // fewer than E elements
 }
 template <int N1>
 static void launch_sigma2(const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U, double* B,
-                          double* SG, hipStream_t s) {
-  if (M.bc) launch_sigma2w<N1, true>(TT, M, ph, Q, A_U, B, SG, s);
-  else launch_sigma2w<N1, false>(TT, M, ph, Q, A_U, B, SG, s);
+                          double* SG, double* vt, hipStream_t s) {
+  if (M.bc) launch_sigma2w<N1, true>(TT, M, ph, Q, A_U, B, SG, vt, s);
+  else launch_sigma2w<N1, false>(TT, M, ph, Q, A_U, B, SG, vt, s);
 }
 
-// phase 1 on meshes without walls and without the visc_test reduction (the other variants stay with kt_sigma)
+// phase 1; vt_partial != null: also the visc_test partials, one per workgroup (at most SIGMA2_MAX_PARTIALS; the caller zeroes
+// the buffer and sums all of it)
 int launch_sigma_tensor2(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
-                         double* B, double* SG, hipStream_t s) {
+                         double* B, double* SG, hipStream_t s, double* vt_partial) {
   if (M.e_count <= 0) return 0;
-  ESDG_T2_DISPATCH(N1v, launch_sigma2<N1>(TT, M, ph, Q, A_U, B, SG, s));
+  ESDG_T2_DISPATCH(N1v, launch_sigma2<N1>(TT, M, ph, Q, A_U, B, SG, vt_partial, s));
   return (int)hipGetLastError();
 }
 
@@ -1448,7 +1487,7 @@ int launch_rhs_tensor2(int N1v, const TensorTables& TT, const MeshDev& M, const 
   return (int)hipGetLastError();
 }
 
-// phase 0 with the v2 kernel; returns -1 where it does not cover the degree (caller falls back to kt_project)
+// phase 0 with the v2 kernel; returns -1 where it does not cover the degree (the caller refuses the degree)
 int launch_project_tensor2(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, double* A_U, hipStream_t s) {
   if (M.e_count <= 0) return 0;
   if (!tensor2d_supported_degree(N1v)) return -1;

@@ -1,6 +1,6 @@
 // esdg_tensor_tables.hpp -- layout of the 1D operator tables of the tensor kernels, shared by the host
 // (esdg_api.hip builds and verifies them from the driver's dense matrices) and the device
-// (esdg_kernels_tensor.hip stages them in LDS once per workgroup).
+// (kt3_rhs stages them in LDS once per workgroup; kt2_* read the per-node rows derived from them).
 //
 // Conventions: volume (Gauss) node q = a + N1*b.  Direction d = 0 walks a (stride 1), d = 1 walks b
 // (stride N1).  node(d,i,o) is the node at position i of the line with transverse index o.
@@ -44,7 +44,7 @@ struct TensorLayout {
 // row, derived on the host from the 1D tables above, so the kernels do no index arithmetic or table chasing.
 // Faces are numbered k = 2 d + t (the face at end t of the d-lines); circulant round r = d * NFULL + i pairs the node
 // at position pos of its d-line with position (pos + i + 1) mod N1; even N1 has one more, antipodal round (pos + N1/2)
-// in which a node serves ONE of its two directions (see kt_rhs).
+// in which a node serves ONE of its two directions (see kt2_rhs).
 //   volume node q = a + N1 b, NodeLayout::LD doubles:
 //     IQ[N1] = IQ[a][:]          IPL[N1] = IP[a][:]      IPH[N1] = IP[b][:]
 //     DG0[N1] = DG[0][a][:]      DG1[N1] = DG[1][b][:]

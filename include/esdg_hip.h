@@ -184,7 +184,7 @@ int esdg_bind_workspace(esdg_ctx* ctx, void* dev_ptr, size_t bytes);
  * Replaces: rhs (euler_quad.jl:141), rhs_inviscid! / rhs_viscous! / rhsRK!
  * (cavity_optimized.jl:447, 749, 955).  All launches are asynchronous on `stream`. */
 int esdg_num_phases(const esdg_ctx* ctx);
-/* 1 if the tensor-line kernels (esdg_kernels_tensor.hip / esdg_kernels_hex.hip) are in use, 0 for the generic pair-list kernels
+/* 1 if the tensor-line kernels (esdg_kernels_tensor2.hip, esdg_kernels_tensor3.hip / esdg_kernels_hex.hip) are in use, 0 for the generic pair-list kernels
  * (operators without tensor-product Gauss structure, or ESDG_FORCE_GENERIC=1 in the environment). */
 int esdg_uses_tensor_kernels(const esdg_ctx* ctx);
 int esdg_rhs_phase(esdg_ctx* ctx, int phase, const double* Q_dev, double* rhs_dev, void* stream);

@@ -182,11 +182,11 @@ def test_cns_variable_lid_velocity_matches_oracle(eng_mod, oracle_lib):
         assert all(np.array_equal(a, b) for a, b in zip(same, ones))
 
 
-@pytest.mark.parametrize("bc,BCTYPE", [("periodic", 1), ("cavity", 1), ("cavity", 3)])
-def test_rhs_inviscid_viscous_split_and_rhsRK_diagnostics(eng_mod, oracle_lib, bc, BCTYPE):
+@pytest.mark.parametrize("bc,BCTYPE,N,Kx,Ky", [("periodic", 1, 3, 6, 5), ("cavity", 1, 3, 6, 5), ("cavity", 3, 3, 6, 5),
+                                               ("periodic", 1, 8, 3, 2), ("cavity", 1, 8, 3, 2)])   # (N = 8: visc_test on kt2_sigma, round 5)
+def test_rhs_inviscid_viscous_split_and_rhsRK_diagnostics(eng_mod, oracle_lib, bc, BCTYPE, N, Kx, Ky):
     """esdg_set_parts: 1 = rhs_inviscid! (:447), 2 = rhs_viscous! (:749) against the oracle's separate restatements, and
     the three returns of rhsRK! (:955-972): rhsQ, rhstest, rhstest_visc (visc_test from esdg_viscous_entropy_test)."""
-    N, Kx, Ky = 3, 6, 5
     rd, md, ops, Q = (product_cns_problem if bc == "periodic" else product_cavity_problem)(N, Kx, Ky)
     p = as_oracle_problem(rd, md, ops, Q, **dict(PHYS, BCTYPE=BCTYPE))
     o, q = _cns(p)

@@ -1,6 +1,6 @@
 """Lid-driven cavity (walls, BCTYPE 1): ms per CNS right-hand side of the current kernels (kt2_project, kt2_sigma, kt3_rhs with its
-wall instantiation), of the same with the v2 last phase (ESDG_V2=rhs: kt2_rhs) and of the round-1 kernels on wall meshes
-(ESDG_V1=walls), and the differences of the results to the first.   python tools/cavity_ab.py [N Kx]"""
+wall instantiation) and of the same with the v2 last phase (ESDG_V2=rhs: kt2_rhs), and the difference of the results.
+(The round-1 kernels this tool also timed until round 4 -- ESDG_V1=walls -- are gone.)   python tools/cavity_ab.py [N Kx]"""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -21,17 +21,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 10
     np.save(sys.argv[4], out.cpu().numpy())
-    tag = "ESDG_V1=" + os.environ["ESDG_V1"] if "ESDG_V1" in os.environ else ("ESDG_V2=" + os.environ["ESDG_V2"] if "ESDG_V2" in os.environ else "default")
+    tag = "ESDG_V2=" + os.environ["ESDG_V2"] if "ESDG_V2" in os.environ else "default"
     print(f"{tag}: {ms:.4f} ms per RHS (cavity N={N} {Kx}x{Kx})")
 else:
     import numpy as np
     N, Kx = (sys.argv[1:3] + ["4", "256"])[:2] if len(sys.argv) > 2 else ("4", "256")
     outs = []
-    for k, v in ((None, None), ("ESDG_V2", "rhs"), ("ESDG_V1", "walls"), (None, None), ("ESDG_V2", "rhs")):
+    for k, v in ((None, None), ("ESDG_V2", "rhs"), (None, None), ("ESDG_V2", "rhs")):
         env = dict(os.environ)
         if k: env[k] = v
         f = f"/tmp/cav_{k}_{v}.npy"
         subprocess.run([sys.executable, __file__, "--child", N, Kx, f], env=env, check=True)
         outs.append(np.load(f))
-    for i, name in ((1, "ESDG_V2=rhs"), (2, "ESDG_V1=walls")):
+    for i, name in ((1, "ESDG_V2=rhs"),):
         print("max rel difference of %s to the default: %.2e" % (name, np.abs(outs[0] - outs[i]).max() / np.abs(outs[0]).max()))

@@ -34,8 +34,8 @@ lid = ey == Ky - 1
 kinds = dict(interior=~(wall | lid), wall=wall & ~lid, lid=lid)
 print(f"cavity N={N} {Kx}x{Ky} BCTYPE={BCTYPE} penalty={PEN} vlid={'0' if VL0 else '1'}: rhs_viscous! alone, fields 2..4")
 print("oracle  :", " ".join("%.2e" % (np.linalg.norm(a - t) / np.linalg.norm(t)) for a, t in zip(ov[1:], tv[1:])))
-for tag, env in (("v2", {}), ("v2, one record per element", {"ESDG_WALL_GEOMETRY": "element"}), ("round-1", {"ESDG_V1": "walls"})):
-    for k in ("ESDG_V1", "ESDG_FORCE_GENERIC", "ESDG_WALL_GEOMETRY"):
+for tag, env in (("v2", {}), ("v2, one record per element", {"ESDG_WALL_GEOMETRY": "element"})):
+    for k in ("ESDG_FORCE_GENERIC", "ESDG_WALL_GEOMETRY"):
         os.environ.pop(k, None)
     os.environ.update(env)
     eng = engine.RhsEngine(rd, md, ops, engine.CNS_MODAL, Re=p.Re, mu=p.mu, lam=p.lam, Pr=p.Pr, BCTYPE=BCTYPE, viscous_dissp=PEN,

@@ -58,7 +58,7 @@ if __name__ == "__main__":
     for K in (32, 64, 128, 256):
         if K > kmax:
             break
-        for mode, env in (("v2", {}), ("v1", {"ESDG_V1": "1"}), ("generic", {"ESDG_FORCE_GENERIC": "1"})):
+        for mode, env in (("v2", {}), ("generic", {"ESDG_FORCE_GENERIC": "1"})):
             if mode == "generic" and K > 128:
                 continue
             e = dict(os.environ); e.update(env)
