@@ -526,9 +526,8 @@ def run(args):
             eng.rhs_into(Qw, out)
             eng.lsrk_update(Qw, res, out, -0.4178904745, 0.1496590219993, 0.0)
         lsrk_stage_unfused_ms = _time(_unfused)
-        # ... and per stage of the library's whole five-stage step (esdg_lsrk45_step), whose stages 1 ... 4 start at phase 1: the
-        # last phase of the stage before has emitted their trace records when ESDG_STAGE_FUSION=1 (cross-stage fusion, 2D unsharded;
-        # measured slower, off by default: the key then equals lsrk_stage_ms)
+        # ... and per stage of the library's whole five-stage step (esdg_lsrk45_step: five fused stages; the cross-stage fusion of
+        # round 4 -- phase 0 of the next stage emitted by the last phase -- measured slower and was removed in round 5)
         import ctypes as C2
         if not hexw:
             qp, rp = C2.c_void_p(Qw.data_ptr()), C2.c_void_p(res.data_ptr())

@@ -137,14 +137,20 @@ class EsdgError(RuntimeError):
     pass
 
 
-def lib():
-    """Load libesdg_hip.so; raise loudly when the HIP extension has not been built."""
+AB_LIB_PATH = os.path.join(_HERE, "libesdg_hip_ab.so")   # the same kernels, environment switches compiled in (build.py)
+_LIBS = {}
+
+
+def lib(ab=False):
+    """Load libesdg_hip.so (ab=True: the A/B build libesdg_hip_ab.so, whose esdg_create reads the ESDG_* environment
+    switches -- the shipped library reads none); raise loudly when the HIP extension has not been built."""
     global _LIB
-    if _LIB is None:
-        if not os.path.exists(LIB_PATH):
-            raise EsdgError(f"{LIB_PATH} not found: the HIP extension is not built "
+    path = AB_LIB_PATH if (ab and not os.environ.get("ESDG_HIP_LIB")) else LIB_PATH
+    if path not in _LIBS:
+        if not os.path.exists(path):
+            raise EsdgError(f"{path} not found: the HIP extension is not built "
                             "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)      # AttributeError if the ABI and the header drifted apart
             fn.restype = res
@@ -152,11 +158,18 @@ def lib():
         for st in (esdg_ops_t, esdg_mesh_t, esdg_phys_t, esdg_hex_ops_t, esdg_hex_mesh_t, esdg_err_ops_t):
             want = L.esdg_abi_sizeof(st.__name__.encode())
             if want != C.sizeof(st):
-                raise EsdgError(f"ABI drift: {st.__name__} is {want} bytes in libesdg_hip.so, {C.sizeof(st)} in _lib.py")
-        _LIB = L
-    return _LIB
+                raise EsdgError(f"ABI drift: {st.__name__} is {want} bytes in {os.path.basename(path)}, {C.sizeof(st)} in _lib.py")
+        _LIBS[path] = L
+        if path == LIB_PATH:
+            _LIB = L
+    return _LIBS[path]
+
+
+def check_on(L, rc):
+    """Raise with the message of the library the failing call went to (two builds may be loaded side by side)."""
+    if rc != 0:
+        raise EsdgError(f"libesdg_hip error {rc}: {L.esdg_last_error().decode()}")
 
 
 def check(rc):
-    if rc != 0:
-        raise EsdgError(f"libesdg_hip error {rc}: {lib().esdg_last_error().decode()}")
+    check_on(lib(), rc)

@@ -3,7 +3,12 @@
 One object per source under esdg_cns_amd/build/ (recompiled when the source or any header is newer), compiled in
 parallel, then linked into esdg_cns_amd/libesdg_hip.so together with librccl (the halo transport of esdg_comm_* /
 esdg_halo_exchange lives inside the library).  `python -m esdg_cns_amd.build [-DNAME ...] [--out path.so]` builds a
-variant (A/B builds under esdg_cns_amd/variants/)."""
+variant (A/B builds under esdg_cns_amd/variants/).
+
+The shipped library reads no environment variable.  build() also links esdg_cns_amd/libesdg_hip_ab.so: the SAME kernel
+objects with csrc/esdg_api.hip compiled once more under -DESDG_AB_HOOKS, which is where the environment switches that select
+partner kernels, geometry modes and schedule variants live (tests and tools that compare kernel sets load that build:
+esdg_cns_amd._lib.lib(ab=True), engine.RhsEngine(..., ab_hooks=True))."""
 import os
 import subprocess
 import sys
@@ -15,6 +20,8 @@ SOURCES = ["csrc/esdg_kernels.hip", "csrc/esdg_kernels_tensor2.hip", "csrc/esdg_
 HEADERS = ["csrc/esdg_dev.hpp", "csrc/esdg_devmath.hpp", "csrc/esdg_t2_physics.hpp", "csrc/esdg_tensor_tables.hpp", "csrc/esdg_hex_tables.hpp",
            "../include/esdg_hip.h"]
 OUT = os.path.join(HERE, "libesdg_hip.so")
+OUT_AB = os.path.join(HERE, "libesdg_hip_ab.so")
+AB_SOURCE = "csrc/esdg_api.hip"   # the only file that reads ESDG_AB_HOOKS
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 LINK = ["-L" + os.path.join(ROCM, "lib"), "-lrccl", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
@@ -36,7 +43,7 @@ def _headers():
 
 
 def needs_build(out=OUT):
-    if not os.path.exists(out):
+    if not os.path.exists(out) or (out == OUT and not os.path.exists(OUT_AB)):
         return True
     t = os.path.getmtime(out)
     return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in _sources() + _headers())
@@ -66,6 +73,11 @@ def build(force=False, verbose=False, defines=(), out=OUT, tag=""):
     os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
     objs = [os.path.join(odir, os.path.basename(s) + ".o") for s in _sources()]
     run([hipcc, "--offload-arch=gfx950", "-shared", "-o", out] + objs + LINK)
+    if out == OUT and not defines:   # the A/B build beside the shipped one: same objects, the API file once more with its hooks
+        ab_obj = os.path.join(odir, os.path.basename(AB_SOURCE) + ".ab.o")
+        run([hipcc] + FLAGS + ["-DESDG_AB_HOOKS", "-c", os.path.join(HERE, AB_SOURCE), "-o", ab_obj])
+        api_obj = os.path.join(odir, os.path.basename(AB_SOURCE) + ".o")
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-o", OUT_AB] + [ab_obj if o == api_obj else o for o in objs] + LINK)
     return out
 
 

@@ -27,6 +27,35 @@ using namespace esdg;
 
 namespace {
 
+// Environment switches exist in A/B builds only (-DESDG_AB_HOOKS: esdg_cns_amd/libesdg_hip_ab.so, the same kernel objects with
+// this file compiled once more; tests and tools that compare kernel sets load that build).  The shipped library reads no
+// environment variable: every ab_env() below is a constant null pointer there.
+//   ESDG_V2=1|rhs            kt2_rhs where kt3_rhs exists          ESDG_FORCE_GENERIC=1     pair-list kernels
+//   ESDG_DBG=32              kt3_rhs without its smooth-wave short cut (same bits); 16: hex workgroup remap off
+//   ESDG_TRACE_LAYOUT=face   traces by mesh face                   ESDG_WALL_GEOMETRY=element  one record per element in wall elements
+//   ESDG_DOPRI_FUSION=0      unfused DOPRI45 attempt               ESDG_HEX_PER_NODE=1 / ESDG_HEX_GEOMETRY=element  hex geometry mode 1 / 0
+//   ESDG_HEX_LINE=0          kh_rhs / kh_rhs_g                     ESDG_T2_WG_PER_CU=n, ESDG_T2_RESERVE=n  persistent grid of kt2_sigma
+//   ESDG_NO_OVERLAP=1, ESDG_ONE_STREAM=1, ESDG_NO_NEST=1           variants of the sharded schedule
+inline const char* ab_env(const char* name) {
+#ifdef ESDG_AB_HOOKS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+#ifdef ESDG_AB_HOOKS
+void ab_apply_tuning() {   // (the knobs that live beside the kernels)
+  const char* a = getenv("ESDG_T2_WG_PER_CU");
+  const char* b = getenv("ESDG_T2_RESERVE");
+  ab_tuning_t2(a ? atoi(a) : -1, b ? atoi(b) : -1);
+  const char* l = getenv("ESDG_HEX_LINE");
+  ab_tuning_hex(l && l[0] == '0' ? 0 : 1);
+}
+#else
+void ab_apply_tuning() {}
+#endif
+
 thread_local std::string g_err;
 
 int fail(int code, const char* fmt, ...) {
@@ -583,16 +612,10 @@ struct esdg_ctx {
   size_t ws_bytes = 0;
   char* ws = nullptr;
   size_t off_AU = 0, off_Av = 0, off_B = 0, off_S = 0;
-  // cross-stage fusion of esdg_lsrk45_step (LsrkFuse::AUn): a second A_U buffer (unsharded 2D tensor contexts; 0 = none), which
-  // of the two the phases read right now, and whether the last phase of the call in flight emits the next stage's traces into the other
-  size_t off_AU2 = 0;
-  int au_sel = 0;
-  bool emit_next = false;
   int64_t stage_cursor = 0;                // partials handed out so far in the current stage
   const StageFuse* stage_fuse = nullptr;   // set by esdg_dopri45_attempt around a last-phase launch (kt3_rhs's STG instantiation)
   bool dopri_fusion = true;    // ESDG_DOPRI_FUSION=0 at esdg_create: the unfused attempt (A/B partner, and the bitwise test's)
   DevBuf d_stage_partial;      // one double per kt3_rhs workgroup (error norm of the fused attempt), allocated at the first attempt
-  bool stage_fusion = false;   // ESDG_STAGE_FUSION=1 at esdg_create (measured in round 4: 15 % slower per stage; off by default)
   int64_t int_lo = 0, int_hi = 0;   // longest run of elements [int_lo, int_hi) that touch no ghost slot
   // nested interiors: nest_lo/hi[0] = [int_lo, int_hi); nest[p] = the longest run inside nest[p-1] all of whose face
   // neighbours lie in nest[p-1] -- what phase p can compute from data the same stream produced in phase p-1
@@ -667,7 +690,11 @@ static void set_interior(esdg_ctx* c, const std::vector<int32_t>& mapP, int64_t 
 extern "C" {
 
 const char* esdg_last_error(void) { return g_err.c_str(); }
+#ifdef ESDG_AB_HOOKS
+const char* esdg_version(void) { return "esdg_hip 0.1 (gfx950) [A/B build: environment hooks compiled in]"; }
+#else
 const char* esdg_version(void) { return "esdg_hip 0.1 (gfx950)"; }
+#endif
 
 int64_t esdg_abi_sizeof(const char* name) {
   if (!name) return -1;
@@ -695,6 +722,7 @@ int esdg_set_device(int device) {
 int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_t* phys, esdg_ctx** out) {
   if (!ops || !mesh || !phys || !out) return fail(ESDG_ERR_ARG, "null argument");
   *out = nullptr;
+  ab_apply_tuning();
   const int N1 = ops->N + 1, Nq = ops->Nq, Nfq = ops->Nfq, Np = ops->Np, Nh = Nq + Nfq;
   if (!tensor2d_supported_degree(N1)) return fail(ESDG_ERR_ARG, "unsupported degree N=%d (need 1..%d)", ops->N, ESDG_MAX_N1 - 1);
   if (Nq != N1 * N1 || Np != N1 * N1 || Nfq != 4 * N1)
@@ -750,8 +778,8 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   c->nphases = visc ? 3 : 2;
   c->ph.parts = 3;
   c->ph.dbg = 0;
-  if (const char* env = getenv("ESDG_DBG")) c->ph.dbg = atoi(env);
-  if (const char* env = getenv("ESDG_V2")) c->v2 = env[0] == '1' ? 7 : env[0] == 'r' ? 2 : env[0] == 's' ? 1 : 0;
+  if (const char* env = ab_env("ESDG_DBG")) c->ph.dbg = atoi(env);
+  if (const char* env = ab_env("ESDG_V2")) c->v2 = env[0] == '1' ? 7 : env[0] == 'r' ? 2 : env[0] == 's' ? 1 : 0;
 
   // ---- collocated sparse operators -------------------------------------------------------
   Mat EfD, PhC, LfC, DrC, DsC, Vq, Pq;
@@ -833,7 +861,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   TensorHost th;
   bool use_fast = build_tensor_host(N1, Qr, Qs, PhC, LfC, EfD, visc ? &DrC : nullptr, visc ? &DsC : nullptr,
                                     modal ? &Vq : nullptr, modal ? &Pq : nullptr, th);
-  if (const char* env = getenv("ESDG_FORCE_GENERIC"))
+  if (const char* env = ab_env("ESDG_FORCE_GENERIC"))
     if (env[0] == '1') use_fast = false;
   if (N1 > 9 && mesh->NmapB > 0)
     return fail(ESDG_ERR_ARG, "meshes with walls are served up to N=8 (the wall instantiation of the last phase is kt2_rhs from N=7 on, "
@@ -914,7 +942,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   // last phase -1 %, RHS +1.7 % -- the over-fetch the layout removes is served by the Infinity Cache (the traces were written by the
   // kernel before), not by HBM.  Off unless ESDG_TRACE_LAYOUT=face.
   c->bf = false;
-  if (const char* env = getenv("ESDG_TRACE_LAYOUT"))
+  if (const char* env = ab_env("ESDG_TRACE_LAYOUT"))
     c->bf = env[0] == 'f' && use_fast && !c->ph.dbg && N1 >= 2 && N1 <= ESDG_MAX_N1 && (int64_t)K * Nfq < ((int64_t)1 << 31);
   if (c->bf) {
     const int64_t KF = (int64_t)K * Nfq, KN1 = (int64_t)K * N1;
@@ -984,7 +1012,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   // what the reference's viscous operators read node by node (MeshDev::wgeo): CNS on a mesh with walls whose driver
   // passed at least the Np nodal rows of the metric arrays.  ESDG_WALL_GEOMETRY=element: off (A/B).
   bool wall_nodal = visc && modal && use_fast && mesh->NmapB > 0 && ld >= Np && Np == Nq;
-  if (const char* env = getenv("ESDG_WALL_GEOMETRY"))
+  if (const char* env = ab_env("ESDG_WALL_GEOMETRY"))
     if (env[0] == 'e') wall_nodal = false;
   if (wall_nodal) {
     std::vector<double> wg((size_t)K * 5 * Np);
@@ -1082,9 +1110,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   size_t off = 0;
   // A_U: generic kernels one array of 5-double records; tensor kernels one array of 4-double records (rho, u, v, beta)
   c->off_AU = off; off = align(off + nodes * (use_fast ? FAU_NC : AU_NC) * sizeof(double));
-  if (const char* env = getenv("ESDG_STAGE_FUSION")) c->stage_fusion = env[0] == '1';
-  if (const char* env = getenv("ESDG_DOPRI_FUSION")) c->dopri_fusion = env[0] != '0';
-  if (use_fast && c->nghost == 0 && c->stage_fusion) { c->off_AU2 = off; off = align(off + nodes * FAU_NC * sizeof(double)); }   // (esdg_lsrk45_step)
+  if (const char* env = ab_env("ESDG_DOPRI_FUSION")) c->dopri_fusion = env[0] != '0';
   c->M.trace_nodes = (int64_t)nodes;
   const bool need_Av = visc && !use_fast;   // the tensor kernels rebuild the neighbour's (v2,v3,v4) from its A_U record
   if (visc) {
@@ -1115,6 +1141,7 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
 int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, const esdg_phys_t* phys, esdg_ctx** out) {
   if (!ops || !mesh || !phys || !out) return fail(ESDG_ERR_ARG, "null argument");
   *out = nullptr;
+  ab_apply_tuning();
   const int N1 = ops->N + 1, NN = N1 * N1, Nq = ops->Nq, Nfq = ops->Nfq, Nh = Nq + Nfq;
   if (!hex_supported_degree(N1)) return fail(ESDG_ERR_ARG, "unsupported hex degree N=%d (need 1..9)", ops->N);
   if (Nq != NN * N1 || Nfq != 6 * NN)
@@ -1142,7 +1169,7 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
   c->ph.kappa = c->ph.inv_Re = 0.0;
   c->ph.dbg = 0;
   c->ph.parts = 3;
-  if (const char* env = getenv("ESDG_DBG")) c->ph.dbg = atoi(env);
+  if (const char* env = ab_env("ESDG_DBG")) c->ph.dbg = atoi(env);
   c->nphases = 2;
   c->use_fast = true;
   c->au_nc = HEX_AU_NC;
@@ -1199,7 +1226,7 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
   // the quadrature nodes and per-node normals, as the script's sparse_hadamard_sum / rhs use them (:145-151, :193-198)
   // ESDG_HEX_PER_NODE=1: the per-node path for affine meshes too (every node's own metric terms and normals, as the script
   // uses them; the element record above replaces them by means, which filters the round-off of the driver's set-up)
-  if (const char* env = getenv("ESDG_HEX_PER_NODE"))
+  if (const char* env = ab_env("ESDG_HEX_PER_NODE"))
     if (env[0] == '1' && ld == Nh) curved = true;
   std::vector<double> G9, Jq, nrm;
   if (curved) {
@@ -1221,7 +1248,7 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
   // element record (mode 0).
   std::vector<uint32_t> hdv, hdf, hdn;
   {
-    const char* env = getenv("ESDG_HEX_GEOMETRY");
+    const char* env = ab_env("ESDG_HEX_GEOMETRY");
     const bool element_only = env && env[0] == 'e';
     if (!curved && ld == Nh && !element_only) {
       hdv.assign((size_t)K * 3 * Nq, 0u); hdf.assign((size_t)K * Nfq, 0u); hdn.assign((size_t)K * Nfq, 0u);
@@ -1351,7 +1378,7 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
   if (!ctx->ws) return fail(ESDG_ERR_STATE, "workspace not bound (esdg_bind_workspace)");
   if (phase < 0 || phase >= ctx->nphases) return fail(ESDG_ERR_ARG, "bad phase %d", phase);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  double* A_U = reinterpret_cast<double*>(ctx->ws + (ctx->au_sel ? ctx->off_AU2 : ctx->off_AU));
+  double* A_U = reinterpret_cast<double*>(ctx->ws + ctx->off_AU);
   const bool visc = ctx->nphases == 3;
   const bool need_Av = visc && !ctx->use_fast;
   double* A_v = need_Av ? reinterpret_cast<double*>(ctx->ws + ctx->off_Av) : nullptr;
@@ -1384,9 +1411,6 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
     // (ESDG_DBG bit 32: kt3_rhs takes every logarithm whatever the state -- the partner of the bitwise test of its data-dependent
     // short cut, tests/test_gpu_engine.py)
     if (ctx->use_fast && !(ctx->v2 & 2)) {
-      LsrkFuse lfe = lf;
-      if (ctx->emit_next && lf.Qw && !ranged)   // (esdg_lsrk45_step: the next stage's traces into the buffer not being read)
-        lfe.AUn = reinterpret_cast<double*>(ctx->ws + (ctx->au_sel ? ctx->off_AU : ctx->off_AU2));
       StageFuse sfl;
       const StageFuse* sfp = ctx->stage_fuse;
       if (sfp && sfp->err) {   // every launch of the stage (the pieces of a sharded schedule) gets its own run of partials
@@ -1395,9 +1419,8 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
         ctx->stage_cursor += rhs_tensor3_blocks(ctx->T.N1, ranged ? e_count : ctx->K);
         sfp = &sfl;
       }
-      rc = launch_rhs_tensor3(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lfe, s, sfp);
+      rc = launch_rhs_tensor3(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s, sfp);
       if (rc == -1 && ctx->stage_fuse) return fail(ESDG_ERR_STATE, "DOPRI45 stage fusion asked of a context the v3 last-phase kernel does not serve");
-      if (rc == -1 && lfe.AUn) return fail(ESDG_ERR_STATE, "stage fusion asked of a context the v3 last-phase kernel does not serve");
     }
     if (rc == -1 && ctx->stage_fuse) return fail(ESDG_ERR_STATE, "DOPRI45 stage fusion asked of a context the v3 last-phase kernel does not serve");
     if (rc == -1 && ctx->use_fast)      // v2 kernel (N1 = 2 ... 9): wall meshes from N1 = 8 on, and the A/B partner of kt3_rhs (ESDG_V2=rhs)
@@ -1622,12 +1645,12 @@ static int rhs_sharded_impl(esdg_ctx* ctx, const double* Q, double* rhs, const L
   hipStream_t s = static_cast<hipStream_t>(stream);
   const LsrkFuse none{nullptr, nullptr, 0.0, 0.0, 0.0};
   const int64_t lo = ctx->int_lo, hi = ctx->int_hi, K = ctx->K;
-  const char* env = getenv("ESDG_NO_OVERLAP");
+  const char* env = ab_env("ESDG_NO_OVERLAP");
   const bool overlap = ctx->use_fast && hi > lo && (hi - lo) < K && !(env && env[0] == '1');
   // ESDG_ONE_STREAM=1: the boundary strips on the caller's stream, after the interior (the schedule before the boundary
   // stream existed; A/B hook).  ESDG_NO_NEST=1: boundary stream, but the same interior range in every phase.
-  const char* env1 = getenv("ESDG_ONE_STREAM");
-  const char* env2 = getenv("ESDG_NO_NEST");
+  const char* env1 = ab_env("ESDG_ONE_STREAM");
+  const char* env2 = ab_env("ESDG_NO_NEST");
   hipStream_t b = (overlap && !(env1 && env1[0] == '1')) ? ctx->bstream : s;
   // Nested interiors (see esdg_ctx::nest_lo): the caller's stream computes phase p on nest[p] and never waits for the
   // boundary stream inside an evaluation; the boundary stream computes the complement (one row more per phase on a strip),
@@ -2048,31 +2071,12 @@ int esdg_lsrk45_step(esdg_ctx* ctx, double* Q, double* resQ, double dt, void* st
                                  2277821191437.0 / 14882151754819.0};
   if (!ctx || !Q || !resQ) return fail(ESDG_ERR_ARG, "null argument");
   if (!ctx->use_fast) return fail(ESDG_ERR_STATE, "esdg_lsrk45_step needs the tensor / hex kernels (fused stage)");
-  // Cross-stage fusion (opt-in: ESDG_STAGE_FUSION=1 at esdg_create): on an unsharded 2D context whose last
-  // phase is kt3_rhs, stage k's last phase -- which holds the updated state in registers -- also writes the trace records phase 0
-  // of stage k + 1 would compute from it, into the second A_U buffer (the first is still being read by the neighbours'
-  // workgroups); stages 1 ... 4 then start at phase 1.  Bitwise the unfused step (tests/test_gpu_drivers.py).  Measured in
-  // round 4 at cfg3: 0.729-0.738 ms per stage against 0.635-0.637 without it (Euler cfg2: 0.092-0.094 vs 0.090-0.096) -- kt3_rhs
-  // is bound by vector-instruction issue, and phase 0's arithmetic costs more inside it (node rounds at 78 % lane use, two more
-  // LDS exchanges per one-shot wave, 28 spilled registers) than the memory-bound kt2_project launch it saves.  Hence off.
-  const bool fuse = ctx->stage_fusion && ctx->dim == 2 && ctx->nghost == 0 && ctx->off_AU2 && !ctx->bf && !(ctx->ph.dbg & ~32) &&
-                    !(ctx->v2 & 2) && ctx->T.N1 >= 2 && ctx->T.N1 <= ESDG_MAX_N1 && (!ctx->M.bc || ctx->T.N1 < 8);
-  if (!fuse) {
-    for (int k = 0; k < 5; ++k) {
-      int rc = esdg_rhs_lsrk(ctx, Q, resQ, rk4a[k], rk4b[k], dt, stream);
-      if (rc) return rc;
-    }
-    return ESDG_OK;
-  }
-  struct FuseGuard { esdg_ctx* c; ~FuseGuard() { c->au_sel = 0; c->emit_next = false; } } fg{ctx};
-  ctx->au_sel = 0;
+  // (Cross-stage fusion -- stage k's last phase also writing the trace records phase 0 of stage k + 1 would compute -- was built in
+  // round 4, bitwise the plain step, and measured 15 % slower per stage at cfg3: kt3_rhs has no vector-issue slack for phase 0's
+  // arithmetic.  Removed in round 5; the code is in the history up to commit 70ca460, the numbers in profiles/experiments/README.md.)
   for (int k = 0; k < 5; ++k) {
-    ctx->emit_next = k < 4;
-    for (int p = (k == 0 ? 0 : 1); p < ctx->nphases; ++p) {
-      int rc = esdg_rhs_phase_lsrk(ctx, p, Q, resQ, rk4a[k], rk4b[k], dt, stream);
-      if (rc) return rc;
-    }
-    if (k < 4) ctx->au_sel ^= 1;   // the traces just emitted are what the next stage reads
+    int rc = esdg_rhs_lsrk(ctx, Q, resQ, rk4a[k], rk4b[k], dt, stream);
+    if (rc) return rc;
   }
   return ESDG_OK;
 }

@@ -62,6 +62,9 @@ constexpr int SIGMA2_MAX_PARTIALS = 8192;   // >= the persistent grid of kt2_sig
 int launch_sigma_tensor2(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
                          double* B, double* SG, hipStream_t s, double* vt_partial = nullptr);
 int launch_project_tensor2(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, double* A_U, hipStream_t s);
+// knobs of the A/B builds (-DESDG_AB_HOOKS): set by esdg_api.hip from the environment, never by the shipped library
+void ab_tuning_t2(int wg_per_cu, int reserve);   // (-1 = leave)
+void ab_tuning_hex(int line);
 // v3 last-phase kernel (esdg_kernels_tensor3.hip); -1 where it does not apply
 struct StageFuse;
 int launch_rhs_tensor3(int N1, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
@@ -154,10 +157,6 @@ struct LsrkFuse {
   double* Qw;   // the state, updated in place (null = plain rhs store)
   double* res;
   double a, b, dt;
-  // Cross-stage fusion (round 4, esdg_lsrk45_step on unsharded 2D contexts): non-null = the last phase also emits the NEXT stage's
-  // phase 0 from the state it has just updated -- the (rho, u, v, beta) trace records of its elements into this second trace buffer
-  // (the current one is still being read by the neighbours' workgroups) -- so the next stage starts at phase 1.  kt3_rhs only.
-  double* AUn;
 };
 
 // optional fusion of the DOPRI45 stage combination and error norm into the last phase (esdg_dopri45_attempt; the STG

@@ -1364,6 +1364,9 @@ int launch_project_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phy
   return (int)hipGetLastError();
 }
 
+static int g_hex_line = 1;   // kh_rhs_l; 0 = kh_rhs / kh_rhs_g (A/B builds: esdg_api.hip under -DESDG_AB_HOOKS, ESDG_HEX_LINE=0)
+void ab_tuning_hex(int line) { g_hex_line = line; }
+
 int launch_rhs_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
                    double* rhs, const LsrkFuse& lf, hipStream_t s) {
   if (M.e_count <= 0) return 0;
@@ -1372,9 +1375,7 @@ int launch_rhs_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phys& p
   // 1.23 ms for kh_rhs; N = 1, 2: 0.65, 0.83 x kh_rhs; N = 4 ... 7: 0.47 ... 0.74 x the row-wise kh_rhs_g);
   // ESDG_HEX_LINE=0: kh_rhs / kh_rhs_g (A/B).
   {
-    static int line = -2;
-    if (line == -2) { const char* env = getenv("ESDG_HEX_LINE"); line = !env ? -1 : (env[0] == '1' ? 1 : 0); }
-    if (line != 0) {
+    if (g_hex_line != 0) {   // (0 only in A/B builds: ab_tuning_hex)
 #define ESDG_HEXL_LAUNCH(N1c)                                                                                                 \
   case N1c: {                                                                                                                \
     const dim3 grid((unsigned)((M.e_count + hdev::LCfg<N1c>::E - 1) / hdev::LCfg<N1c>::E)), blk(hdev::LCfg<N1c>::T);         \

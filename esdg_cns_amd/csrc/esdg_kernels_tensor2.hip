@@ -145,6 +145,10 @@ __device__ __forceinline__ void vq_apply(const double* c, d2* sA, d2* sB0, d2* s
 // kt2_sigma by s_memtime stamps); inline-asm loads with counted waits remove that wait, but hipcc then copies the asm
 // destinations between registers before the data has landed (audited in the .s), so the loads stay compiler-managed.
 // grid = what the device holds at once (occupancy query; ESDG_T2_WG_PER_CU overrides for experiments)
+// Tuning knobs of the A/B builds (esdg_api.hip under -DESDG_AB_HOOKS sets them from the environment through ab_tuning_t2; the
+// shipped library never changes them): persistent workgroups per CU (0 = the occupancy query), slots the interior launch of a
+// sharded schedule leaves to its boundary strips.
+int g_wg_per_cu = 0, g_reserve = 64;
 template <auto kernel>
 __host__ inline int persistent_grid(int threads, int64_t ngroups) {
   static int per_cu = 0, cus = 0;     // one pair per kernel (the kernel is the template argument)
@@ -154,7 +158,7 @@ __host__ inline int persistent_grid(int threads, int64_t ngroups) {
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) != hipSuccess || n < 1) n = 2;
-    if (const char* env = getenv("ESDG_T2_WG_PER_CU")) n = atoi(env) > 0 ? atoi(env) : n;
+    if (g_wg_per_cu > 0) n = g_wg_per_cu;   // (A/B builds only: esdg_ab_tuning)
     per_cu = n;
   }
   const int64_t g = (int64_t)cus * per_cu;
@@ -1432,8 +1436,7 @@ static void launch_sigma2w(const TensorTables& TT, const MeshDev& M, const Phys&
     // (the schedule says which launch is which -- MeshDev::launch_role; any other ranged launch, e.g. the pieces of
     // esdg_rhs_phase_range, gets the full grid)
     if (M.launch_role) {
-      static int reserve = -1;
-      if (reserve < 0) { const char* env = getenv("ESDG_T2_RESERVE"); reserve = env ? atoi(env) : 64; }
+      const int reserve = t2::g_reserve;
       if (reserve > 0) {
         const int cap = t2::persistent_grid<t2::kt2_sigma<N1, true, WALLS>>(G::GT, (int64_t)1 << 40);
         if (M.launch_role == 1) { if (nb > cap - reserve && cap - reserve > 0) nb = cap - reserve; }   // interior
@@ -1485,6 +1488,11 @@ int launch_rhs_tensor2(int N1v, const TensorTables& TT, const MeshDev& M, const 
     }
   });
   return (int)hipGetLastError();
+}
+
+void ab_tuning_t2(int wg_per_cu, int reserve) {
+  if (wg_per_cu >= 0) t2::g_wg_per_cu = wg_per_cu;
+  if (reserve >= 0) t2::g_reserve = reserve;
 }
 
 // phase 0 with the v2 kernel; returns -1 where it does not cover the degree (the caller refuses the degree)

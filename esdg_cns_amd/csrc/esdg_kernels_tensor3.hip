@@ -97,10 +97,13 @@ constexpr int wpe3(int N1, bool walls_cns) { return N1 <= 4 ? 3 : (N1 <= 6 ? (wa
 #else
 #define T3_NVGPR_ATTR
 #endif
-template <int N1, bool MODAL, bool VISC, bool WALLS, bool EMIT = false, bool STG = false>
-__global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_eu(wpe3(N1, WALLS && VISC && MODAL)))) void kt3_rhs(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
+template <int N1, bool MODAL, bool VISC, bool WALLS, bool STG = false>
+__global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_eu(wpe3(N1, WALLS && VISC && MODAL)))) void kt3_rhs(TensorTables TT, MeshDev M, Phys ph, const double* Q,
                                                           const double* __restrict__ A_U, const double* __restrict__ SG,
-                                                          const double* __restrict__ B, double* __restrict__ rhs, LsrkFuse lf, StageFuse sf) {
+                                                          const double* __restrict__ B, double* rhs, LsrkFuse lf, StageFuse sf) {
+  // (Q and rhs are NOT restrict-qualified: the fused RK forms write the state in place -- lf.Qw, StageFuse::y may be the array Q
+  // points to -- and the DOPRI error stage re-reads rhs.  The in-place update is safe because a wave reads its elements' state at
+  // entry only; the compiler fence in front of the epilogue keeps every Q load above every store.)
   using G = G3<N1>;
   constexpr int TW = G::TW, Nq = G::Nq, Nfq = G::Nfq, NLN = G::NLN, E = G::E, NV = G::NV, LL = G::LL, NR = G::NR;
   constexpr TensorLayout TL(N1);
@@ -188,7 +191,6 @@ __global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_e
     }
   }
 
-  constexpr int NF = G::NF, NFR = (NF + TW - 1) / TW;   // (EMIT: face nodes of the wave, rounds of the face-node layout)
   // ---- staging: geometry, tables, nodal values ------------------------------------------------------------------------------
 #pragma unroll
   for (int i = 0; i < GPT; ++i) sGeo[tid + i * TW] = geo[i];
@@ -546,34 +548,16 @@ __global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_e
 #pragma unroll
       for (int f = 0; f < 4; ++f) out[r][f] = R[r][f];
   }
+  asm volatile("" ::: "memory");   // (no load of the state sinks below this point: the epilogue may overwrite it in place)
   if (STG || ESDG_T3_PIN_OUT) {   // (the results in registers before any of the epilogue's loads is issued)
 #pragma unroll
     for (int r = 0; r < NR; ++r) T3_PIN4(out[r]);
   }
   // ---- store, or fused low-storage RK stage (dg2D_euler_quad.jl:204-205) -------------------------------------------------------
-  double qn[EMIT ? NR : 1][4];   // EMIT: the updated state of this lane's nodes
   double stg_acc = 0.0;          // STG: this lane's part of the error norm
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const unsigned n = tid + r * TW;
-    if (EMIT) {   // every lane forms the update of its slot's node; only the owner stores it.  (A duplicate slot -- n >= NV -- reads
-                  // res / Q AFTER its owner, an earlier round of this wave, has stored the update: its value is wrong, and it
-                  // must not reach LDS -- the emission below writes from lanes with n < NV only.)
-      const unsigned nc = slot[r] < (unsigned)(nE * Nq) ? slot[r] : 0u;
-      const bool own = n < (unsigned)(nE * Nq);
-      double ro[4], qo[4];
-#pragma unroll
-      for (int f = 0; f < 4; ++f) { const int64_t idx = f * KN + e0 * Nq + nc; ro[f] = lf.res[idx]; qo[f] = lf.Qw[idx]; }
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        const int64_t idx = f * KN + e0 * Nq + nc;
-        const double rr = __builtin_fma(lf.a, ro[f], lf.dt * out[r][f]);
-        const double qw = __builtin_fma(lf.b, rr, qo[f]);
-        if (own) { lf.res[idx] = rr; lf.Qw[idx] = qw; }
-        qn[r][f] = qw;
-      }
-      continue;
-    }
     if (STG) {   // DOPRI45: the store of k_s plus the next stage's state / the error norm (StageFuse, esdg_dev.hpp)
       T3_FENCE();   // (one round's loads at a time: hoisted together they spill)
       if (n < (unsigned)(nE * Nq)) {
@@ -638,108 +622,6 @@ __global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_e
     for (int off = 32; off > 0; off >>= 1) stg_acc += __shfl_xor(stg_acc, off, 64);
     if (tid == 0) sf.partial[blockIdx.x] = stg_acc;
   }
-  // ---- EMIT: phase 0 of the NEXT stage for this wave's elements, from the state just updated (LsrkFuse::AUn) -----------------------
-  // The statements of kt2_project (esdg_kernels_tensor2.hip) in the same order -- Vq as above, prim_logs, v_of_prim2, the face
-  // extrapolation c_0 p + fma ..., prim_of_v2 -- so the records are bit for bit what kt2_project would write for that state
-  // (tests/test_gpu_drivers.py: the fused and the unfused five-stage step agree bitwise).
-  if (EMIT) {
-    // the face nodes this lane serves (face-node layout: slot = lane + 64 round), their line codes d | t << 1 | o << 2
-    // (TensorLayout::FINV; requested here, used after the node rounds below -- not at entry: two registers less through the line stage)
-    int fcode[NFR];
-#pragma unroll
-    for (int fr = 0; fr < NFR; ++fr) { const unsigned tf = tid + fr * TW, tfc = tf < (unsigned)NF ? tf : tf - NF; fcode[fr] = TT.ints[TL.FINV + tfc % Nfq]; }
-    double Un[NR][4];
-    if (MODAL) {
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        if (tid + r * TW < (unsigned)NV) {
-          sA[slot[r]] = make_double2(qn[r][0], qn[r][1]);
-          sA[NV + slot[r]] = make_double2(qn[r][2], qn[r][3]);
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        const unsigned ev = slot[r] / Nq, a = nq[r] % N1, b = nq[r] / N1;
-        const double* c = sTab + TL.IQ + a * N1;
-        const d2* rw = sA + ev * Nq + N1 * b;
-        d2 p = rw[0], t = rw[NV];
-        const double c0 = c[0];
-        double w0 = c0 * p.x, w1 = c0 * p.y, w2 = c0 * t.x, w3 = c0 * t.y;
-#pragma unroll
-        for (int i = 1; i < N1; ++i) {
-          p = rw[i]; t = rw[NV + i];
-          const double ci = c[i];
-          w0 = __builtin_fma(ci, p.x, w0); w1 = __builtin_fma(ci, p.y, w1);
-          w2 = __builtin_fma(ci, t.x, w2); w3 = __builtin_fma(ci, t.y, w3);
-        }
-        sB[slot[r]] = make_double2(w0, w1);        // (duplicate slots: computed from the planes, i.e. the owner's value again)
-        sB[NV + slot[r]] = make_double2(w2, w3);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        const unsigned ev = slot[r] / Nq, a = nq[r] % N1, b = nq[r] / N1;
-        const double* c = sTab + TL.IQ + a * N1;
-        const d2* rw = sB + ev * Nq + b;
-        d2 p = rw[0], t = rw[NV];
-        const double c0 = c[0];
-        Un[r][0] = c0 * p.x; Un[r][1] = c0 * p.y; Un[r][2] = c0 * t.x; Un[r][3] = c0 * t.y;
-#pragma unroll
-        for (int j = 1; j < N1; ++j) {
-          p = rw[N1 * j]; t = rw[NV + N1 * j];
-          const double cj = c[j];
-          Un[r][0] = __builtin_fma(cj, p.x, Un[r][0]); Un[r][1] = __builtin_fma(cj, p.y, Un[r][1]);
-          Un[r][2] = __builtin_fma(cj, t.x, Un[r][2]); Un[r][3] = __builtin_fma(cj, t.y, Un[r][3]);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < NR; ++r)
-#pragma unroll
-        for (int f = 0; f < 4; ++f) Un[r][f] = qn[r][f];
-    }
-    __syncthreads();   // every lane is past its reads of the buffers, the first of which takes the entropy variables
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      T3_FENCE();   // (one round at a time: interleaved, the logarithms of three rounds push the kernel over its register budget)
-      double qh[6], V[4];
-      prim_logs<MODAL>(Un[r], qh);
-      t2::v_of_prim2<MODAL>(qh, V);
-      if (MODAL || tid + r * TW < (unsigned)NV) {   // (collocated: a duplicate slot's state is not the owner's, see above)
-        sA[slot[r]] = make_double2(V[0], V[1]);
-        sA[NV + slot[r]] = make_double2(V[2], V[3]);
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int fr = 0; fr < NFR; ++fr) {   // face nodes: Vf = Ef * V along the node's line, then the primitive state of u(Vf)
-      T3_FENCE();
-      const unsigned tf = tid + fr * TW, tfc = tf < (unsigned)NF ? tf : tf - NF;
-      const unsigned ef = tfc / Nfq, fn = tfc - ef * Nfq;
-      const int code = fcode[fr], dd = code & 1, tt = (code >> 1) & 1, oo = code >> 2;
-      const unsigned fnode0 = ef * Nq + (dd ? oo : N1 * oo), fstride = dd ? N1 : 1;
-      const double* ee = sTab + TL.EE + (2 * dd + tt) * N1;
-      d2 p0 = sA[fnode0], p1 = sA[NV + fnode0];
-      const double e0w = ee[0];
-      double Vf[4] = {e0w * p0.x, e0w * p0.y, e0w * p1.x, e0w * p1.y};
-#pragma unroll
-      for (int j = 1; j < N1; ++j) {
-        p0 = sA[fnode0 + j * fstride]; p1 = sA[NV + fnode0 + j * fstride];
-        const double ej = ee[j];
-        Vf[0] = __builtin_fma(ej, p0.x, Vf[0]); Vf[1] = __builtin_fma(ej, p0.y, Vf[1]);
-        Vf[2] = __builtin_fma(ej, p1.x, Vf[2]); Vf[3] = __builtin_fma(ej, p1.y, Vf[3]);
-      }
-      double qf[4];
-      t2::prim_of_v2<MODAL>(Vf, qf);
-      if (tf < (unsigned)(nE * Nfq)) {
-        d2* rec = reinterpret_cast<d2*>(lf.AUn + trace_slot<N1>(M, e0 + ef, fn) * FAU_NC);
-        rec[0] = make_double2(qf[0], qf[1]);
-        rec[1] = make_double2(qf[2], qf[3]);
-      }
-    }
-  }
 }
 
 }  // namespace t3
@@ -771,14 +653,9 @@ static void launch_rhs3(const TensorTables& TT, const MeshDev& M, const Phys& ph
   const StageFuse sf0{};
   if (sf) {   // DOPRI45 stage (esdg_dopri45_attempt): instantiated for the CNS formulation, which is what the reference integrates so
     if constexpr (MODAL && VISC) {
-      if (M.bc) hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, true, false, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, *sf);
-      else hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, false, false, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, *sf);
+      if (M.bc) hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, true, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, *sf);
+      else hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, false, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, *sf);
     }
-    return;
-  }
-  if (lf.AUn) {   // fused RK stage that also emits the next stage's traces (esdg_lsrk45_step)
-    if (M.bc) hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, true, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, sf0);
-    else hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, false, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, sf0);
     return;
   }
   if (M.bc) hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, sf0);

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import check, esdg_hex_mesh_t, esdg_hex_ops_t, esdg_mesh_t, esdg_ops_t, esdg_phys_t
+from ._lib import check_on as _chk, esdg_hex_mesh_t, esdg_hex_ops_t, esdg_mesh_t, esdg_ops_t, esdg_phys_t
 
 EULER_COLLOCATED, CNS_MODAL, EULER_MODAL, EULER_HEX_COLLOCATED = 0, 1, 2, 3
 
@@ -78,13 +78,23 @@ class HaloExchanger:
         pending[2] = True
 
 
+def check(rc):
+    """For callers that drive the C ABI themselves (tests, tools): raise on a non-zero status, with the message of whichever
+    loaded build of the library holds one (the engine's own calls go through _lib.check_on with their library)."""
+    if rc != 0:
+        msgs = [L.esdg_last_error().decode() for L in _lib._LIBS.values()]
+        raise _lib.EsdgError(f"libesdg_hip error {rc}: " + " | ".join(m for m in msgs if m))
+
+
 class RhsEngine:
     """One esdg_ctx: operators + (local shard of the) mesh resident on one MI355X."""
 
     def __init__(self, rd, md, ops, formulation, lf_scale=None, inviscid_dissp=True, viscous_dissp=True, BCTYPE=1,
                  Re=1000.0, mu=None, lam=None, Pr=.71, device=None, rank=0, nranks=1, rank_offsets=None, group=None,
-                 inflow=None, inflow_nodes=None, vlid=None):
-        L = _lib.lib()
+                 inflow=None, inflow_nodes=None, vlid=None, ab_hooks=False):
+        # ab_hooks: the A/B build of the library (libesdg_hip_ab.so), whose esdg_create reads the ESDG_* environment switches that
+        # select partner kernels / geometry modes / schedule variants; the shipped library (default) reads no environment variable
+        L = _lib.lib(ab=ab_hooks)
         if not torch.cuda.is_available() or L.esdg_device_count() < 1:
             raise _lib.EsdgError("no MI355X/HIP device visible: the RHS engine has no CPU path")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -102,7 +112,7 @@ class RhsEngine:
         self.nphases = L.esdg_num_phases(ctx)
         nbytes = int(L.esdg_workspace_bytes(ctx))
         self.ws = torch.zeros(max(nbytes, 256), dtype=torch.uint8, device=self.device)
-        check(L.esdg_bind_workspace(ctx, C.c_void_p(self.ws.data_ptr()), nbytes))
+        _chk(L, L.esdg_bind_workspace(ctx, C.c_void_p(self.ws.data_ptr()), nbytes))
 
         # halo plan
         self.nranks = nranks
@@ -113,19 +123,19 @@ class RhsEngine:
         segs = []
         for x in range(L.esdg_num_exchanges(ctx)):
             a, b, nc = C.c_int32(), C.c_int32(), C.c_int32()
-            check(L.esdg_exchange_info(ctx, x, C.byref(a), C.byref(b), C.byref(nc)))
+            _chk(L, L.esdg_exchange_info(ctx, x, C.byref(a), C.byref(b), C.byref(nc)))
             self.xinfo.append((a.value, b.value, nc.value))
             s = []
             for n in range(nn):
                 peer = C.c_int32()
                 so, sb, ro, rb = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
-                check(L.esdg_halo_segment(ctx, x, n, C.byref(peer), C.byref(so), C.byref(sb), C.byref(ro), C.byref(rb)))
+                _chk(L, L.esdg_halo_segment(ctx, x, n, C.byref(peer), C.byref(so), C.byref(sb), C.byref(ro), C.byref(rb)))
                 s.append((peer.value, so.value, sb.value, ro.value, rb.value))
             segs.append(s)
         if nn:
             self.halo = HaloExchanger(segs, group)
         lo, hi = C.c_int64(), C.c_int64()
-        check(L.esdg_interior_range(ctx, C.byref(lo), C.byref(hi)))
+        _chk(L, L.esdg_interior_range(ctx, C.byref(lo), C.byref(hi)))
         self.interior = (lo.value, hi.value)
         # overlap exchanges with the interior elements (tensor / hex kernels); ESDG_NO_OVERLAP=1 restores phase-by-phase
         import os
@@ -143,9 +153,9 @@ class RhsEngine:
         L, ctx = self.L, self.ctx
         idb = (C.c_ubyte * 128)()
         if loopback:
-            check(L.esdg_comm_set_loopback(ctx, 1))
-            check(L.esdg_comm_unique_id(idb))
-            check(L.esdg_comm_init(ctx, idb, 0, 1))
+            _chk(L, L.esdg_comm_set_loopback(ctx, 1))
+            _chk(L, L.esdg_comm_unique_id(idb))
+            _chk(L, L.esdg_comm_init(ctx, idb, 0, 1))
         else:
             import torch.distributed as dist
             rank = dist.get_rank(group)
@@ -153,7 +163,7 @@ class RhsEngine:
             t = torch.zeros(128, dtype=torch.uint8, device=self.device if on_dev else "cpu")
             if rank == 0:      # (an error here must not keep rank 0 out of the broadcast its peers are waiting in)
                 try:
-                    check(L.esdg_comm_unique_id(idb))
+                    _chk(L, L.esdg_comm_unique_id(idb))
                     t.copy_(torch.frombuffer(bytearray(bytes(idb)), dtype=torch.uint8))
                 except Exception:  # noqa: BLE001
                     t.zero_()
@@ -161,14 +171,14 @@ class RhsEngine:
             raw = bytes(t.cpu().numpy().tobytes())
             if not any(raw):
                 raise RuntimeError("rank 0 could not create the RCCL unique id (esdg_comm_unique_id)")
-            check(L.esdg_comm_init(ctx, C.create_string_buffer(raw, 128), rank, dist.get_world_size(group)))
+            _chk(L, L.esdg_comm_init(ctx, C.create_string_buffer(raw, 128), rank, dist.get_world_size(group)))
         self.transport = "rccl"
         return int(L.esdg_comm_size(ctx))
 
     def allreduce(self, vals, op="sum"):
         """Sum / max / min of a few host doubles over the ranks of the library's communicator (esdg_comm_allreduce)."""
         a = (C.c_double * len(vals))(*[float(v) for v in vals])
-        check(self.L.esdg_comm_allreduce(self.ctx, a, len(vals), {"sum": 0, "max": 1, "min": 2}[op], self._stream()))
+        _chk(self.L, self.L.esdg_comm_allreduce(self.ctx, a, len(vals), {"sum": 0, "max": 1, "min": 2}[op], self._stream()))
         return list(a)
 
     def _create_hex(self, L, rd, md, ops, lf_scale, rank, nranks, rank_offsets):
@@ -201,7 +211,7 @@ class RhsEngine:
         p.formulation = EULER_HEX_COLLOCATED
         p.lf_scale = float(lf_scale)
         ctx = C.c_void_p()
-        check(L.esdg_create_hex(C.byref(o), C.byref(m), C.byref(p), C.byref(ctx)))
+        _chk(L, L.esdg_create_hex(C.byref(o), C.byref(m), C.byref(p), C.byref(ctx)))
         return ctx
 
     def _create_2d(self, L, rd, md, ops, formulation, lf_scale, inviscid_dissp, viscous_dissp, BCTYPE, Re, mu, lam, Pr,
@@ -299,7 +309,7 @@ class RhsEngine:
             p.inflow_rho, p.inflow_u, p.inflow_v, p.inflow_p = (float(x) for x in inflow)
 
         ctx = C.c_void_p()
-        check(L.esdg_create(C.byref(o), C.byref(m), C.byref(p), C.byref(ctx)))
+        _chk(L, L.esdg_create(C.byref(o), C.byref(m), C.byref(p), C.byref(ctx)))
         return ctx
 
     def __del__(self):
@@ -353,7 +363,7 @@ class RhsEngine:
                 ranged(ph, 0, lo)                                # boundary ranges
                 ranged(ph, hi, self.K - hi)
                 for x in outgoing:
-                    check(L.esdg_halo_pack(ctx, x, self._stream()))
+                    _chk(L, L.esdg_halo_pack(ctx, x, self._stream()))
             if outgoing:                                         # one batch (one RCCL group) per producing phase
                 tok = self.halo.start(self.ws, outgoing)
                 for x in outgoing:
@@ -366,11 +376,11 @@ class RhsEngine:
         assert Qd.is_contiguous() and out.is_contiguous() and Qd.dtype == torch.float64
         L, ctx, s = self.L, self.ctx, self._stream()
         if self.halo is None or self.transport == "rccl":
-            check(L.esdg_rhs(ctx, C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr()), s))
+            _chk(L, L.esdg_rhs(ctx, C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr()), s))
             return out
         q, o = C.c_void_p(Qd.data_ptr()), C.c_void_p(out.data_ptr())
-        self._phases(lambda ph: check(L.esdg_rhs_phase(ctx, ph, q, o, self._stream())),
-                     lambda ph, e0, n: check(L.esdg_rhs_phase_range(ctx, ph, e0, n, q, o, self._stream())))
+        self._phases(lambda ph: _chk(L, L.esdg_rhs_phase(ctx, ph, q, o, self._stream())),
+                     lambda ph, e0, n: _chk(L, L.esdg_rhs_phase_range(ctx, ph, e0, n, q, o, self._stream())))
         return out
 
     def rhs(self, Qd):
@@ -379,7 +389,7 @@ class RhsEngine:
     def rhstest(self, Qd, rhsd):
         """sum(wJq .* v(u) .* rhs) over the local elements (euler_quad.jl:186-191)."""
         diag = (C.c_double * 2)()
-        check(self.L.esdg_rhstest(self.ctx, C.c_void_p(Qd.data_ptr()), C.c_void_p(rhsd.data_ptr()), diag, self._stream()))
+        _chk(self.L, self.L.esdg_rhstest(self.ctx, C.c_void_p(Qd.data_ptr()), C.c_void_p(rhsd.data_ptr()), diag, self._stream()))
         return diag[0]
 
     # ---- error functionals of the drivers, evaluated on the device (SURVEY.md section 8(f) rank 4) ----
@@ -401,7 +411,7 @@ class RhsEngine:
         if boundary:
             keep["e_Vf"], keep["e_wf"] = _f(rd.Vf), _f(rd.wf)
             e.Vf, e.wf = _dp(keep["e_Vf"]), _dp(keep["e_wf"])
-        check(self.L.esdg_error_setup(self.ctx, C.byref(e)))
+        _chk(self.L, self.L.esdg_error_setup(self.ctx, C.byref(e)))
 
     @staticmethod
     def _par(par):
@@ -427,14 +437,14 @@ class RhsEngine:
         """(L2err, per-field sums of squares) against vortex (exact=0) or the Becker shock (exact=1, par) at time t,
         dg2D_euler_quad.jl:214-233; on a sharded mesh the sums are added over the ranks before the square root."""
         out = (C.c_double * 5)()
-        check(self.L.esdg_error_l2(self.ctx, C.c_void_p(Qd.data_ptr()), exact, self._par(par), float(t), out, self._stream()))
+        _chk(self.L, self.L.esdg_error_l2(self.ctx, C.c_void_p(Qd.data_ptr()), exact, self._par(par), float(t), out, self._stream()))
         sums, _ = self._reduce(sums=list(out)[1:])
         return float(np.sqrt(sum(sums))) if self.nranks > 1 else out[0], sums
 
     def nodal_error(self, Qd, t, exact=1, par=None):
         """(L1err, Linferr, raw) of dg2D_CNS_modalESDG.jl:745-771 (sums and maxima reduced over the ranks)."""
         out = (C.c_double * 14)()
-        check(self.L.esdg_error_nodal(self.ctx, C.c_void_p(Qd.data_ptr()), exact, self._par(par), float(t), out, self._stream()))
+        _chk(self.L, self.L.esdg_error_nodal(self.ctx, C.c_void_p(Qd.data_ptr()), exact, self._par(par), float(t), out, self._stream()))
         raw = list(out)[2:]
         if self.nranks <= 1:
             return out[0], out[1], raw
@@ -447,19 +457,19 @@ class RhsEngine:
         """dg2D_CNS_convergence_test.jl:1055-1080 (Jf = 2/K1D there) -> (err as executed by Julia: the u_2 term only,
         err as written: all three terms, the three sums); see include/esdg_hip.h."""
         out = (C.c_double * 5)()
-        check(self.L.esdg_error_boundary_velocity(self.ctx, C.c_void_p(Qd.data_ptr()), float(Jf), out, self._stream()))
+        _chk(self.L, self.L.esdg_error_boundary_velocity(self.ctx, C.c_void_p(Qd.data_ptr()), float(Jf), out, self._stream()))
         sums, _ = self._reduce(sums=list(out)[2:])
         return float(np.sqrt(sums[0])), float(np.sqrt(sum(sums))), sums
 
     def check_state(self, Qd):
         """(min rho, min p) over the local nodal values; the reference raises DomainError where these are <= 0."""
         out = (C.c_double * 2)()
-        check(self.L.esdg_check_state(self.ctx, C.c_void_p(Qd.data_ptr()), out, self._stream()))
+        _chk(self.L, self.L.esdg_check_state(self.ctx, C.c_void_p(Qd.data_ptr()), out, self._stream()))
         return out[0], out[1]
 
     def set_parts(self, parts):
         """1 = rhs_inviscid! only, 2 = rhs_viscous! only, 3 = rhsRK! (default)."""
-        check(self.L.esdg_set_parts(self.ctx, int(parts)))
+        _chk(self.L, self.L.esdg_set_parts(self.ctx, int(parts)))
 
     def rhsRK_diagnostics(self, Qd, rhsd=None):
         """(rhstest, rhstest_visc) of rhsRK! (cavity_optimized.jl:958-969) for the state Qd."""
@@ -472,7 +482,7 @@ class RhsEngine:
         finally:
             self.set_parts(3)
         vt = C.c_double(0.0)
-        check(self.L.esdg_viscous_entropy_test(self.ctx, C.c_void_p(Qd.data_ptr()), C.byref(vt), self._stream()))
+        _chk(self.L, self.L.esdg_viscous_entropy_test(self.ctx, C.c_void_p(Qd.data_ptr()), C.byref(vt), self._stream()))
         return rt, self.rhstest(Qd, visc) + vt.value
 
     def rhs_host(self, Q):
@@ -481,12 +491,12 @@ class RhsEngine:
         out = [np.zeros_like(q) for q in Qh]
         qa = (_lib.c_double_p * len(Qh))(*[_dp(q) for q in Qh])
         ra = (_lib.c_double_p * len(Qh))(*[_dp(r) for r in out])
-        check(self.L.esdg_rhs_host(self.ctx, qa, ra))
+        _chk(self.L, self.L.esdg_rhs_host(self.ctx, qa, ra))
         return out
 
     # -- time integration (the step either side of the path) -------------------------------------
     def lsrk_update(self, Qd, resd, rhsd, a, b, dt):
-        check(self.L.esdg_lsrk_update(C.c_void_p(Qd.data_ptr()), C.c_void_p(resd.data_ptr()), C.c_void_p(rhsd.data_ptr()),
+        _chk(self.L, self.L.esdg_lsrk_update(C.c_void_p(Qd.data_ptr()), C.c_void_p(resd.data_ptr()), C.c_void_p(rhsd.data_ptr()),
                                       float(a), float(b), float(dt), Qd.numel(), self._stream()))
 
     def rhs_lsrk_fused(self, Qd, resd, a, b, dt):
@@ -495,10 +505,10 @@ class RhsEngine:
         q, r = C.c_void_p(Qd.data_ptr()), C.c_void_p(resd.data_ptr())
         a, b, dt = float(a), float(b), float(dt)
         if self.halo is None or self.transport == "rccl":
-            check(L.esdg_rhs_lsrk(ctx, q, r, a, b, dt, s))
+            _chk(L, L.esdg_rhs_lsrk(ctx, q, r, a, b, dt, s))
             return
-        self._phases(lambda ph: check(L.esdg_rhs_phase_lsrk(ctx, ph, q, r, a, b, dt, self._stream())),
-                     lambda ph, e0, n: check(L.esdg_rhs_phase_range_lsrk(ctx, ph, e0, n, q, r, a, b, dt, self._stream())))
+        self._phases(lambda ph: _chk(L, L.esdg_rhs_phase_lsrk(ctx, ph, q, r, a, b, dt, self._stream())),
+                     lambda ph, e0, n: _chk(L, L.esdg_rhs_phase_range_lsrk(ctx, ph, e0, n, q, r, a, b, dt, self._stream())))
 
     def lsrk45_step_fused(self, Qd, resd, dt, coeffs):
         rk4a, rk4b = coeffs[0], coeffs[1]

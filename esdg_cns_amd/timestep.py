@@ -13,7 +13,7 @@ import math
 import torch
 
 from . import setup_dg as sd
-from ._lib import check
+from ._lib import check_on as _chk
 
 
 def lsrk45_run_graph(eng, Qd, dt, nsteps):
@@ -102,19 +102,19 @@ class Dopri45:
             # phase of each stage (esdg_dopri45_attempt, StageFuse); on a sharded context with the library's communicator the
             # norm is reduced there
             e = C.c_double(0.0)
-            check(L.esdg_dopri45_attempt(eng.ctx, C.c_void_p(self.Q.data_ptr()), C.c_void_p(self.Qtmp.data_ptr()), self._ptrs(self.k),
+            _chk(L, L.esdg_dopri45_attempt(eng.ctx, C.c_void_p(self.Q.data_ptr()), C.c_void_p(self.Qtmp.data_ptr()), self._ptrs(self.k),
                                          self.dt, self.tol, C.byref(e), s))
             self.n_rhs += 6
             return self._finish(e.value)
         for INTRK in range(1, 7):                       # stages 2..7 (:1002-1012)
             coef = (C.c_double * INTRK)(*[float(self.rka[INTRK, j]) for j in range(INTRK)])
-            check(L.esdg_axpy_stages(C.c_void_p(self.Qtmp.data_ptr()), C.c_void_p(self.Q.data_ptr()),
+            _chk(L, L.esdg_axpy_stages(C.c_void_p(self.Qtmp.data_ptr()), C.c_void_p(self.Q.data_ptr()),
                                      self._ptrs(self.k[:INTRK]), coef, INTRK, self.dt, n, s))
             eng.rhs_into(self.Qtmp, self.k[INTRK])
             self.n_rhs += 1
         coefE = (C.c_double * 7)(*[float(x) for x in self.rkE])
         acc = C.c_double(0.0)
-        check(L.esdg_dopri_error(C.c_void_p(self.Q.data_ptr()), self._ptrs(self.k), coefE, 7, self.tol, n, C.byref(acc), s))
+        _chk(L, L.esdg_dopri_error(C.c_void_p(self.Q.data_ptr()), self._ptrs(self.k), coefE, 7, self.tol, n, C.byref(acc), s))
         if self.eng.nranks > 1:
             import torch.distributed as dist
             t = torch.tensor([acc.value], dtype=torch.float64, device=self.Q.device)

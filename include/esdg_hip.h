@@ -17,7 +17,8 @@
  *   - gamma = 1.4 is fixed, as in the reference (EntropyStableEuler.jl:9 and the literals
  *     0.4/1.4/2.4 in dg2D_CNS_cavity_optimized.jl:463-474).
  * No CPU fallback exists: without a HIP device every compute entry point fails with
- * ESDG_ERR_NO_DEVICE.
+ * ESDG_ERR_NO_DEVICE.  The library reads no environment variable; the switches that select partner kernels, geometry modes and
+ * schedule variants for A/B measurements exist only in the separate build libesdg_hip_ab.so (esdg_cns_amd/build.py).
  */
 #ifndef ESDG_HIP_H
 #define ESDG_HIP_H
@@ -59,7 +60,8 @@ typedef enum {
 /* Reference-element operators: fields of `rd::RefElemData` (src/SetupDG.jl:38-75) and of the
  * driver's `ops` tuple.  Column-major.  Pointers not needed by the formulation may be NULL. */
 typedef struct {
-  int32_t N;    /* polynomial degree */
+  int32_t N;    /* polynomial degree.  Quads: periodic meshes 1..9, meshes with walls 1..8; the generic pair-list kernels (operators
+                 * that do not factor into 1D tables) 1..7.  esdg_create refuses anything beyond with the reason. */
   int32_t Np;   /* rows of a state matrix: (N+1)^2 */
   int32_t Nq;   /* volume quadrature nodes: length(rd.wq) */
   int32_t Nfq;  /* face quadrature nodes: length(rd.wf) */
@@ -126,7 +128,7 @@ typedef struct {
 /* Hexahedral path: operators of examples/dg3D_euler_hex.jl:34-98 (quadrature basis) and the 3D MeshData
  * fields the driver holds when it calls `rhs` (:167).  Same conventions as above. */
 typedef struct {
-  int32_t N;    /* polynomial degree: quads 1..9 (N = 8, 9: tensor kernels only, no visc_test diagnostic), hexahedra 1..7 */
+  int32_t N;    /* polynomial degree: hexahedra 1..9 (one element per workgroup from N = 7 on; affine and curved meshes) */
   int32_t Nq;   /* (N+1)^3 */
   int32_t Nfq;  /* 6 (N+1)^2 */
   const double *Qrhskew, *Qshskew, *Qthskew; /* (Nh x Nh), dg3D_euler_hex.jl:49-51 */
@@ -215,7 +217,8 @@ int esdg_check_state(esdg_ctx* ctx, const double* Q_dev, double* min_rho_p, void
  * (default).  esdg_viscous_entropy_test returns the second value of rhs_viscous!,
  *   visc_test = sum(wJq .* (VUx .* sigma_x + VUy .* sigma_y))   (:802-806),
  * so that rhsRK!'s third return is  rhstest_visc = esdg_rhstest(Q, rhs_viscous) + visc_test  (:962-969).
- * (Runs phases 0 and 1 itself; synchronises `stream`.  On a sharded context -- communicator attached -- it exchanges
+ * (Every degree the context serves: the reduction rides in the phase-1 kernel.  Runs phases 0 and 1 itself; synchronises
+ * `stream`.  On a sharded context -- communicator attached -- it exchanges
  * the traces of phase 0 and returns this rank's share of the sum, like esdg_rhstest: add the shares with
  * esdg_comm_allreduce.) */
 int esdg_set_parts(esdg_ctx* ctx, int parts);
@@ -356,7 +359,11 @@ int esdg_dopri_error(const double* Q_dev, const double* const* k_dev, const doub
  * On CNS contexts served by the tensor kernels (unsharded, or sharded with a communicator attached) the stage combinations and the
  * error norm are computed inside the last-phase launch of each stage from the k_s it holds in registers (no separate passes
  * over the state; esdg_axpy_stages / esdg_dopri_error above are then not used): per node the same bits, the estimate to summation
- * order, 4.6 instead of 5.1 ms per attempt at N=4 on 512x512.  ESDG_DOPRI_FUSION=0 at esdg_create: always the separate passes.
+ * order, 4.6 instead of 5.1 ms per attempt at N=4 on 512x512.
+ * Reproducibility of the estimate: it is a sum of one partial per workgroup of the last-phase launches, so its last bits depend on
+ * how a context cuts that phase into launches (stand-alone, or interior + boundary strips of a sharded schedule) and on whether
+ * the fused or the separate-pass form runs.  An adaptive run (step sizes follow the estimate) is bitwise reproducible for a FIXED
+ * sharding and library build; the states, all k_s and the accept / reject decisions of one attempt do not depend on either.
  * (The accept copy Q <- Qtmp may be a pointer swap on the caller's side: the library keeps no reference to either array.) */
 int esdg_lsrk45_step(esdg_ctx* ctx, double* Q_dev, double* resQ_dev, double dt, void* stream);
 int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q_dev, double* Qtmp_dev, double* const* k_dev, double dt, double err_tol,

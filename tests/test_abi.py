@@ -48,6 +48,26 @@ def test_no_cpu_fallback():
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
 
 
+def test_shipped_library_reads_no_environment_variable():
+    """The environment switches that select partner kernels, geometry modes and schedule variants exist in the A/B build only
+    (libesdg_hip_ab.so: the same kernel objects, csrc/esdg_api.hip compiled under -DESDG_AB_HOOKS).  The shipped library does not
+    even import getenv; no kernel source calls it; both builds export the same ABI."""
+    import subprocess
+    from esdg_cns_amd import _lib
+    def undefined(path):
+        out = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+        return {ln.split()[-1].split("@")[0] for ln in out.splitlines() if ln.strip()}
+    main, ab = undefined(_lib.LIB_PATH), undefined(_lib.AB_LIB_PATH)
+    assert "getenv" not in main and "secure_getenv" not in main
+    assert "getenv" in ab
+    csrc = os.path.join(ROOT, "esdg_cns_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f != "esdg_api.hip":
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+    La, Lb = _lib.lib(), _lib.lib(ab=True)
+    assert La.esdg_version() == b"esdg_hip 0.1 (gfx950)" and b"A/B build" in Lb.esdg_version()
+
+
 def test_error_codes_and_messages():
     from esdg_cns_amd import _lib
     L = _lib.lib()

@@ -31,7 +31,7 @@ def test_uses_tensor_kernels_and_generic_fallback_agree(E):
     assert fast.L.esdg_uses_tensor_kernels(fast.ctx) == 1
     os.environ["ESDG_FORCE_GENERIC"] = "1"
     try:
-        gen = E.RhsEngine(rd, md, ops, E.CNS_MODAL)
+        gen = E.RhsEngine(rd, md, ops, E.CNS_MODAL, ab_hooks=True)   # (the A/B build reads the environment switches)
     finally:
         del os.environ["ESDG_FORCE_GENERIC"]
     assert gen.L.esdg_uses_tensor_kernels(gen.ctx) == 0
@@ -478,7 +478,7 @@ def test_generic_fallback_refuses_wall_meshes_explicitly(E):
     os.environ["ESDG_FORCE_GENERIC"] = "1"
     try:
         with pytest.raises(EsdgError, match="wall boundary conditions need tensor-structured operators"):
-            E.RhsEngine(rd, md, ops, E.CNS_MODAL, BCTYPE=1)
+            E.RhsEngine(rd, md, ops, E.CNS_MODAL, BCTYPE=1, ab_hooks=True)
     finally:
         del os.environ["ESDG_FORCE_GENERIC"]
     eng = E.RhsEngine(rd, md, ops, E.CNS_MODAL, BCTYPE=1)        # the tensor kernels take the same mesh
@@ -501,7 +501,7 @@ def test_smooth_wave_short_cut_of_the_last_phase_is_bitwise_the_general_path(E, 
     lazy = E.RhsEngine(rd, md, ops, form_id)
     os.environ["ESDG_DBG"] = "32"
     try:
-        full = E.RhsEngine(rd, md, ops, form_id)
+        full = E.RhsEngine(rd, md, ops, form_id, ab_hooks=True)
     finally:
         del os.environ["ESDG_DBG"]
     for name, S in states.items():
@@ -521,7 +521,7 @@ def test_line_per_lane_and_node_per_lane_last_phase_kernels_agree(E, form, N):
     v3 = E.RhsEngine(rd, md, ops, form_id)
     os.environ["ESDG_V2"] = "rhs"
     try:
-        v2 = E.RhsEngine(rd, md, ops, form_id)
+        v2 = E.RhsEngine(rd, md, ops, form_id, ab_hooks=True)
     finally:
         del os.environ["ESDG_V2"]
     assert rel_l2(_rhs(v3, Qs), _rhs(v2, Qs)) <= 1e-12
@@ -554,6 +554,6 @@ def test_degree_limits_are_refused_with_a_reason(E):
     os.environ["ESDG_FORCE_GENERIC"] = "1"
     try:
         with pytest.raises(Exception, match="tensor kernels only"):
-            E.RhsEngine(rd, md, ops, E.CNS_MODAL)
+            E.RhsEngine(rd, md, ops, E.CNS_MODAL, ab_hooks=True)
     finally:
         del os.environ["ESDG_FORCE_GENERIC"]

@@ -303,12 +303,12 @@ def test_hex_per_node_geometry_of_affine_meshes_at_a_size_where_it_matters(eng_m
         e2, e_orc = truth_gate(f"hex N=3 {K}^3 smooth (per-node geometry, 10-bit differences)", _gpu_rhs(eng, Q), ref, tru)
         os.environ["ESDG_HEX_PER_NODE"] = "1"
         try:
-            e1, _ = truth_gate(f"hex N=3 {K}^3 smooth (per-node geometry, full arrays)", _gpu_rhs(eng_mod.RhsEngine(rd, md, ops, eng_mod.EULER_HEX_COLLOCATED, lf_scale=0.0), Q), ref, tru)
+            e1, _ = truth_gate(f"hex N=3 {K}^3 smooth (per-node geometry, full arrays)", _gpu_rhs(eng_mod.RhsEngine(rd, md, ops, eng_mod.EULER_HEX_COLLOCATED, lf_scale=0.0, ab_hooks=True), Q), ref, tru)
         finally:
             del os.environ["ESDG_HEX_PER_NODE"]
         os.environ["ESDG_HEX_GEOMETRY"] = "element"
         try:
-            e0 = rel_l2(_gpu_rhs(eng_mod.RhsEngine(rd, md, ops, eng_mod.EULER_HEX_COLLOCATED, lf_scale=0.0), Q), tru)
+            e0 = rel_l2(_gpu_rhs(eng_mod.RhsEngine(rd, md, ops, eng_mod.EULER_HEX_COLLOCATED, lf_scale=0.0, ab_hooks=True), Q), tru)
         finally:
             del os.environ["ESDG_HEX_GEOMETRY"]
         print(f"hex N=3 {K}^3: e_orc {e_orc:.2e}; e_gpu mode 2 {e2:.2e}, mode 1 {e1:.2e}, mode 0 (element record) {e0:.2e}")
@@ -321,8 +321,8 @@ def test_hex_per_node_geometry_of_affine_meshes_at_a_size_where_it_matters(eng_m
 @pytest.mark.parametrize("N", [1, 2, 3, 4])
 def test_hex_line_per_lane_and_node_per_lane_kernels_agree(eng_mod, N):
     """kh_rhs_l (production on affine meshes) against kh_rhs / the row-wise kh_rhs_g (ESDG_HEX_LINE=0), element record and per-node
-    geometry: two mappings of the same formulas, round-off apart.  (The switch is read once per process by the launcher, so the
-    second setting runs in a child process.)"""
+    geometry: two mappings of the same formulas, round-off apart.  (Both settings run in child processes on the A/B build of the
+    library, the one that reads the switch.)"""
     import os
     import subprocess
     import sys
@@ -341,7 +341,7 @@ for per_node in (False, True):
     ops = sd.hex_ops(rd)
     sd.hex_driver_geometry(md, rd, hybrid=per_node)
     Q = hex_random_state(md.xq.shape, seed=5, vel=(0.3, 1.0, -0.2))
-    eng = engine.RhsEngine(rd, md, ops, engine.EULER_HEX_COLLOCATED, lf_scale=0.25)
+    eng = engine.RhsEngine(rd, md, ops, engine.EULER_HEX_COLLOCATED, lf_scale=0.25, ab_hooks=True)
     out = eng.download(eng.rhs(eng.upload(Q)))
     np.save(sys.argv[1] + ("_pn" if per_node else "_el") + ".npy", np.stack(out))
 '''

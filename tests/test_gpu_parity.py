@@ -414,7 +414,7 @@ def test_cavity_64x64_rhsRK_and_rhs_viscous_alone_within_the_gate(eng_mod, oracl
         import os
         os.environ["ESDG_WALL_GEOMETRY"] = "element"
         try:
-            old = eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, **kw)
+            old = eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, ab_hooks=True, **kw)
         finally:
             del os.environ["ESDG_WALL_GEOMETRY"]
         old.set_parts(2)

@@ -2,6 +2,7 @@
 wall instantiation) and of the same with the v2 last phase (ESDG_V2=rhs: kt2_rhs), and the difference of the results.
 (The round-1 kernels this tool also timed until round 4 -- ESDG_V1=walls -- are gone.)   python tools/cavity_ab.py [N Kx]"""
 import os, subprocess, sys, time
+os.environ.setdefault("ESDG_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "esdg_cns_amd", "libesdg_hip_ab.so"))   # the A/B build reads the ESDG_* switches; the shipped library reads none
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":

@@ -4,6 +4,7 @@ touch a wall / the lid / a corner, and the worst elements.  Kernel sets: v2 (def
 per element everywhere (ESDG_WALL_GEOMETRY=element), round-1 (ESDG_V1=walls).
   python tools/cavity_visc_probe.py [N Kx Ky [BCTYPE [nopen] [vlid0]]]     nopen: viscous_dissp = false; vlid0: lid velocity 0"""
 import os
+os.environ.setdefault("ESDG_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "esdg_cns_amd", "libesdg_hip_ab.so"))   # the A/B build reads the ESDG_* switches; the shipped library reads none
 import sys
 
 import numpy as np

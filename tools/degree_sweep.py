@@ -1,6 +1,7 @@
 """Last-phase kernel by degree: kt3_rhs (default) against kt2_rhs (ESDG_V2=rhs), CNS and collocated Euler, same box, same inputs.
     python tools/degree_sweep.py [Kx]      (prints ms per launch of the last phase and the relative difference of the two results)"""
 import ctypes as C, os, sys
+os.environ.setdefault("ESDG_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "esdg_cns_amd", "libesdg_hip_ab.so"))   # the A/B build reads the ESDG_* switches; the shipped library reads none
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

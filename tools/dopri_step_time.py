@@ -2,6 +2,7 @@
 against six right-hand sides, i.e. what the stage combinations and the error norm cost on top of the hot path.
     python tools/dopri_step_time.py [N Kx reps]"""
 import os, sys, time
+os.environ.setdefault("ESDG_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "esdg_cns_amd", "libesdg_hip_ab.so"))   # the A/B build reads the ESDG_* switches; the shipped library reads none
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

@@ -26,14 +26,17 @@ run_step() {
     smoke)
       timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; local rc=$?
       tail -2 gpurun_out/smoke.log; return $rc ;;
-    abenv)
+    abenv)   # (both legs on the A/B build of the library -- the one that reads environment switches)
       local kv=$1; shift
+      export ESDG_HIP_LIB=$PWD/esdg_cns_amd/libesdg_hip_ab.so
+      [ -f "$ESDG_HIP_LIB" ] || { echo "missing $ESDG_HIP_LIB"; return 2; }
       for v in new base new base new base; do
         echo -n "$v: "
         if [ $v = base ]; then (export "$kv"; timeout -k 10 300 python bench.py --no-cpu-baseline "$@" 2>/dev/null | grepms)
         else timeout -k 10 300 python bench.py --no-cpu-baseline "$@" 2>/dev/null | grepms; fi
         echo
-      done ;;
+      done
+      unset ESDG_HIP_LIB ;;
     ablib)   # (the base build is selected through ESDG_HIP_LIB: the in-tree library is never overwritten)
       local alt=esdg_cns_amd/variants/$1; shift
       [ -f "$alt" ] || { echo "missing variant $alt"; return 2; }

@@ -2,6 +2,7 @@
 (ESDG_HEX_LINE=0), same box, same inputs.
     python tools/hex_degree_sweep.py [Kx Kz]   (ms per RHS, nodal DOF updates per second, relative difference of the two results)"""
 import os, sys, time
+os.environ.setdefault("ESDG_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "esdg_cns_amd", "libesdg_hip_ab.so"))   # the A/B build reads the ESDG_* switches; the shipped library reads none
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench

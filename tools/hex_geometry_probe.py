@@ -3,6 +3,7 @@ with the record plus 10-bit per-node differences (default on affine meshes whose
 node's own metric terms and normals in full (ESDG_HEX_PER_NODE=1, the kernels of curved meshes), for K^3 boxes.
     python tools/hex_geometry_probe.py [K ...]"""
 import os, subprocess, sys
+os.environ.setdefault("ESDG_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "esdg_cns_amd", "libesdg_hip_ab.so"))   # the A/B build reads the ESDG_* switches; the shipped library reads none
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 

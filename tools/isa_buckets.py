@@ -127,7 +127,7 @@ def main():
     stub = os.path.join(tmp, "stub.hip")
     with open(stub, "w") as f:
         f.write('#define ESDG_T3_NO_DISPATCH\n#include "esdg_kernels_tensor3.hip"\n'
-                "template __global__ void esdg::t3::kt3_rhs<%d, true, true, false, false, false>(esdg::TensorTables, esdg::MeshDev, esdg::Phys, "
+                "template __global__ void esdg::t3::kt3_rhs<%d, true, true, false, false>(esdg::TensorTables, esdg::MeshDev, esdg::Phys, "
                 "const double*, const double*, const double*, const double*, double*, esdg::LsrkFuse, esdg::StageFuse);\n" % n1)
     flags = {"smooth": ["-DESDG_T3_ATTR=1", "-DESDG_T2_FORCE_MODE=1"], "rough": ["-DESDG_T3_ATTR=2", "-DESDG_T2_FORCE_MODE=2"], "production": []}[mode]
     asm = os.path.join(tmp, "k.s")
@@ -147,7 +147,7 @@ def main():
 
     def bucket(fname, line):
         if fname == "merged":
-            return "inlined at line %d (merged line info: the flux core behind flux_dir's uniform branch)" % line if False else "fn ec_flux_core + series + rcp (merged line info)"
+            return "fn ec_flux_core + series + rcp (merged line info)"
         if fname == "esdg_kernels_tensor3.hip":
             name = "kernel body (before the first marker)"
             for l0, nm in kmarks:
@@ -188,7 +188,7 @@ def main():
     tot = collections.Counter()
     for b in tab:
         tot.update(tab[b])
-    print("kernel kt3_rhs<%d,1,1,0,0,0>, %s wave, flags %s" % (n1, mode, " ".join(flags + defs)))
+    print("kernel kt3_rhs<%d,1,1,0,0>, %s wave, flags %s" % (n1, mode, " ".join(flags + defs)))
     print("%-58s %6s %6s %6s %5s %5s %5s" % ("bucket", "VALU", "fp64", "other", "LDS", "VMEM", "SALU"))
     for b, c in sorted(tab.items(), key=lambda kv: -(kv[1]["fp64"] + kv[1]["valu_other"])):
         v = c["fp64"] + c["valu_other"]

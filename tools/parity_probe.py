@@ -1,6 +1,7 @@
 """Viscous part (rhs_viscous!) on the periodic vortex box: tensor kernels (neighbour entropy variables rebuilt from the
 trace state) vs generic kernels (interpolated entropy variables carried in A_v), each against the binary128 truth."""
 import os
+os.environ.setdefault("ESDG_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "esdg_cns_amd", "libesdg_hip_ab.so"))   # the A/B build reads the ESDG_* switches; the shipped library reads none
 import sys
 
 import numpy as np

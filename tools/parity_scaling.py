@@ -4,6 +4,7 @@ e_gpu / e_orc for the production kernels, the round-1 tensor kernels (ESDG_V1=1)
 (ESDG_FORCE_GENERIC=1); the split of both errors into the vortex core (r < 3) and the far field; the free-stream residual
 of GPU and oracle.    python tools/parity_scaling.py [cns] [Kmax]"""
 import os
+os.environ.setdefault("ESDG_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "esdg_cns_amd", "libesdg_hip_ab.so"))   # the A/B build reads the ESDG_* switches; the shipped library reads none
 import sys
 import subprocess
 

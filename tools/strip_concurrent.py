@@ -4,6 +4,7 @@ element rows; stream B does the last phase of strip k as soon as phase 1 of stri
 done.  Uses only esdg_rhs_phase_range; the result must equal the plain evaluation bit for bit.
     python tools/strip_concurrent.py [S ...]        (ESDG_T2_RESERVE=0; ESDG_T2_WG_PER_CU=n limits the persistent kt2_sigma grid)"""
 import ctypes as C, os, sys, time
+os.environ.setdefault("ESDG_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "esdg_cns_amd", "libesdg_hip_ab.so"))   # the A/B build reads the ESDG_* switches; the shipped library reads none
 os.environ.setdefault("ESDG_T2_RESERVE", "0")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -5,6 +5,7 @@ a stand-alone periodic strip in one launch per phase.  Prints ms per evaluation 
 weak-scaled run can reach relative to an unsharded one, network aside)."""
 import copy
 import os
+os.environ.setdefault("ESDG_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "esdg_cns_amd", "libesdg_hip_ab.so"))   # the A/B build reads the ESDG_* switches; the shipped library reads none
 import sys
 import time
 

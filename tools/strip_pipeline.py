@@ -3,6 +3,7 @@ the traces a strip's phase p writes are read by its phase p+1 while they are sti
 one launch per phase.  Uses only esdg_rhs_phase_range; the result must equal the plain evaluation bit for bit.
     python tools/strip_pipeline.py [S ...]          (ESDG_T2_RESERVE=0 is set: no slot reserve for ranged launches)"""
 import ctypes as C, os, sys, time
+os.environ.setdefault("ESDG_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "esdg_cns_amd", "libesdg_hip_ab.so"))   # the A/B build reads the ESDG_* switches; the shipped library reads none
 os.environ.setdefault("ESDG_T2_RESERVE", "0")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -2,6 +2,7 @@
 shock-tube closures (BCTYPE 4) where the test helpers provide them: relative difference of the two results (two mappings of the
 same formulas: round-off apart).   python tools/walls_sweep.py"""
 import os, sys
+os.environ.setdefault("ESDG_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "esdg_cns_amd", "libesdg_hip_ab.so"))   # the A/B build reads the ESDG_* switches; the shipped library reads none
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
