@@ -227,7 +227,7 @@ GATHER_OVERFETCH = 1.6   # neighbour-trace gathers: 160-byte runs inside 640-byt
 def design_bytes(formulation, Np, Nfq, hexw=False, hex_delta=False):
     """Design bytes per element and evaluation, by array family and phase: what every phase reads (r) and writes (w) once, no
     cache reuse assumed; `g` marks the reads that are neighbour gathers (counted x GATHER_OVERFETCH in `with_overfetch`).
-    DESIGN.md sections 3-4 (quads), 9 (hexahedra)."""
+    DESIGN.md sections 3-4 (quads), 6 (hexahedra)."""
     if hexw:
         ph = [{"Q": ("r", 40 * Np), "A_U": ("w", 40 * Nfq)},
               {"Q": ("r", 40 * Np), "A_U": ("r", 40 * Nfq), "A_U(nbr)": ("g", 40 * Nfq), "rhs": ("w", 40 * Np),
@@ -586,7 +586,7 @@ def run(args):
     # --- which roof binds: computed, per formulation, from the numbers of this line ------------------------------------
     # HBM floor = bytes moved / the pool's practical copy rate; fp64 floor = counted fp64 flops / the measured vector peak.
     # Bytes: the PMC traffic of this command where the committed profile is current, else the design bytes per element
-    # (DESIGN.md section 4 / 9: what each phase reads and writes once, no cache reuse assumed).
+    # (DESIGN.md section 4 / 6: what each phase reads and writes once, no cache reuse assumed).
     Nfq_ = eng.Nfq if hasattr(eng, "Nfq") else (6 * (N + 1) ** 2 if hexw else 4 * (N + 1))
     fam, per_phase = design_bytes(args.formulation, Np, Nfq_, hexw, hexw and args.hex_geometry == "per-node" and not args.hex_curve)
     design_k = per_phase[-1]["read"] + per_phase[-1]["write"]
