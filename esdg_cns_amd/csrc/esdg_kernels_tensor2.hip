@@ -856,9 +856,8 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_project(TensorTables TT, Mesh
 #pragma unroll
     for (int f = 0; f < 4; ++f) U[f] = x[f];
   }
-  double qh[6], V[4];
-  prim_logs<MODAL>(U, qh);
-  v_of_prim2<MODAL>(qh, V);
+  double V[4];
+  v_of_state_onelog<MODAL>(U, V);
   sA[tv] = make_double2(V[0], V[1]);
   sA[NV + tv] = make_double2(V[2], V[3]);
   __syncthreads();
@@ -873,7 +872,7 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_project(TensorTables TT, Mesh
     Vf[2] = __builtin_fma(ee[j], p1.x, Vf[2]); Vf[3] = __builtin_fma(ee[j], p1.y, Vf[3]);
   }
   double qf[4];
-  prim_of_v2<MODAL>(Vf, qf);
+  prim_of_v2_fast<MODAL>(Vf, qf);
   if (fact) {
     d2* rec = reinterpret_cast<d2*>(A_U + trace_slot<N1>(M, ESDG_EW(e0) + ef, fn) * FAU_NC);
     rec[0] = make_double2(qf[0], qf[1]);

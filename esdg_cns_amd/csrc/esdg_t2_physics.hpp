@@ -184,6 +184,52 @@ __device__ __forceinline__ void prim_of_v2(const double* V, double* q) {
   q[3] = (U[0] * U[0]) * (U[0] * R) * (1.0 / (2 * GM1));
 }
 
+// Phase 0 only (kt2_project), round 5: the same two maps with gamma = 1.4's exact exponents instead of three logarithms.
+//   s = log(p / rho^gamma) = -0.4 log rho - log beta - log 2 = -log(32 beta^5 rho^2) / 5       ONE logarithm per volume node
+//   rhoe(v) = ((gamma-1) / (-v4)^gamma)^(1/(gamma-1)) exp(-s/(gamma-1)) = 0.4^2.5 (-v4)^(-3.5) exp(-2.5 s)   (-v4)^(-3.5) = r^7, r = rsqrt(-v4)
+// -- the reference's own form, a power times an exponential (euler_variables.jl:107-120 / cavity :473-478), with the power taken
+// by a refined v_rsq_f64 and three multiplications instead of a logarithm inside the exponent; u = -v_i / v4 and beta = -v4 / (2 (gamma-1))
+// in closed form from r^2 = 1 / (-v4).  345 -> 292 VALU per wave of kt2_project; last bits of the trace records change (every factor is
+// accurate to an ulp or two, as before).
+__device__ __forceinline__ double rsqrt_refined(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  // two coupled Newton steps (as sqrt_fast): g -> sqrt(x), h -> 1 / (2 sqrt(x))
+  double g = x * y, h = .5 * y;
+  double r = __builtin_fma(-h, g, .5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  r = __builtin_fma(-h, g, .5);
+  h = __builtin_fma(h, r, h);
+  return h + h;
+}
+template <bool MODAL>
+__device__ __forceinline__ void v_of_state_onelog(const double* U, double* V) {
+  constexpr double GM1 = Gas2<MODAL>::GM1;
+  double q[4];
+  prims<MODAL>(U, q);
+  const double b2 = q[3] * q[3], r2 = q[0] * q[0];
+  const double s = -0.2 * log_pos(32.0 * (b2 * b2) * (q[3] * r2));
+  const double bb = 2 * GM1 * q[3];
+  V[0] = 1.4 - s - .5 * bb * (q[1] * q[1] + q[2] * q[2]);
+  V[1] = bb * q[1];
+  V[2] = bb * q[2];
+  V[3] = -bb;
+}
+template <bool MODAL>
+__device__ __forceinline__ void prim_of_v2_fast(const double* V, double* q) {
+  constexpr double GM1 = Gas2<MODAL>::GM1;
+  const double mv = -V[3];
+  const double r = rsqrt_refined(mv), r2 = r * r;          // r2 = 1 / (-v4)
+  const double h = -.5 * (V[1] * V[1] + V[2] * V[2]) * r2;  // |vU|^2 / (2 v4)
+  const double s = 1.4 - V[0] + h;
+  const double r4 = r2 * r2;
+  const double rhoeV = 0.10119288512538815 * ((r4 * r2) * r) * exp(-2.5 * s);   // 0.4^2.5 (-v4)^(-3.5) exp(-2.5 s)
+  q[0] = rhoeV * mv;
+  q[1] = V[1] * r2;
+  q[2] = V[2] * r2;
+  q[3] = mv * (1.0 / (2 * GM1));
+}
+
 // Wall closures (meshes with boundary nodes, M.bc != null; bc: 1 wall, 2 lid, 3 Dirichlet inflow, 4 copy).
 // wall_exterior_v: exterior projected entropy variables (v2,v3,v4) at a boundary face node from the own ones
 // (impose_BCs_entropyvars! cavity :178-216; dg2D_CNS_modalESDG.jl:187-203); gn = (nxJ, nyJ, sJ) of the face.
