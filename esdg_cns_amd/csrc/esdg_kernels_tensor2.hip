@@ -71,6 +71,13 @@ template <int N1, int GWv = Cfg<N1>::GW> struct Geo {
 };
 
 template <int N1> using GeoR = Geo<N1, CfgRhs<N1>::GW>;   // group geometry of kt2_rhs
+// ... and of kt2_sigma (A/B hook ESDG_T2_SIGMA_GW5: waves per group at N1 = 5)
+#ifndef ESDG_T2_SIGMA_GW5
+#define ESDG_T2_SIGMA_GW5 2
+#endif
+template <int N1> struct CfgSigmaG { static constexpr int GW = Cfg<N1>::GW; };
+template <> struct CfgSigmaG<5> { static constexpr int GW = ESDG_T2_SIGMA_GW5; };
+template <int N1> using GeoS = Geo<N1, CfgSigmaG<N1>::GW>;
 
 // LDS layout.  Measured on MI355X (tools/ubench/lds_read.hip, 2 waves per SIMD): a ds_read_b64 and a ds_read_b128
 // wave-instruction cost the same LDS time (~4.5 cycles; 119 vs 223 B/clk/CU), ds_read2_b64 costs two.  All arrays are
@@ -282,10 +289,10 @@ template <int N1, bool WALLS> struct SigmaCfg {
 // WALLS: boundary nodes (M.bc): exterior entropy variables by the wall closure; at a boundary node B holds MINUS the
 // prescribed stress jump, so that the last phase's .5*(-B[mapP] - B[own]) with mapP = own gives the jump unchanged.
 template <int N1, bool FULL, bool WALLS>
-__global__ __launch_bounds__(Geo<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_sigma(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
+__global__ __launch_bounds__(GeoS<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_sigma(TensorTables TT, MeshDev M, Phys ph, const double* __restrict__ Q,
                                                         const double* __restrict__ A_U, double* __restrict__ B,
                                                         double* __restrict__ SG, double* __restrict__ vt_partial) {
-  using G = Geo<N1>;
+  using G = GeoS<N1>;
   constexpr int Nq = G::Nq, Nfq = G::Nfq, E = G::E, NV = G::NV, NF = G::NF;
   constexpr NodeLayout NL(N1);
   constexpr FaceLayout FL(N1);
@@ -1425,7 +1432,7 @@ extern "C" int esdg_debug_stamps(unsigned long long* out16, int reset) {
 template <int N1, bool WALLS>
 static void launch_sigma2w(const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U, double* B,
                            double* SG, double* vt, hipStream_t s) {
-  using G = t2::Geo<N1>;
+  using G = t2::GeoS<N1>;
   const int64_t nfull = M.e_count >= G::E ? (M.e_count + G::E - 1) / G::E : 0;   // complete groups, the last one shifted back
   if (nfull > 0) {
     int nb = t2::persistent_grid<t2::kt2_sigma<N1, true, WALLS>>(G::GT, nfull);

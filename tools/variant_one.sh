@@ -8,9 +8,8 @@ name=$1; src=$2; shift 2
 mkdir -p build/$name variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c csrc/$src -o build/$name/$src.o
 objs=""
-for o in build/main/*.o; do
-  b=$(basename $o)
-  if [ "$b" = "$src.o" ]; then objs="$objs build/$name/$src.o"; else objs="$objs $o"; fi
+for b in $(python3 -c "import build; print(' '.join(__import__('os').path.basename(s) + '.o' for s in build.SOURCES))"); do   # (the objects build.py links)
+  if [ "$b" = "$src.o" ]; then objs="$objs build/$name/$src.o"; else objs="$objs build/main/$b"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o variants/$name.so $objs -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 echo "built esdg_cns_amd/variants/$name.so"
