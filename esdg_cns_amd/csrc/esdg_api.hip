@@ -2114,7 +2114,7 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
   // right-hand sides.
   const bool fuse = ctx->dopri_fusion && ctx->dim == 2 && ctx->use_fast && ctx->nphases == 3 && ctx->ph.formulation == 1 &&
                     !ctx->bf && !(ctx->ph.dbg & ~32) && !(ctx->v2 & 2) && ctx->T.N1 >= 2 && ctx->T.N1 <= ESDG_MAX_N1 &&
-                    (!ctx->M.bc || ctx->T.N1 < 8);
+                    (!ctx->M.bc || ctx->T.N1 < 6);   // (CNS wall meshes from N = 5 on run kt2_rhs: no fused attempt there)
   if (fuse) {
     if (!ctx->d_stage_partial.p) {   // (a sharded schedule launches the last phase in up to three pieces, each rounding up)
       int rc = ctx->d_stage_partial.alloc(sizeof(double) * (size_t)(rhs_tensor3_blocks(ctx->T.N1, ctx->K) + 9));

@@ -645,35 +645,49 @@ __global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_e
     default: return -1;                              \
   }
 
+// CNS on meshes with walls from N1 = 6 on: kt2_rhs (measured in round 5 on the lid-driven cavity, 128 x 128: N = 5 0.1021 vs 0.1047 ms,
+// N = 6 0.1652 vs 0.1910 ms -- the wall instantiation of kt3_rhs spills 54-64 registers there).  Not instantiated.
+template <int N1, bool MODAL, bool VISC> constexpr bool kt3_serves_walls() { return N1 < 8 && !(MODAL && VISC && N1 >= 6); }
+
 template <int N1, bool MODAL, bool VISC>
-static void launch_rhs3(const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U, const double* SG,
-                        const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s, const StageFuse* sf) {
+static int launch_rhs3(const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U, const double* SG,
+                       const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s, const StageFuse* sf) {
   using G = t3::G3<N1>;
   const int nb = (int)((M.e_count + G::E - 1) / G::E);
   const StageFuse sf0{};
-  if (sf) {   // DOPRI45 stage (esdg_dopri45_attempt): instantiated for the CNS formulation, which is what the reference integrates so
-    if constexpr (MODAL && VISC) {
-      if (M.bc) hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, true, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, *sf);
-      else hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, false, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, *sf);
+  if (M.bc) {
+    if constexpr (kt3_serves_walls<N1, MODAL, VISC>()) {
+      if (sf) {
+        if constexpr (MODAL && VISC) hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, true, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, *sf);
+      } else {
+        hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, sf0);
+      }
+      return 0;
+    } else {
+      return -1;
     }
-    return;
   }
-  if (M.bc) hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, sf0);
-  else hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, false>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, sf0);
+  if (sf) {   // DOPRI45 stage (esdg_dopri45_attempt): instantiated for the CNS formulation, which is what the reference integrates so
+    if constexpr (MODAL && VISC) hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, false, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, *sf);
+    return 0;
+  }
+  hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, false>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, sf0);
+  return 0;
 }
 
 // last phase on meshes without walls; returns -1 where the v3 kernel does not apply (caller falls back to kt2_rhs)
 int launch_rhs_tensor3(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
                        const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s, const StageFuse* sf) {
   if (M.e_count <= 0) return 0;
-  if (M.bc && N1v >= 8) return -1;   // (the wall instantiation from N1 = 8 on would not fit the register file)
   const bool modal = ph.formulation != 0, visc = ph.formulation == 1;
   if (sf && !(modal && visc)) return -1;
+  int rc = 0;
   ESDG_T3_DISPATCH(N1v, {
-    if (!modal) (launch_rhs3<N1, false, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s, sf);
-    else if (visc) (launch_rhs3<N1, true, true>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s, sf);
-    else (launch_rhs3<N1, true, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s, sf);
+    if (!modal) rc = (launch_rhs3<N1, false, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s, sf);
+    else if (visc) rc = (launch_rhs3<N1, true, true>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s, sf);
+    else rc = (launch_rhs3<N1, true, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s, sf);
   });
+  if (rc) return rc;   // (-1: a wall mesh this kernel does not serve -- the caller takes kt2_rhs)
   return (int)hipGetLastError();
 }
 
