@@ -476,7 +476,11 @@ __global__ __launch_bounds__(GeoS<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_
     sA[NV + tv] = make_double2(x[2], x[3]);
     __builtin_amdgcn_sched_barrier(0);
     if (ESDG_T2_SIGMA_DEFER_STORES) {   // the previous group's results (none in the first iteration: cva = cfa = false)
+#ifdef ESDG_EXP_NOSG   // (bound experiment, wrong results: the divergence stored into an L2-resident window)
+      if (cva) { double* o = SG + (ce0 & 1023) * Nq + tv; o[0] = cdv[0]; o[KN] = cdv[1]; o[2 * KN] = cdv[2]; }
+#else
       if (cva) { double* o = SG + ESDG_EW(ce0) * Nq + tv; o[0] = cdv[0]; o[KN] = cdv[1]; o[2 * KN] = cdv[2]; }
+#endif
       if (COAL) {
         double* bb = B + ESDG_EW(ce0) * Nfq * B_NC;
 #pragma unroll

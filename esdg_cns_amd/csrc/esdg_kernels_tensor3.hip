@@ -431,7 +431,11 @@ __global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_e
     for (int r = 0; r < NR; ++r) {
       const unsigned sl = slot[r] < (unsigned)(nE * Nq) ? slot[r] : 0u;
 #pragma unroll
+#ifdef ESDG_EXP_NOSG   // bound experiment (wrong results): the stored divergence read from an L2-resident window = what removing its 600 B / element buys at most
+      for (int c = 0; c < 3; ++c) dvs[r][c] = SG[c * KN + (e0 & 1023) * Nq + sl];
+#else
       for (int c = 0; c < 3; ++c) dvs[r][c] = SG[c * KN + e0 * Nq + sl];
+#endif
     }
   }
   __syncthreads();   // every lane is past its reads of the records, whose space takes the lines' results
