@@ -107,22 +107,30 @@ __global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_e
   using G = G3<N1>;
   constexpr int TW = G::TW, Nq = G::Nq, Nfq = G::Nfq, NLN = G::NLN, E = G::E, NV = G::NV, LL = G::LL, NR = G::NR;
   constexpr TensorLayout TL(N1);
-  constexpr int NGEO = E * GEO_STRIDE, GPT = (NGEO + TW - 1) / TW, TPT = (TL.NDBL + TW - 1) / TW;
+  constexpr int NGEO = E * GEO_STRIDE, GPT = (NGEO + TW - 1) / TW;
   constexpr double GM1 = Gas2<MODAL>::GM1;
-  // LDS: one arena of 8 NV doubles that is, in turn, Vq's two buffers ([2][NV] pair planes each), the node records
-  // ([3][NV] pair planes: (rho,u) (v,beta) (log rho, log beta)), the two lines' results per node ([2 directions][2][NV]) and
-  // Pq's two buffers; the geometry records of the wave's elements; the 1D operator tables (TensorLayout, esdg_tensor_tables.hpp).
-  __shared__ __align__(16) double arena[8 * NV];
-  __shared__ __align__(16) double sGeo[GPT * TW];
-  __shared__ __align__(16) double sTab[TPT * TW];
+  // LDS (round 5: 10.1 instead of 13.2 KB at N1 = 5 -- sixteen workgroups per CU fit): ONE block of
+  //   arena  6 NV doubles: in turn Vq's buffer ([2][NV] pair planes, both stages in place: a wave reads everything a stage needs
+  //          into registers before it writes), the node records ([3][NV] pair planes: (rho,u) (v,beta) (log rho, log beta)), the
+  //          lines' results per node ([2][NV]: direction 0 writes, direction 1 adds) and Pq's buffer (in place as well);
+  //   sTab   the 1D operator tables this kernel reads (TensorLayout without its EE and DG blocks: NTAB doubles);
+  //   sGeo   the geometry records of the wave's elements, laid over the padding of sTab's last staging round (staged after it).
+  constexpr int cIQ = TL.EE, cIP = TL.EE + N1 * N1, NTAB = TL.EE + 2 * N1 * N1;   // compact offsets of IQ, IP; table doubles staged
+  static_assert(TL.DG == TL.EE + 4 * N1 && TL.IQ == TL.DG + 2 * N1 * N1 && TL.IP == TL.IQ + N1 * N1, "TensorLayout order: ..., EE, DG, IQ, IP");
+  constexpr int TPTc = (NTAB + TW - 1) / TW;
+  constexpr int OFF_TAB = 6 * NV, OFF_GEO = OFF_TAB + NTAB, NLDS = OFF_GEO + GPT * TW;
+  static_assert(OFF_TAB + TPTc * TW <= NLDS, "the table staging stays inside the block");
+  __shared__ __align__(16) double lds[NLDS];
+  double* arena = lds;
+  double* sTab = lds + OFF_TAB;
+  double* sGeo = lds + OFF_GEO;
   // WALLS (CNS): the lines' shares of the lifted penalty per node, [2 directions][3][NV], and the elements that have a boundary node
   constexpr bool WCORR = WALLS && VISC && MODAL;
   __shared__ double sX[WCORR ? 6 * NV : 1];
   __shared__ int sEb[WALLS ? E : 1];
   d2* sA = reinterpret_cast<d2*>(arena);                // [2][NV]
-  d2* sB = reinterpret_cast<d2*>(arena + 4 * NV);       // [2][NV]
   d2* sRec = reinterpret_cast<d2*>(arena);              // [3][NV]
-  d2* sS = reinterpret_cast<d2*>(arena);                // [2][2][NV]
+  d2* sS = reinterpret_cast<d2*>(arena);                // [2][NV]
 
   const unsigned tid = threadIdx.x;
   const int64_t e0r = M.e_begin + xcd_group3(blockIdx.x, gridDim.x) * E;
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_e
   const int64_t nsA = trace_slot<N1>(M, e0 + elc, (unsigned)fA), nsB = trace_slot<N1>(M, e0 + elc, (unsigned)fB);   // own records (MeshDev::bf)
 
   // ---- every global load of the inputs, unconditionally ------------------------------------------------------------------
-  double x[NR][4], geo[GPT], tab[TPT];
+  double x[NR][4], geo[GPT], tab[TPTc];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const unsigned n = tid + r * TW, s = n < (unsigned)NV ? n : n - NV, sl = s < (unsigned)(nE * Nq) ? s : 0u;
@@ -157,7 +165,10 @@ __global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_e
 #pragma unroll
   for (int i = 0; i < GPT; ++i) { const unsigned n = tid + i * TW; geo[i] = M.geo[e0 * GEO_STRIDE + (n < (unsigned)(nE * GEO_STRIDE) ? n : 0u)]; }
 #pragma unroll
-  for (int i = 0; i < TPT; ++i) { const unsigned n = tid + i * TW; tab[i] = TT.dbl[n < (unsigned)TL.NDBL ? n : 0u]; }
+  for (int i = 0; i < TPTc; ++i) {   // (entries [0, EE) and [IQ, NDBL) of the tables: EE and DG are not read here)
+    const unsigned n = tid + i * TW;
+    tab[i] = TT.dbl[n < (unsigned)TL.EE ? n : (n < (unsigned)NTAB ? n + (unsigned)(TL.IQ - TL.EE) : 0u)];
+  }
   // traces of the line's two face nodes, both sides: (rho, u, v, beta); their logs, energy and wavespeed are rebuilt below
   double qMA[8], qPA[8], qMB[8], qPB[8];
   {
@@ -193,9 +204,9 @@ __global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_e
 
   // ---- staging: geometry, tables, nodal values ------------------------------------------------------------------------------
 #pragma unroll
-  for (int i = 0; i < GPT; ++i) sGeo[tid + i * TW] = geo[i];
+  for (int i = 0; i < TPTc; ++i) sTab[tid + i * TW] = tab[i];
 #pragma unroll
-  for (int i = 0; i < TPT; ++i) sTab[tid + i * TW] = tab[i];
+  for (int i = 0; i < GPT; ++i) sGeo[tid + i * TW] = geo[i];   // (after the tables: it lies over their padding)
   unsigned slot[NR], nq[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
@@ -212,11 +223,12 @@ __global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_e
     }
     __syncthreads();
     // Uq = Vq Qn by sum factorisation, exactly as t2::vq_apply: W[a + N1 b] = sum_i IQ[a,i] Qn[i + N1 b], then
-    // Uq[a + N1 b] = sum_j IQ[a,j] W[b + N1 j]
+    // Uq[a + N1 b] = sum_j IQ[a,j] W[b + N1 j]; W goes back into the buffer it was read from, once every round has read
+    double W[NR][4];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const unsigned ev = slot[r] / Nq, a = nq[r] % N1, b = nq[r] / N1;
-      const double* c = sTab + TL.IQ + a * N1;
+      const double* c = sTab + cIQ + a * N1;
       const d2* rw = sA + ev * Nq + N1 * b;
       d2 p = rw[0], t = rw[NV];
       const double c0 = c[0];
@@ -228,15 +240,20 @@ __global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_e
         w0 = __builtin_fma(ci, p.x, w0); w1 = __builtin_fma(ci, p.y, w1);
         w2 = __builtin_fma(ci, t.x, w2); w3 = __builtin_fma(ci, t.y, w3);
       }
-      sB[slot[r]] = make_double2(w0, w1);
-      sB[NV + slot[r]] = make_double2(w2, w3);
+      W[r][0] = w0; W[r][1] = w1; W[r][2] = w2; W[r][3] = w3;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      sA[slot[r]] = make_double2(W[r][0], W[r][1]);
+      sA[NV + slot[r]] = make_double2(W[r][2], W[r][3]);
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const unsigned ev = slot[r] / Nq, a = nq[r] % N1, b = nq[r] / N1;
-      const double* c = sTab + TL.IQ + a * N1;
-      const d2* rw = sB + ev * Nq + b;
+      const double* c = sTab + cIQ + a * N1;
+      const d2* rw = sA + ev * Nq + b;
       d2 p = rw[0], t = rw[NV];
       const double c0 = c[0];
       U[r][0] = c0 * p.x; U[r][1] = c0 * p.y; U[r][2] = c0 * t.x; U[r][3] = c0 * t.y;
@@ -451,11 +468,31 @@ __global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_e
 #pragma unroll
       for (int c = 0; c < 4; ++c) rr[c] = __builtin_fma(pb, GfB[c], __builtin_fma(pa, GfA[c], pd * acc[i][c]));
       const unsigned n = n0 + i * st;
-      sS[(2 * d) * NV + n] = make_double2(rr[0], rr[1]);
-      sS[(2 * d + 1) * NV + n] = make_double2(rr[2], rr[3]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[i][c] = rr[c];   // (the line's share of node i, kept for the two passes below)
       if (WCORR) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) sX[(3 * d + c) * NV + n] = __builtin_fma(pb, gpB[c], pa * gpA[c]);
+      }
+    }
+    // a node's result = the shares of its two lines: the direction-0 lines write, then the direction-1 lines add (one pair of planes
+    // instead of two; lanes that duplicate a line -- tid >= LL -- write duplicates but never add)
+    if (d == 0) {
+#pragma unroll
+      for (int i = 0; i < N1; ++i) {
+        const unsigned n = n0 + i * st;
+        sS[n] = make_double2(acc[i][0], acc[i][1]);
+        sS[NV + n] = make_double2(acc[i][2], acc[i][3]);
+      }
+    }
+    __syncthreads();
+    if (d == 1 && tid < (unsigned)LL) {
+#pragma unroll
+      for (int i = 0; i < N1; ++i) {
+        const unsigned n = n0 + i * st;
+        const d2 a0 = sS[n], a1 = sS[NV + n];
+        sS[n] = make_double2(a0.x + acc[i][0], a0.y + acc[i][1]);
+        sS[NV + n] = make_double2(a1.x + acc[i][2], a1.y + acc[i][3]);
       }
     }
   }
@@ -471,8 +508,8 @@ __global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_e
   for (int r = 0; r < NR; ++r) {
     const unsigned s = slot[r], ev = s / Nq;
     const double iJ = rcp_refined(sGeo[ev * GEO_STRIDE + 4]);
-    const d2 a0 = sS[s], a1 = sS[NV + s], b0 = sS[2 * NV + s], b1 = sS[3 * NV + s];
-    R[r][0] = -(a0.x + b0.x) * iJ; R[r][1] = -(a0.y + b0.y) * iJ; R[r][2] = -(a1.x + b1.x) * iJ; R[r][3] = -(a1.y + b1.y) * iJ;
+    const d2 a0 = sS[s], a1 = sS[NV + s];
+    R[r][0] = -a0.x * iJ; R[r][1] = -a0.y * iJ; R[r][2] = -a1.x * iJ; R[r][3] = -a1.y * iJ;
     if (VISC) {
       const double vs = viscous ? iJ : 0.0;
 #pragma unroll
@@ -488,17 +525,18 @@ __global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_e
   if (MODAL) {
     // o = Pq X as in kt2_rhs: W[a + N1 b] = sum_j IP[a,j] X[b + N1 j], o[a + N1 b] = sum_i IP[b,i] W[a + N1 i]
     auto pq_apply = [&](const double (*X)[4], double (*o)[4]) {
-      __syncthreads();   // every lane is past its reads of what the two buffers held before
+      __syncthreads();   // every lane is past its reads of what the buffer held before
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         sA[slot[r]] = make_double2(X[r][0], X[r][1]);
         sA[NV + slot[r]] = make_double2(X[r][2], X[r][3]);
       }
       __syncthreads();
+      double W[NR][4];   // (first stage into registers, then back into the same buffer: in place, as Vq above)
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const unsigned ev = slot[r] / Nq, a = nq[r] % N1, b = nq[r] / N1;
-        const double* c = sTab + TL.IP + a * N1;
+        const double* c = sTab + cIP + a * N1;
         const d2* rw = sA + ev * Nq + b;
         d2 p = rw[0], t = rw[NV];
         const double c0 = c[0];
@@ -510,15 +548,20 @@ __global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_e
           w0 = __builtin_fma(cj, p.x, w0); w1 = __builtin_fma(cj, p.y, w1);
           w2 = __builtin_fma(cj, t.x, w2); w3 = __builtin_fma(cj, t.y, w3);
         }
-        sB[slot[r]] = make_double2(w0, w1);
-        sB[NV + slot[r]] = make_double2(w2, w3);
+        W[r][0] = w0; W[r][1] = w1; W[r][2] = w2; W[r][3] = w3;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        sA[slot[r]] = make_double2(W[r][0], W[r][1]);
+        sA[NV + slot[r]] = make_double2(W[r][2], W[r][3]);
       }
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const unsigned ev = slot[r] / Nq, a = nq[r] % N1, b = nq[r] / N1;
-        const double* c = sTab + TL.IP + b * N1;
-        const d2* rw = sB + ev * Nq + a;
+        const double* c = sTab + cIP + b * N1;
+        const d2* rw = sA + ev * Nq + a;
         d2 p = rw[0], t = rw[NV];
         const double c0 = c[0];
         o[r][0] = c0 * p.x; o[r][1] = c0 * p.y; o[r][2] = c0 * t.x; o[r][3] = c0 * t.y;
