@@ -72,6 +72,15 @@ template <int N1, int GWv = Cfg<N1>::GW> struct Geo {
 
 template <int N1> using GeoR = Geo<N1, CfgRhs<N1>::GW>;   // group geometry of kt2_rhs
 // ... and of kt2_sigma (A/B hook ESDG_T2_SIGMA_GW5: waves per group at N1 = 5)
+#ifndef ESDG_T2_PROJECT_GRID_NUM
+#define ESDG_T2_PROJECT_GRID_NUM 1   // persistent grid of kt2_project = resident workgroups x NUM / DEN (A/B hooks)
+#endif
+#ifndef ESDG_T2_PROJECT_GRID_DEN
+#define ESDG_T2_PROJECT_GRID_DEN 1
+#endif
+#ifndef ESDG_T2_PROJECT_PERSIST
+#define ESDG_T2_PROJECT_PERSIST 4   // (measured: 12.8 groups per resident workgroup at cfg3 -15 %, 3.2 at cfg2 +5 %) persistent kt2_project when the launch has more than that many groups per resident workgroup (0 = always one-shot)
+#endif
 #ifndef ESDG_T2_SIGMA_GW5
 #define ESDG_T2_SIGMA_GW5 2
 #endif
@@ -843,14 +852,20 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_project(TensorTables TT, Mesh
   const unsigned ef = tf / Nfq, fn = tf - ef * Nfq;
   const unsigned rowb = ev * Nq + N1 * b, colq = ev * Nq + b;
   const int64_t KN = M.K * Nq;
-  const int64_t e0 = M.e_begin + xcd_group(blockIdx.x, gridDim.x) * E;
-  const int nE = (int)min((int64_t)E, M.e_begin + M.e_count - e0);
-  const unsigned tvl = tv < (unsigned)(nE * Nq) ? tv : 0u;
-  const bool fact = tid < (unsigned)(nE * Nfq);
+  // Element groups blockIdx.x, blockIdx.x + gridDim.x, ...: one group per workgroup when the launch brings a workgroup per group
+  // (the one-shot form), several with the persistent grid of ESDG_T2_PROJECT_PERSIST (A/B hook): the per-node table rows are then
+  // fetched once per workgroup and the next group's state is requested into the registers of the current one after their last use.
+  const int64_t ngroups = (M.e_count + E - 1) / E;
+  int64_t grp = gridDim.x == (unsigned)ngroups ? xcd_group(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
   // every global load at entry, unconditionally (state; per-node / per-face-node table rows)
   double x[4], cq[N1], ee[N1];
+  {
+    const int64_t e0 = M.e_begin + grp * E;
+    const int nE = (int)min((int64_t)E, M.e_begin + M.e_count - e0);
+    const unsigned tvl = tv < (unsigned)(nE * Nq) ? tv : 0u;
 #pragma unroll
-  for (int f = 0; f < 4; ++f) x[f] = Q[f * KN + ESDG_EW(e0) * Nq + tvl];
+    for (int f = 0; f < 4; ++f) x[f] = Q[f * KN + ESDG_EW(e0) * Nq + tvl];
+  }
   const double* nd_ = TT.node_d + q;
   const double* fd_ = TT.face_d + fn;
   const int* fi_ = TT.face_i + fn;
@@ -859,35 +874,49 @@ __global__ __launch_bounds__(Geo<N1>::GT) void kt2_project(TensorTables TT, Mesh
   const unsigned fnode0 = ef * Nq + fi_[(FL.NODE0) * Nfq], fstride = fi_[(FL.STRIDE) * Nfq];
   prio_entry_end();
 
-  double U[4];
-  if (MODAL) {
-    vq_apply<N1, NV>(cq, sA, sB0, sB1, tv, rowb, colq, x, U);
-    __syncthreads();   // every lane is past its reads of the scratch planes, which take the entropy variables below
-  } else {
+#pragma unroll 1
+  for (; grp < ngroups; grp += gridDim.x) {
+    const int64_t e0 = M.e_begin + grp * E;
+    const int nE = (int)min((int64_t)E, M.e_begin + M.e_count - e0);
+    const bool fact = tid < (unsigned)(nE * Nfq);
+    double U[4];
+    if (MODAL) {
+      vq_apply<N1, NV>(cq, sA, sB0, sB1, tv, rowb, colq, x, U);
+    } else {
 #pragma unroll
-    for (int f = 0; f < 4; ++f) U[f] = x[f];
-  }
-  double V[4];
-  v_of_state_onelog<MODAL>(U, V);
-  sA[tv] = make_double2(V[0], V[1]);
-  sA[NV + tv] = make_double2(V[2], V[3]);
-  __syncthreads();
-  prio_exit();
-  // face lanes: Vf = Ef * V along the node's line, then the primitive state of u(Vf)
-  d2 p0 = sA[fnode0], p1 = sA[NV + fnode0];
-  double Vf[4] = {ee[0] * p0.x, ee[0] * p0.y, ee[0] * p1.x, ee[0] * p1.y};
+      for (int f = 0; f < 4; ++f) U[f] = x[f];
+    }
+    if (grp + gridDim.x < ngroups) {   // (uniform) the next group's state into the registers just consumed
+      const int64_t e1 = M.e_begin + (grp + gridDim.x) * E;
+      const int nE1 = (int)min((int64_t)E, M.e_begin + M.e_count - e1);
+      const unsigned tv1 = tv < (unsigned)(nE1 * Nq) ? tv : 0u;
 #pragma unroll
-  for (int j = 1; j < N1; ++j) {
-    p0 = sA[fnode0 + j * fstride]; p1 = sA[NV + fnode0 + j * fstride];
-    Vf[0] = __builtin_fma(ee[j], p0.x, Vf[0]); Vf[1] = __builtin_fma(ee[j], p0.y, Vf[1]);
-    Vf[2] = __builtin_fma(ee[j], p1.x, Vf[2]); Vf[3] = __builtin_fma(ee[j], p1.y, Vf[3]);
-  }
-  double qf[4];
-  prim_of_v2_fast<MODAL>(Vf, qf);
-  if (fact) {
-    d2* rec = reinterpret_cast<d2*>(A_U + trace_slot<N1>(M, ESDG_EW(e0) + ef, fn) * FAU_NC);
-    rec[0] = make_double2(qf[0], qf[1]);
-    rec[1] = make_double2(qf[2], qf[3]);
+      for (int f = 0; f < 4; ++f) x[f] = Q[f * KN + ESDG_EW(e1) * Nq + tv1];
+    }
+    if (MODAL) __syncthreads();   // every lane is past its reads of the scratch planes, which take the entropy variables below
+    double V[4];
+    v_of_state_onelog<MODAL>(U, V);
+    sA[tv] = make_double2(V[0], V[1]);
+    sA[NV + tv] = make_double2(V[2], V[3]);
+    __syncthreads();
+    prio_exit();
+    // face lanes: Vf = Ef * V along the node's line, then the primitive state of u(Vf)
+    d2 p0 = sA[fnode0], p1 = sA[NV + fnode0];
+    double Vf[4] = {ee[0] * p0.x, ee[0] * p0.y, ee[0] * p1.x, ee[0] * p1.y};
+#pragma unroll
+    for (int j = 1; j < N1; ++j) {
+      p0 = sA[fnode0 + j * fstride]; p1 = sA[NV + fnode0 + j * fstride];
+      Vf[0] = __builtin_fma(ee[j], p0.x, Vf[0]); Vf[1] = __builtin_fma(ee[j], p0.y, Vf[1]);
+      Vf[2] = __builtin_fma(ee[j], p1.x, Vf[2]); Vf[3] = __builtin_fma(ee[j], p1.y, Vf[3]);
+    }
+    double qf[4];
+    prim_of_v2_fast<MODAL>(Vf, qf);
+    if (fact) {
+      d2* rec = reinterpret_cast<d2*>(A_U + trace_slot<N1>(M, ESDG_EW(e0) + ef, fn) * FAU_NC);
+      rec[0] = make_double2(qf[0], qf[1]);
+      rec[1] = make_double2(qf[2], qf[3]);
+    }
+    __syncthreads();   // (the planes are rewritten by the next group)
   }
 }
 
@@ -1505,6 +1534,21 @@ void ab_tuning_t2(int wg_per_cu, int reserve) {
   if (reserve >= 0) t2::g_reserve = reserve;
 }
 
+// (A/B hook ESDG_T2_PROJECT_PERSIST = P > 0: the persistent grid when the launch has more than P groups per resident workgroup)
+template <int N1>
+static int project_grid(bool modal, int nb) {
+#if ESDG_T2_PROJECT_PERSIST
+  using G = t2::Geo<N1>;
+  constexpr auto km = t2::kt2_project<N1, true>;
+  constexpr auto kc = t2::kt2_project<N1, false>;
+  const int cap = modal ? t2::persistent_grid<km>(G::GT, (int64_t)1 << 40) : t2::persistent_grid<kc>(G::GT, (int64_t)1 << 40);
+  if (nb > cap * ESDG_T2_PROJECT_PERSIST) nb = (int)((int64_t)cap * ESDG_T2_PROJECT_GRID_NUM / ESDG_T2_PROJECT_GRID_DEN);
+#else
+  (void)modal;
+#endif
+  return nb;
+}
+
 // phase 0 with the v2 kernel; returns -1 where it does not cover the degree (the caller refuses the degree)
 int launch_project_tensor2(int N1v, const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, double* A_U, hipStream_t s) {
   if (M.e_count <= 0) return 0;
@@ -1512,7 +1556,8 @@ int launch_project_tensor2(int N1v, const TensorTables& TT, const MeshDev& M, co
   const bool modal = ph.formulation != 0;
   ESDG_T2_DISPATCH(N1v, {
     using G = t2::Geo<N1>;
-    const int nb = (int)((M.e_count + G::E - 1) / G::E);
+    int nb = (int)((M.e_count + G::E - 1) / G::E);
+    nb = project_grid<N1>(modal, nb);
     if (modal) hipLaunchKernelGGL((t2::kt2_project<N1, true>), dim3(nb), dim3(G::GT), 0, s, TT, M, Q, A_U);
     else hipLaunchKernelGGL((t2::kt2_project<N1, false>), dim3(nb), dim3(G::GT), 0, s, TT, M, Q, A_U);
   });

@@ -338,6 +338,21 @@ def test_cfg2_euler_256_exact_size_values_against_oracle_and_truth(eng_mod, orac
         _one_core()
 
 
+def test_cfg2_euler_256_exact_size_with_oracle_built_inputs(eng_mod, oracle_lib):
+    """The same configuration at its exact size with the ORACLE's set-up objects (oracle/ref_setup.py: the reference set-up restated
+    statement by statement -- Vandermonde inversions, distance-matrix connectivity) fed to engine, oracle and truth alike: the gate
+    does not depend on whose set-up built the arrays (round 5; the small cases: test_oracle_built_inputs_give_the_same_verdict)."""
+    from oracle import oracle as orc
+    pe = orc.build_euler_problem(4, 256, 256)
+    f64, truth = _euler(pe)
+    eng = eng_mod.RhsEngine(pe.rd, pe.md, pe.ops, eng_mod.EULER_COLLOCATED)
+    _all_cores()
+    try:
+        truth_gate("cfg2 euler N=4 256x256 vortex (oracle-built inputs)", _gpu_rhs(eng, pe.Q), f64(pe.Q), truth(pe.Q))
+    finally:
+        _one_core()
+
+
 def test_cfg3_cns_512_exact_size_values_against_oracle(eng_mod, oracle_lib):
     """BASELINE config 3 (2D CNS, N=4, 512x512, the headline workload) at its exact size: `rhsRK!` of
     dg2D_CNS_cavity_optimized.jl:955-972, GPU vs the Float64 oracle vs the binary128 truth on identical inputs, all host
