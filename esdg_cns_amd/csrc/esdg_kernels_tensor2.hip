@@ -830,7 +830,9 @@ __global__ __launch_bounds__(GeoS<N1>::GT, (SigmaCfg<N1, WALLS>::WPE)) void kt2_
 // ---------------------------------------------------------------------------------------------------------------------
 // phase 0: entropy projection to the faces -> the (rho, u, v, beta) trace records A_U
 // (euler_quad.jl:141-157 / rhs_inviscid! :447-495: VU = v(Vq u), Uf = u(Vf Pq VU))
-// One workgroup per group of E elements (one-shot), pair planes, per-node table rows.  The round-1 kernel kept its LDS
+// A workgroup per group of E elements -- one-shot on small launches, persistent from ESDG_T2_PROJECT_PERSIST groups per resident
+// workgroup on (round 5) --, pair planes, per-node table rows; one logarithm per node and a refined rsqrt instead of a logarithm in
+// the inverse map (v_of_state_onelog / prim_of_v2_fast, esdg_t2_physics.hpp).  The round-1 kernel kept its LDS
 // arrays as [element][component][node] planes of doubles: a wave waited 38 % of its life on LDS instructions, a third of its
 // LDS cycles were bank conflicts (profiles/r03u_sq_counters.txt).
 // ---------------------------------------------------------------------------------------------------------------------

@@ -15,13 +15,18 @@
 //     streamed from LDS (3 ds_read_b128 per flux, the only LDS traffic of the stage);
 //   * the SBP weight of a pair is folded into the accumulation (acc_i += S_ij F, acc_j -= S_ij F: the flux is linear in the metric
 //     vector, which carries the line's transverse weight), and the lift of the two face totals is applied by the line lane, so a
-//     node's result is the sum of what its two lines hold for it: r = r_0 + r_1, one LDS exchange;
+//     node's result is the sum of what its two lines hold for it: r = r_0 + r_1, one LDS exchange (direction 0 writes, direction 1 adds);
 //   * node-wise work (Vq, primitives + logs, gather, viscous divergence, Pq, store) runs in ceil(E N1^2 / 64) rounds of the same
 //     wave with the node-per-lane layout of kt2_rhs.
 // An element's result depends on nothing but its own data and its neighbours' traces (no cross-lane reduction whose order
 // depends on the slot), so ranged, sharded and full launches agree bit for bit as before.
 // Meshes with walls: the WALLS instantiation applies the closures of init_BC_funs / the shock-tube driver in the face turns and
-// the nodal-basis correction of the wall elements after Pq, both as kt2_rhs does (formulas and citations there).
+// the nodal-basis correction of the wall elements after Pq, both as kt2_rhs does (formulas and citations there); CNS wall meshes
+// from N1 = 6 on run kt2_rhs (launch_rhs3 below).
+// Round 5: the instruction stream was attributed at ISA level (tools/isa_buckets.py) and dieted -- a smooth
+// wave calls the series flux directly, the flux works on sums with exact power-of-two folds, its series constants are pinned in
+// VGPRs (flux_dir / ec_flux_core) --, and the LDS block shrank from 13.2 to 10.1 KB at N1 = 5 (Vq / Pq in place, one pair of exchange
+// planes, compact tables).
 #include "esdg_dev.hpp"
 #include "esdg_tensor_tables.hpp"
 #include "esdg_devmath.hpp"
@@ -92,13 +97,8 @@ constexpr int wpe3(int, bool) { return ESDG_T3_WPE; }
 #else
 constexpr int wpe3(int N1, bool walls_cns) { return N1 <= 4 ? 3 : (N1 <= 6 ? (walls_cns ? 2 : 3) : (N1 == 7 || !walls_cns ? 2 : 1)); }
 #endif
-#ifdef ESDG_T3_NVGPR   // (experiment hook: a hard register cap, e.g. 128 for four waves per SIMD)
-#define T3_NVGPR_ATTR __attribute__((amdgpu_num_vgpr(ESDG_T3_NVGPR)))
-#else
-#define T3_NVGPR_ATTR
-#endif
 template <int N1, bool MODAL, bool VISC, bool WALLS, bool STG = false>
-__global__ __launch_bounds__(64) T3_NVGPR_ATTR __attribute__((amdgpu_waves_per_eu(wpe3(N1, WALLS && VISC && MODAL)))) void kt3_rhs(TensorTables TT, MeshDev M, Phys ph, const double* Q,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WALLS && VISC && MODAL)))) void kt3_rhs(TensorTables TT, MeshDev M, Phys ph, const double* Q,
                                                           const double* __restrict__ A_U, const double* __restrict__ SG,
                                                           const double* __restrict__ B, double* rhs, LsrkFuse lf, StageFuse sf) {
   // (Q and rhs are NOT restrict-qualified: the fused RK forms write the state in place -- lf.Qw, StageFuse::y may be the array Q
