@@ -288,6 +288,9 @@ def parse_args(argv=None):
                     help="skip the extra timings -- the state without smooth regions (ms_per_step_rough_state) and the RK stages "
                          "(lsrk_*): the rocprofv3 passes use it so that their per-kernel averages and counters cover the headline "
                          "evaluation only")
+    ap.add_argument("--state", choices=["vortex", "rough"], default="vortex",
+                    help="2D, one GPU: rough = the whole measurement on the state without smooth regions (SURVEY 8d's robustness variant; "
+                         "profiling aid: the headline is the vortex state BASELINE specifies, config.workload says which one ran)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the process group (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank logic on fewer GPUs: traces are then staged through the host)")
     ap.add_argument("--transport", choices=["rccl", "torch"], default=None,
@@ -412,6 +415,8 @@ def run(args):
         rank_offsets = np.array([Kx * kyr * r for r in range(world + 1)], dtype=np.int64)   # elements are numbered x-fastest
         e0, e1 = int(rank_offsets[rank]), int(rank_offsets[rank + 1])
         rd, md, ops, Q = build_problem(N, Kx, Ky_total, e0, e1, args.formulation)
+        if args.state == "rough" and world == 1:
+            Q = rough_state(Q)
         form = engine.CNS_MODAL if args.formulation == "cns" else engine.EULER_COLLOCATED
         eng = engine.RhsEngine(rd, md, ops, form, rank=rank, nranks=world, rank_offsets=rank_offsets)
         K_total = Kx * Ky_total
@@ -714,7 +719,7 @@ def run(args):
                     + ("_pernode_geometry" if args.hex_geometry == "per-node" else "_element_geometry"))
         metric = f"element-DOF updates/sec (RHS evals/s) at N={N}, 3D hex Euler"
     else:
-        workload = (f"{args.formulation}2d_N{N}_{Kx}x{Ky_total}_quads_periodic_vortex"
+        workload = (f"{args.formulation}2d_N{N}_{Kx}x{Ky_total}_quads_periodic_{'vortex' if args.state == 'vortex' or world > 1 else 'rough_state'}"
                     + ("_Re1000_inviscid+viscous_dissipation" if args.formulation == "cns" else ""))
         metric = f"element-DOF updates/sec (RHS evals/s) at N={N}, 2D {'CNS' if args.formulation == 'cns' else 'Euler'} quad mesh"
     per = sorted(r / args.steps * 1e3 for r in reps)
