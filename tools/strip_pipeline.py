@@ -11,7 +11,7 @@ import bench
 from esdg_cns_amd import engine
 from esdg_cns_amd._lib import check
 
-Kx = Ky = 512
+Kx, Ky = int(os.environ.get("KX", "512")), int(os.environ.get("KY", "512"))   # (KX=2048 KY=256: rank 0's strip of cfg4 as a stand-alone periodic mesh)
 rd, md, ops, Q = bench.build_problem(4, Kx, Ky, 0, Kx * Ky, "cns")
 eng = engine.RhsEngine(rd, md, ops, engine.CNS_MODAL)
 Qd = eng.upload(Q); out = eng.new_state()
@@ -53,6 +53,7 @@ def timeit(fn, n=50):
 for _ in range(200): full()      # clock ramp
 full(); torch.cuda.synchronize(); ref = out.clone()
 sizes = [int(a) for a in sys.argv[1:]] or [16, 32, 64, 128]
+print(f"mesh {Kx} x {Ky}")
 print(f"full: {timeit(full):.4f} ms")
 for S in sizes:
     out.zero_(); pipeline(S); torch.cuda.synchronize()
