@@ -1333,6 +1333,7 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
   off = align(off + (size_t)c->nsend * HEX_AU_NC * sizeof(double));
   c->xch.push_back(x0);
   c->ws_bytes = off;
+  if (const char* env = ab_env("ESDG_DOPRI_FUSION")) c->dopri_fusion = env[0] != '0';
   guard.c = nullptr;
   *out = c;
   return ESDG_OK;
@@ -1391,7 +1392,16 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
       rc = launch_project_hex(ctx->T.N1, ctx->HT, ctx->M, ctx->ph, Q, A_U, s);
     } else {
       if (!rhs && !lf.Qw) return fail(ESDG_ERR_ARG, "rhs output is null");
-      rc = launch_rhs_hex(ctx->T.N1, ctx->HT, ctx->M, ctx->ph, Q, A_U, rhs, lf, s);
+      StageFuse sfl;
+      const StageFuse* sfp = ctx->stage_fuse;
+      if (sfp && sfp->err) {   // (as for kt3_rhs below: every launch of the stage gets its own run of partials)
+        sfl = *sfp;
+        sfl.partial += ctx->stage_cursor;
+        ctx->stage_cursor += rhs_hex_blocks(ctx->T.N1, ranged ? e_count : ctx->K);
+        sfp = &sfl;
+      }
+      rc = launch_rhs_hex(ctx->T.N1, ctx->HT, ctx->M, ctx->ph, Q, A_U, rhs, lf, s, sfp);
+      if (rc == -1) return fail(ESDG_ERR_STATE, "DOPRI45 stage fusion asked of a hexahedral context whose last phase is not kh_rhs_l");
     }
   } else if (phase == 0) {
     rc = ctx->use_fast ? launch_project_tensor2(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, s)
@@ -2105,19 +2115,23 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
     return fail(ESDG_ERR_STATE, "esdg_dopri45_attempt on a sharded mesh needs the library's communicator (esdg_comm_init): the "
                                 "error norm is a sum over all ranks");
   const int64_t n = (int64_t)ctx->nfld * ctx->K * ctx->Np;
-  // Fused attempt (round 4; CNS contexts whose last phase is kt3_rhs, sharded ones included; ESDG_DOPRI_FUSION=0: off): the last phase of stage
+  // Fused attempt (round 4: CNS; round 5: every 2D context whose last phase is kt3_rhs, sharded ones included; ESDG_DOPRI_FUSION=0: off): the last phase of stage
   // s holds k_s in registers and also writes the NEXT stage's state Q + dt sum_j a_{s+1,j} k_j, so the separate combination pass
   // (read Q, k_0 ... k_s, write Qtmp) shrinks to the reads of Q, k_0 ... k_{s-1} inside the launch; stage 6 (the b row) also leaves
   // the error combination of k_0 ... k_5 in k[6]'s array, which stage 7's launch reads back, completes with k_6 and reduces to
   // one partial per workgroup.  Stages with a zero coefficient in both rows are not read.  Per node the same fma chains as the
   // unfused attempt (same bits: tests/test_gpu_drivers.py); 30 instead of 43 state-sized sweeps per attempt on top of six
   // right-hand sides.
-  const bool fuse = ctx->dopri_fusion && ctx->dim == 2 && ctx->use_fast && ctx->nphases == 3 && ctx->ph.formulation == 1 &&
-                    !ctx->bf && !(ctx->ph.dbg & ~32) && !(ctx->v2 & 2) && ctx->T.N1 >= 2 && ctx->T.N1 <= ESDG_MAX_N1 &&
-                    (!ctx->M.bc || ctx->T.N1 < 6);   // (CNS wall meshes from N = 5 on run kt2_rhs: no fused attempt there)
+  // (wall meshes whose last phase is kt2_rhs -- CNS from N = 5, the inviscid formulations from N = 7 on -- take the unfused attempt)
+  const bool fuse2 = ctx->dopri_fusion && ctx->dim == 2 && ctx->use_fast && (ctx->nphases == 3 || ctx->nphases == 2) &&
+                     !ctx->bf && !(ctx->ph.dbg & ~32) && !(ctx->v2 & 2) && ctx->T.N1 >= 2 && ctx->T.N1 <= ESDG_MAX_N1 &&
+                     (!ctx->M.bc || ctx->T.N1 < (ctx->ph.formulation == 1 ? 6 : 8));
+  const bool fuse3 = ctx->dopri_fusion && ctx->dim == 3 && !ctx->bf && rhs_hex_blocks(ctx->T.N1, ctx->K) > 0;   // (kh_rhs_l)
+  const bool fuse = fuse2 || fuse3;
   if (fuse) {
     if (!ctx->d_stage_partial.p) {   // (a sharded schedule launches the last phase in up to three pieces, each rounding up)
-      int rc = ctx->d_stage_partial.alloc(sizeof(double) * (size_t)(rhs_tensor3_blocks(ctx->T.N1, ctx->K) + 9));
+      const int nblk = fuse3 ? rhs_hex_blocks(ctx->T.N1, ctx->K) : rhs_tensor3_blocks(ctx->T.N1, ctx->K);
+      int rc = ctx->d_stage_partial.alloc(sizeof(double) * (size_t)(nblk + 9));
       if (rc) return rc;
     }
     const LsrkFuse none{nullptr, nullptr, 0.0, 0.0, 0.0};

@@ -160,7 +160,7 @@ struct LsrkFuse {
 };
 
 // optional fusion of the DOPRI45 stage combination and error norm into the last phase (esdg_dopri45_attempt; the STG
-// instantiation of kt3_rhs, CNS contexts).  The launch stores its right-hand side k_s as always and, from the value in registers,
+// instantiations of kt3_rhs and kh_rhs_l).  The launch stores its right-hand side k_s as always and, from the value in registers,
 //   y != null : y = x0 + dt (sum_{j<ns} c[j] k[j] + c_last k_s), the state of the next stage (y may be the state the launch read:
 //               a workgroup reads its elements' state at entry only), and with e_out != null also
 //               e_out = sum_{j<ns} ce[j] k[j] + ce_last k_s, the error combination so far;
@@ -235,7 +235,8 @@ bool hex_supported_degree(int N1);
 int launch_project_hex(int N1, const HexTables& HT, const MeshDev& M, const Phys& ph, const double* Q, double* A_U,
                        hipStream_t s);
 int launch_rhs_hex(int N1, const HexTables& HT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
-                   double* rhs, const LsrkFuse& lf, hipStream_t s);
+                   double* rhs, const LsrkFuse& lf, hipStream_t s, const StageFuse* sf = nullptr);
+int rhs_hex_blocks(int N1, int64_t e_count);   // workgroups of that launch (StageFuse::partial); -1 where the fused stage does not apply
 int launch_rhstest_hex(int64_t n, const double* wJq, const double* Q, const double* rhs, double* partial, int nblocks,
                        hipStream_t s);
 int launch_log_test(const double* x, double* y, int64_t n, hipStream_t s);

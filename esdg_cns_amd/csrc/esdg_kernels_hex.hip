@@ -1050,9 +1050,12 @@ __device__ __forceinline__ void line_slots(int d, int o, int& base, int& stride)
 #define KHL_FENCE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
 #define KHL_PIN5(a) asm volatile("" : "+v"((a)[0]), "+v"((a)[1]), "+v"((a)[2]), "+v"((a)[3]), "+v"((a)[4]))
 
-template <int N1, int GM>
-__global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M, Phys ph, const double* __restrict__ Q,
-                                                       const double* __restrict__ A_U, double* __restrict__ rhs, LsrkFuse lf) {
+// STG: the DOPRI45 stage fusion of kt3_rhs (StageFuse, esdg_dev.hpp) for the hexahedral path: the node rounds also form the next
+// stage's state / the error norm from the value they hold.  Q and rhs are not __restrict__: the fused updates write the state
+// the launch read (lf.Qw, sf.y) -- every read of Q lies before the barrier that precedes the node rounds.
+template <int N1, int GM, bool STG = false>
+__global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M, Phys ph, const double* Q,
+                                                       const double* __restrict__ A_U, double* rhs, LsrkFuse lf, StageFuse sf) {
   using C = LCfg<N1>;
   constexpr HexLayout L(N1);
   constexpr int E = C::E, NN = C::NN, Nq = C::Nq, Nfq = C::Nfq, T = C::T, NV = C::NV, NVN = C::NVN, NQP = C::NQP, LLD = C::LLD, NRN = C::NRN;
@@ -1288,12 +1291,55 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
     __syncthreads();
   }
   // ---- node rounds: -(.)/J, store or fused low-storage RK stage (:198-212) ------------------------------------------------
+  asm volatile("" ::: "memory");   // (no load of the state sinks below this point: the fused updates may overwrite it in place)
+  double stg_acc = 0.0;            // STG: this lane's part of the error norm
 #pragma unroll
   for (int r = 0; r < NRN; ++r) {
     const int n = tid + r * T;
     if (n < nE * Nq) {
       const int en = n / Nq, q = n - en * Nq, sl = en * NQP + q + (C::P != N1 ? q / N1 : 0);
       const double miJ = -rcp_refined(CURVED ? M.Jq[e0 * Nq + n] : sGeo[en * HEX_GEO_STRIDE + 9]);
+      if (STG) {   // DOPRI45: the store of k_s plus the next stage's state / the error norm -- the fma chains of kt3_rhs's STG epilogue
+        const int64_t i0 = e0 * Nq + n;
+        double out[HEX_NFLD];
+#pragma unroll
+        for (int c = 0; c < HEX_NFLD; ++c) out[c] = sR[c * NV + sl] * miJ;
+        if (sf.y) {   // (uniform)
+          double xo[HEX_NFLD], kk[6][HEX_NFLD];
+#pragma unroll
+          for (int c = 0; c < HEX_NFLD; ++c) xo[c] = sf.x0[c * KN + i0];
+#pragma unroll
+          for (int j = 0; j < 6; ++j)
+            if (j < sf.ns) {   // (uniform)
+#pragma unroll
+              for (int c = 0; c < HEX_NFLD; ++c) kk[j][c] = sf.k[j][c * KN + i0];
+            }
+#pragma unroll
+          for (int c = 0; c < HEX_NFLD; ++c) rhs[c * KN + i0] = out[c];
+#pragma unroll
+          for (int c = 0; c < HEX_NFLD; ++c) {
+            double a = 0.0, ee = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+              if (j < sf.ns) { a = __builtin_fma(sf.c[j], kk[j][c], a); ee = __builtin_fma(sf.ce[j], kk[j][c], ee); }
+            a = __builtin_fma(sf.c_last, out[c], a);
+            sf.y[c * KN + i0] = __builtin_fma(sf.dt, a, xo[c]);
+            if (sf.e_out) sf.e_out[c * KN + i0] = __builtin_fma(sf.ce_last, out[c], ee);
+          }
+        } else {
+          double xo[HEX_NFLD], ei[HEX_NFLD];
+#pragma unroll
+          for (int c = 0; c < HEX_NFLD; ++c) { xo[c] = sf.x0[c * KN + i0]; ei[c] = sf.err ? rhs[c * KN + i0] : 0.0; }
+#pragma unroll
+          for (int c = 0; c < HEX_NFLD; ++c) {
+            rhs[c * KN + i0] = out[c];
+            const double e = __builtin_fma(sf.ce_last, out[c], ei[c]);
+            const double sc = fabs(e) / (sf.tol * (1 + fabs(xo[c])));
+            stg_acc += sc * sc;
+          }
+        }
+        continue;
+      }
       if (lf.Qw) {   // (uniform) fused low-storage RK stage, same rounding sequence as k_lsrk; res and Qw are distinct arrays: all
         double ro[HEX_NFLD], qo[HEX_NFLD];   // loads first, then the stores (one round trip instead of ten)
 #pragma unroll
@@ -1309,6 +1355,18 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
 #pragma unroll
         for (int c = 0; c < HEX_NFLD; ++c) rhs[(int64_t)c * KN + e0 * Nq + n] = sR[c * NV + sl] * miJ;
       }
+    }
+  }
+  if (STG && sf.err) {   // (uniform) one partial per workgroup: lanes of a wave, then the workgroup's waves in order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) stg_acc += __shfl_xor(stg_acc, off, 64);
+    __syncthreads();     // (the tables' space: every lane left the line stage several barriers ago)
+    if ((tid & 63) == 0) sTab[tid >> 6] = stg_acc;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < T / 64; ++w) t += sTab[w];
+      sf.partial[blockIdx.x] = t;
     }
   }
 }
@@ -1367,9 +1425,22 @@ int launch_project_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phy
 static int g_hex_line = 1;   // kh_rhs_l; 0 = kh_rhs / kh_rhs_g (A/B builds: esdg_api.hip under -DESDG_AB_HOOKS, ESDG_HEX_LINE=0)
 void ab_tuning_hex(int line) { g_hex_line = line; }
 
+// workgroups of a last-phase launch over e_count elements (StageFuse::partial has one entry each); -1: the line kernel is off
+int rhs_hex_blocks(int N1v, int64_t e_count) {
+  if (g_hex_line == 0) return -1;
+  switch (N1v) {
+#define ESDG_HEXL_BLOCKS(N1c) case N1c: return (int)((e_count + hdev::LCfg<N1c>::E - 1) / hdev::LCfg<N1c>::E);
+    ESDG_HEXL_BLOCKS(2) ESDG_HEXL_BLOCKS(3) ESDG_HEXL_BLOCKS(4) ESDG_HEXL_BLOCKS(5) ESDG_HEXL_BLOCKS(6) ESDG_HEXL_BLOCKS(7) ESDG_HEXL_BLOCKS(8) ESDG_HEXL_BLOCKS(9) ESDG_HEXL_BLOCKS(10)
+#undef ESDG_HEXL_BLOCKS
+    default: return -1;
+  }
+}
+
 int launch_rhs_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U,
-                   double* rhs, const LsrkFuse& lf, hipStream_t s) {
+                   double* rhs, const LsrkFuse& lf, hipStream_t s, const StageFuse* sf) {
   if (M.e_count <= 0) return 0;
+  if (sf && g_hex_line == 0) return -1;   // (DOPRI45 stage fusion: the line kernel only)
+  const StageFuse sf0{};
   const int remap = (ph.dbg & 16) ? 0 : 1;
   // The line-per-lane kernel kh_rhs_l at every degree and in every geometry mode (round 4: N = 3 128x128x16 1.03 vs
   // 1.23 ms for kh_rhs; N = 1, 2: 0.65, 0.83 x kh_rhs; N = 4 ... 7: 0.47 ... 0.74 x the row-wise kh_rhs_g);
@@ -1379,9 +1450,13 @@ int launch_rhs_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phys& p
 #define ESDG_HEXL_LAUNCH(N1c)                                                                                                 \
   case N1c: {                                                                                                                \
     const dim3 grid((unsigned)((M.e_count + hdev::LCfg<N1c>::E - 1) / hdev::LCfg<N1c>::E)), blk(hdev::LCfg<N1c>::T);         \
-    if (M.G9) hipLaunchKernelGGL((hdev::kh_rhs_l<N1c, 1>), grid, blk, 0, s, HT, M, ph, Q, A_U, rhs, lf);                    \
-    else if (M.hdv) hipLaunchKernelGGL((hdev::kh_rhs_l<N1c, 2>), grid, blk, 0, s, HT, M, ph, Q, A_U, rhs, lf);              \
-    else hipLaunchKernelGGL((hdev::kh_rhs_l<N1c, 0>), grid, blk, 0, s, HT, M, ph, Q, A_U, rhs, lf);                          \
+    if (sf) {                                                                                                                \
+      if (M.G9) hipLaunchKernelGGL((hdev::kh_rhs_l<N1c, 1, true>), grid, blk, 0, s, HT, M, ph, Q, A_U, rhs, lf, *sf);         \
+      else if (M.hdv) hipLaunchKernelGGL((hdev::kh_rhs_l<N1c, 2, true>), grid, blk, 0, s, HT, M, ph, Q, A_U, rhs, lf, *sf);   \
+      else hipLaunchKernelGGL((hdev::kh_rhs_l<N1c, 0, true>), grid, blk, 0, s, HT, M, ph, Q, A_U, rhs, lf, *sf);               \
+    } else if (M.G9) hipLaunchKernelGGL((hdev::kh_rhs_l<N1c, 1>), grid, blk, 0, s, HT, M, ph, Q, A_U, rhs, lf, sf0);         \
+    else if (M.hdv) hipLaunchKernelGGL((hdev::kh_rhs_l<N1c, 2>), grid, blk, 0, s, HT, M, ph, Q, A_U, rhs, lf, sf0);          \
+    else hipLaunchKernelGGL((hdev::kh_rhs_l<N1c, 0>), grid, blk, 0, s, HT, M, ph, Q, A_U, rhs, lf, sf0);                      \
   } break;
       switch (N1v) {
         ESDG_HEXL_LAUNCH(2) ESDG_HEXL_LAUNCH(3) ESDG_HEXL_LAUNCH(4) ESDG_HEXL_LAUNCH(5) ESDG_HEXL_LAUNCH(6) ESDG_HEXL_LAUNCH(7) ESDG_HEXL_LAUNCH(8) ESDG_HEXL_LAUNCH(9) ESDG_HEXL_LAUNCH(10)

@@ -705,7 +705,7 @@ static int launch_rhs3(const TensorTables& TT, const MeshDev& M, const Phys& ph,
   if (M.bc) {
     if constexpr (kt3_serves_walls<N1, MODAL, VISC>()) {
       if (sf) {
-        if constexpr (MODAL && VISC) hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, true, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, *sf);
+        hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, true, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, *sf);
       } else {
         hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, sf0);
       }
@@ -714,8 +714,8 @@ static int launch_rhs3(const TensorTables& TT, const MeshDev& M, const Phys& ph,
       return -1;
     }
   }
-  if (sf) {   // DOPRI45 stage (esdg_dopri45_attempt): instantiated for the CNS formulation, which is what the reference integrates so
-    if constexpr (MODAL && VISC) hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, false, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, *sf);
+  if (sf) {   // DOPRI45 stage (esdg_dopri45_attempt); the reference integrates CNS so (cavity_optimized.jl:999-1037), the library every 2D formulation
+    hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, false, true>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, *sf);
     return 0;
   }
   hipLaunchKernelGGL((t3::kt3_rhs<N1, MODAL, VISC, false>), dim3(nb), dim3(G::TW), 0, s, TT, M, ph, Q, A_U, SG, B, rhs, lf, sf0);
@@ -727,7 +727,6 @@ int launch_rhs_tensor3(int N1v, const TensorTables& TT, const MeshDev& M, const 
                        const double* SG, const double* B, double* rhs, const LsrkFuse& lf, hipStream_t s, const StageFuse* sf) {
   if (M.e_count <= 0) return 0;
   const bool modal = ph.formulation != 0, visc = ph.formulation == 1;
-  if (sf && !(modal && visc)) return -1;
   int rc = 0;
   ESDG_T3_DISPATCH(N1v, {
     if (!modal) rc = (launch_rhs3<N1, false, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s, sf);

@@ -356,10 +356,11 @@ int esdg_dopri_error(const double* Q_dev, const double* const* k_dev, const doub
  * (cavity_optimized.jl:1002-1021): k is an array of 7 device state buffers, k[0] = rhs(Q) on entry (FSAL); on return
  * Qtmp is the candidate state, *err_est the estimate; the caller accepts (Q <- Qtmp, swap k[0], k[6]) if it is < 1 and
  * takes the next step size from esdg_dopri45_next_dt (the P / PI controller of :1027-1033).
- * On CNS contexts served by the tensor kernels (unsharded, or sharded with a communicator attached) the stage combinations and the
- * error norm are computed inside the last-phase launch of each stage from the k_s it holds in registers (no separate passes
- * over the state; esdg_axpy_stages / esdg_dopri_error above are then not used): per node the same bits, the estimate to summation
- * order, 4.6 instead of 5.1 ms per attempt at N=4 on 512x512.
+ * On contexts whose last phase is the line-per-lane kernel -- every 2D formulation on the tensor kernels (CNS wall meshes up to
+ * N = 4, inviscid ones up to N = 6) and hexahedra; unsharded, or sharded with a communicator attached -- the stage combinations
+ * and the error norm are computed inside the last-phase launch of each stage from the k_s it holds in registers (no separate
+ * passes over the state; esdg_axpy_stages / esdg_dopri_error above are then not used): per node the same bits, the estimate to
+ * summation order, 4.3 instead of 5.1 ms per attempt for CNS at N=4 on 512x512.
  * Reproducibility of the estimate: it is a sum of one partial per workgroup of the last-phase launches, so its last bits depend on
  * how a context cuts that phase into launches (stand-alone, or interior + boundary strips of a sharded schedule) and on whether
  * the fused or the separate-pass form runs.  An adaptive run (step sizes follow the estimate) is bitwise reproducible for a FIXED

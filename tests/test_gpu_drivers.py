@@ -299,32 +299,43 @@ def test_two_gloo_ranks_sharing_the_gpu_match_the_single_engine(formulation):
 
 
 @pytest.mark.parametrize("case", ["cns N=4 13x9", "cns N=2 10x7", "cns N=6 5x4", "cns N=7 4x3", "cavity N=4 9x8 BCTYPE=1", "cavity N=3 8x7 BCTYPE=2",
-                                  "cavity N=1 7x6 BCTYPE=1", "cns N=4 256x256", "cns N=9 3x2"])
+                                  "cavity N=1 7x6 BCTYPE=1", "cns N=4 256x256", "cns N=9 3x2", "euler N=4 12x9", "euler N=3 16x16", "euler N=7 4x3",
+                                  "inviscid N=4 9x8", "hex N=3 5x4x3", "hex N=1 6x5x4", "hex N=4 3x2x2", "hex N=7 2x2x1", "hexcurved N=2 4x3x3"])
 def test_fused_dopri45_attempt_is_bitwise_the_attempt_from_building_blocks(case):
-    """esdg_dopri45_attempt on an unsharded CNS context: the last phase of every stage also forms the next stage's state from the
+    """esdg_dopri45_attempt on an unsharded 2D context (CNS; round 5: collocated Euler and the inviscid modal formulation too): the last phase of every stage also forms the next stage's state from the
     k_s it holds in registers, stage 6 leaves the error combination so far in k[6]'s array and stage 7 reduces the norm
     (StageFuse, kt3_rhs STG).  Claim: per node the same bits as esdg_axpy_stages + RHS + esdg_dopri_error
     (dg2D_CNS_cavity_optimized.jl:1002-1021) -- the stage state, all seven k and the accepted solution -- and the error estimate to
     summation order; same accept / reject and step-size history.  Partial last groups, periodic and wall meshes, N1 = 2 ... 8.
     A context created with ESDG_DOPRI_FUSION=0 takes the unfused attempt inside the library: same bits again."""
     import torch
-    from common import product_cavity_problem
+    from common import product_cavity_problem, product_euler_problem
     from esdg_cns_amd import engine, timestep
     kind, rest = case.split(" ", 1)
-    N = int(rest.split()[0][2:]); Kx, Ky = (int(v) for v in rest.split()[1].split("x"))
-    kw = {}
-    if kind == "cns":
+    N = int(rest.split()[0][2:]); Kx, Ky = (int(v) for v in rest.split()[1].split("x")[:2])
+    kw, form = {}, engine.CNS_MODAL
+    if kind.startswith("hex"):  # (round 5: kh_rhs_l's STG instantiation; affine and curved geometry modes)
+        from common import product_hex_problem
+        rd, md, ops, Q = product_hex_problem(N, Kx, Ky, int(rest.split()[1].split("x")[2]), a=0.1 if kind == "hexcurved" else 0.0)
+        form, kw = engine.EULER_HEX_COLLOCATED, {"lf_scale": 0.25}
+    elif kind == "cns":
         rd, md, ops, Q = product_cns_problem(N, Kx, Ky)
+    elif kind == "euler":       # (round 5: the collocated Euler formulation and rhs_inviscid! alone take the fused attempt too)
+        rd, md, ops, Q = product_euler_problem(N, Kx, Ky)
+        form = engine.EULER_COLLOCATED
+    elif kind == "inviscid":
+        rd, md, ops, Q = product_cns_problem(N, Kx, Ky)
+        form = engine.EULER_MODAL
     else:
         rd, md, ops, Q = product_cavity_problem(N, Kx, Ky)
         kw["BCTYPE"] = int(rest.split("=")[-1])
-    eng = engine.RhsEngine(rd, md, ops, engine.CNS_MODAL, **kw)
+    eng = engine.RhsEngine(rd, md, ops, form, **kw)
     os.environ["ESDG_DOPRI_FUSION"] = "0"
     try:
-        eng0 = engine.RhsEngine(rd, md, ops, engine.CNS_MODAL, ab_hooks=True, **kw)
+        eng0 = engine.RhsEngine(rd, md, ops, form, ab_hooks=True, **kw)
     finally:
         del os.environ["ESDG_DOPRI_FUSION"]
-    dt0 = 0.5 * (2 / Kx) / ((N + 1) * (N + 2) / 2)
+    dt0 = 0.5 * (2 / Kx) / ((N + 1) * (N + 2) / 2) * (0.2 if kind.startswith("hex") else 1.0)
     integs = []
     for e, pieces in ((eng, False), (eng, True), (eng0, False)):     # (the first accepts by swapping its buffers, the others copy)
         integs.append(timestep.Dopri45(e, e.upload(Q), dt0, err_tol=1e-7 if case == "cns N=4 13x9" else 1e-5, pieces=pieces,

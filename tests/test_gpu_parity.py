@@ -386,6 +386,24 @@ def test_cfg3_cns_512_exact_size_values_against_oracle(eng_mod, oracle_lib):
         _one_core()
 
 
+def test_cfg3_cns_512_exact_size_with_oracle_built_inputs(eng_mod, oracle_lib):
+    """The headline configuration at its exact size with the ORACLE's set-up objects (oracle/ref_setup.py, ~25 s at this size) fed to
+    engine, Float64 oracle and binary128 truth alike -- the gate at the headline size does not rest on the product's own set-up
+    arrays (parity: "none at a headline size").  ESDG_TRUTH_512=0 skips it (the truth takes ~100 s on 16 cores)."""
+    import os
+    if os.environ.get("ESDG_TRUTH_512", "1") == "0":
+        pytest.skip("ESDG_TRUTH_512=0: the binary128 truth at 512x512 is switched off")
+    from oracle import oracle as orc
+    p = orc.build_cns_problem(4, 512, 512, bc="periodic")
+    o, q = _cns(p)
+    eng = eng_mod.RhsEngine(p.rd, p.md, p.ops, eng_mod.CNS_MODAL, Re=p.Re, mu=p.mu, lam=p.lam, Pr=p.Pr)
+    _all_cores()
+    try:
+        truth_gate("cfg3 cns N=4 512x512 vortex (oracle-built inputs)", _gpu_rhs(eng, p.Q), o.rhsRK(p.Q, False)[0], q.rhsRK(p.Q, False)[0])
+    finally:
+        _one_core()
+
+
 def test_cavity_state_with_exact_zeros_of_the_normal_velocity_looser_documented_bound(eng_mod, oracle_lib):
     """The cavity state WITHOUT the phase shift of common.cavity_state: u = .1 sin(pi x) cos(pi y) vanishes exactly on the
     element interfaces x = 0, +-1/2 ..., so rhoU_n there is an exact zero plus round-off and the reference's wavespeed
