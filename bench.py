@@ -540,11 +540,11 @@ def run(args):
         del Qw, res
         eng.rhs_into(Qd, out)
     # One attempted DOPRI45 step of the CNS drivers' time loop (dg2D_CNS_cavity_optimized.jl:999-1037; six right-hand sides, the
-    # stage combinations, the error norm) through esdg_dopri45_attempt -- on CNS contexts with the combinations and the norm
+    # stage combinations, the error norm) through esdg_dopri45_attempt -- with the combinations and the norm
     # inside the last phase of each stage (StageFuse) -- and from the library's building blocks (esdg_axpy_stages, esdg_rhs,
     # esdg_dopri_error: 41 state-sized sweeps beside the six evaluations).  Accepting swaps the two state buffers; includes the host's read of the estimate.
     dopri45_attempt_ms = dopri45_attempt_pieces_ms = None
-    if world == 1 and args.formulation == "cns" and not hexw and not args.no_rough_state:
+    if world == 1 and not args.no_rough_state:    # (round 5: the fused attempt serves every formulation)
         from esdg_cns_amd import timestep
         for pieces in (False, True):
             Qw = Qd.clone()

@@ -863,9 +863,6 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
                                     modal ? &Vq : nullptr, modal ? &Pq : nullptr, th);
   if (const char* env = ab_env("ESDG_FORCE_GENERIC"))
     if (env[0] == '1') use_fast = false;
-  if (N1 > 9 && mesh->NmapB > 0)
-    return fail(ESDG_ERR_ARG, "meshes with walls are served up to N=8 (the wall instantiation of the last phase is kt2_rhs from N=7 on, "
-                              "whose packed rows end at N=8); N=%d works on periodic meshes", ops->N);
   if (!supported_degree(N1) && !use_fast)
     return fail(ESDG_ERR_STRUCTURE, "degree N=%d is served by the tensor kernels only, and the operators passed do not factor into 1D tables "
                                     "(the generic kernels stop at N=7)", ops->N);
@@ -2122,10 +2119,10 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
   // one partial per workgroup.  Stages with a zero coefficient in both rows are not read.  Per node the same fma chains as the
   // unfused attempt (same bits: tests/test_gpu_drivers.py); 30 instead of 43 state-sized sweeps per attempt on top of six
   // right-hand sides.
-  // (wall meshes whose last phase is kt2_rhs -- CNS from N = 5, the inviscid formulations from N = 7 on -- take the unfused attempt)
+  // (wall meshes whose last phase is kt2_rhs -- CNS at N = 5 ... 8, the inviscid formulations at N = 7, 8 -- take the unfused attempt)
   const bool fuse2 = ctx->dopri_fusion && ctx->dim == 2 && ctx->use_fast && (ctx->nphases == 3 || ctx->nphases == 2) &&
                      !ctx->bf && !(ctx->ph.dbg & ~32) && !(ctx->v2 & 2) && ctx->T.N1 >= 2 && ctx->T.N1 <= ESDG_MAX_N1 &&
-                     (!ctx->M.bc || ctx->T.N1 < (ctx->ph.formulation == 1 ? 6 : 8));
+                     (!ctx->M.bc || ctx->T.N1 < (ctx->ph.formulation == 1 ? 6 : 8) || ctx->T.N1 == 10);
   const bool fuse3 = ctx->dopri_fusion && ctx->dim == 3 && !ctx->bf && rhs_hex_blocks(ctx->T.N1, ctx->K) > 0;   // (kh_rhs_l)
   const bool fuse = fuse2 || fuse3;
   if (fuse) {

@@ -48,7 +48,7 @@ constexpr int FAU_NC = 4;
 // Largest N1 = N + 1 of the 2D tensor kernels (kt2_project, kt2_sigma, kt3_rhs; kt2_rhs stops at 9).  The generic pair-list
 // kernels stop at N1 = 8, the hexahedral kernels at 10 (the row-wise kh_rhs_g at 8).
 #ifndef ESDG_MAX_N1
-#define ESDG_MAX_N1 10
+#define ESDG_MAX_N1 12
 #endif
 
 struct TensorTables;

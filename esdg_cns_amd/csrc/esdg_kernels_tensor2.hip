@@ -57,6 +57,8 @@ template <> struct Cfg<8> { static constexpr int GW = 2; };
 #endif
 template <> struct Cfg<9> { static constexpr int GW = ESDG_T2_GW9; };
 template <> struct Cfg<10> { static constexpr int GW = ESDG_T2_GW10; };
+template <> struct Cfg<11> { static constexpr int GW = 2; };   // (round 5: one element per group, 121 of 128 / 144 of 192 lanes)
+template <> struct Cfg<12> { static constexpr int GW = 3; };
 
 // ... and of the last-phase kernel where its measured optimum differs (N=5, 384x384, same box: kt2_rhs 0.400 ms with 4
 // waves per group -- 58 KB LDS, 2 workgroups per CU -- 0.358 ms with 2; kt2_sigma the other way round, 0.161 vs 0.179 ms)
@@ -1437,21 +1439,33 @@ __global__ __launch_bounds__(GeoR<N1>::GT, (RhsLds2<N1, MODAL, VISC>::WPE)) void
 
 }  // namespace t2
 
-#if ESDG_MAX_N1 >= 10
-#define ESDG_T2_DISPATCH_HI(...) case 9: { constexpr int N1 = 9; __VA_ARGS__; } break; case 10: { constexpr int N1 = 10; __VA_ARGS__; } break;
+#if ESDG_MAX_N1 >= 12
+#define ESDG_T2_DISPATCH_HI(...) case 10: { constexpr int N1 = 10; __VA_ARGS__; } break; case 11: { constexpr int N1 = 11; __VA_ARGS__; } break; case 12: { constexpr int N1 = 12; __VA_ARGS__; } break;
+#elif ESDG_MAX_N1 >= 10
+#define ESDG_T2_DISPATCH_HI(...) case 10: { constexpr int N1 = 10; __VA_ARGS__; } break;
 #else
 #define ESDG_T2_DISPATCH_HI(...)
 #endif
-#define ESDG_T2_DISPATCH(N1v, BODY)                  \
+// (N1 = 2 ... 9: every kernel of this file -- ESDG_T2_DISPATCH9, kt2_rhs's packed rows end there; ESDG_T2_DISPATCH adds the degrees
+// that only phases 0 and 1 serve.  Two stand-alone macros: a body that launches a kernel cannot pass through a second macro.)
+#define ESDG_T2_CASES9(...)                          \
+    case 2: { constexpr int N1 = 2; __VA_ARGS__; } break;   \
+    case 3: { constexpr int N1 = 3; __VA_ARGS__; } break;   \
+    case 4: { constexpr int N1 = 4; __VA_ARGS__; } break;   \
+    case 5: { constexpr int N1 = 5; __VA_ARGS__; } break;   \
+    case 6: { constexpr int N1 = 6; __VA_ARGS__; } break;   \
+    case 7: { constexpr int N1 = 7; __VA_ARGS__; } break;   \
+    case 8: { constexpr int N1 = 8; __VA_ARGS__; } break;   \
+    case 9: { constexpr int N1 = 9; __VA_ARGS__; } break;
+#define ESDG_T2_DISPATCH9(N1v, ...)                  \
   switch (N1v) {                                     \
-    case 2: { constexpr int N1 = 2; BODY; } break;   \
-    case 3: { constexpr int N1 = 3; BODY; } break;   \
-    case 4: { constexpr int N1 = 4; BODY; } break;   \
-    case 5: { constexpr int N1 = 5; BODY; } break;   \
-    case 6: { constexpr int N1 = 6; BODY; } break;   \
-    case 7: { constexpr int N1 = 7; BODY; } break;   \
-    case 8: { constexpr int N1 = 8; BODY; } break;   \
-    ESDG_T2_DISPATCH_HI(BODY)                          \
+    ESDG_T2_CASES9(__VA_ARGS__)                      \
+    default: return (int)hipErrorInvalidValue;       \
+  }
+#define ESDG_T2_DISPATCH(N1v, ...)                   \
+  switch (N1v) {                                     \
+    ESDG_T2_CASES9(__VA_ARGS__)                      \
+    ESDG_T2_DISPATCH_HI(__VA_ARGS__)                 \
     default: return (int)hipErrorInvalidValue;       \
   }
 
@@ -1521,7 +1535,7 @@ int launch_rhs_tensor2(int N1v, const TensorTables& TT, const MeshDev& M, const 
   if (M.e_count <= 0) return 0;
   if (N1v < 2 || N1v > 9) return -1;   // (RhsRows packs a node's NRND <= 8 partner ids into two ints: N1 = 10 has nine)
   const bool modal = ph.formulation != 0, visc = ph.formulation == 1;
-  ESDG_T2_DISPATCH(N1v, {
+  ESDG_T2_DISPATCH9(N1v, {
     {
       if (!modal) (launch_rhs2<N1, false, false>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);
       else if (visc) (launch_rhs2<N1, true, true>)(TT, M, ph, Q, A_U, SG, B, rhs, lf, s);

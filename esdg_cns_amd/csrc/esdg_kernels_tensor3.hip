@@ -674,7 +674,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
 }  // namespace t3
 
 #ifndef ESDG_T3_NO_DISPATCH   // (tools/isa_buckets.py includes this file for one explicit instantiation)
-#if ESDG_MAX_N1 >= 10
+#if ESDG_MAX_N1 >= 12
+#define ESDG_T3_DISPATCH_HI(...) case 9: { constexpr int N1 = 9; __VA_ARGS__; } break; case 10: { constexpr int N1 = 10; __VA_ARGS__; } break; \
+  case 11: { constexpr int N1 = 11; __VA_ARGS__; } break; case 12: { constexpr int N1 = 12; __VA_ARGS__; } break;
+#elif ESDG_MAX_N1 >= 10
 #define ESDG_T3_DISPATCH_HI(...) case 9: { constexpr int N1 = 9; __VA_ARGS__; } break; case 10: { constexpr int N1 = 10; __VA_ARGS__; } break;
 #else
 #define ESDG_T3_DISPATCH_HI(...)
@@ -693,8 +696,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
   }
 
 // CNS on meshes with walls from N1 = 6 on: kt2_rhs (measured in round 5 on the lid-driven cavity, 128 x 128: N = 5 0.1021 vs 0.1047 ms,
-// N = 6 0.1652 vs 0.1910 ms -- the wall instantiation of kt3_rhs spills 54-64 registers there).  Not instantiated.
-template <int N1, bool MODAL, bool VISC> constexpr bool kt3_serves_walls() { return N1 < 8 && !(MODAL && VISC && N1 >= 6); }
+// N = 6 0.1652 vs 0.1910 ms -- the wall instantiation of kt3_rhs spills 54-64 registers there).  Not instantiated -- except at N1 = 10,
+// which kt2_rhs does not reach (its packed rows hold eight partner ids): there the wall instantiation of this kernel runs, one wave
+// per SIMD (512 registers, 22 spilled in the CNS form), so that every degree the library serves is served with walls too.
+template <int N1, bool MODAL, bool VISC> constexpr bool kt3_serves_walls() { return (N1 < 8 && !(MODAL && VISC && N1 >= 6)) || N1 >= 10; }
 
 template <int N1, bool MODAL, bool VISC>
 static int launch_rhs3(const TensorTables& TT, const MeshDev& M, const Phys& ph, const double* Q, const double* A_U, const double* SG,

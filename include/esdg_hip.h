@@ -60,8 +60,8 @@ typedef enum {
 /* Reference-element operators: fields of `rd::RefElemData` (src/SetupDG.jl:38-75) and of the
  * driver's `ops` tuple.  Column-major.  Pointers not needed by the formulation may be NULL. */
 typedef struct {
-  int32_t N;    /* polynomial degree.  Quads: periodic meshes 1..9, meshes with walls 1..8; the generic pair-list kernels (operators
-                 * that do not factor into 1D tables) 1..7.  esdg_create refuses anything beyond with the reason. */
+  int32_t N;    /* polynomial degree.  Quads: 1..11, periodic meshes and meshes with walls alike; the generic pair-list kernels (operators
+                 * that do not factor into 1D tables; periodic meshes only) 1..7.  esdg_create refuses anything beyond with the reason. */
   int32_t Np;   /* rows of a state matrix: (N+1)^2 */
   int32_t Nq;   /* volume quadrature nodes: length(rd.wq) */
   int32_t Nfq;  /* face quadrature nodes: length(rd.wf) */

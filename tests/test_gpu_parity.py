@@ -47,7 +47,7 @@ PHYS = dict(Re=1000.0, mu=1e-3, lam=-2e-3 / 3, Pr=.71, BCTYPE=1)
 
 
 @pytest.mark.parametrize("N,Kx,Ky", [(3, 16, 16), (4, 12, 8), (4, 64, 64), (2, 9, 7), (1, 6, 6), (5, 5, 4), (6, 4, 3), (7, 3, 3), (8, 4, 3),
-                                     (9, 3, 2)])
+                                     (9, 3, 2), (10, 3, 2), (11, 2, 3)])
 def test_euler_collocated_matches_oracle(eng_mod, oracle_lib, N, Kx, Ky):
     """`rhs` of examples/dg2D_euler_quad.jl:141-194; (3, 16, 16) is BASELINE config 1 at its exact size."""
     rd, md, ops, Q = product_euler_problem(N, Kx, Ky)
@@ -83,7 +83,7 @@ def test_degenerate_periodic_meshes_match_oracle(eng_mod, oracle_lib, form, N, K
 
 
 @pytest.mark.parametrize("N,Kx,Ky", [(4, 12, 8), (4, 64, 64), (3, 10, 10), (2, 7, 9), (1, 5, 5), (5, 4, 4), (4, 7, 3), (5, 5, 3), (6, 6, 5),
-                                     (7, 4, 3), (8, 4, 3), (9, 3, 2)])
+                                     (7, 4, 3), (8, 4, 3), (9, 3, 2), (10, 3, 2), (11, 2, 3)])
 def test_cns_modal_matches_oracle(eng_mod, oracle_lib, N, Kx, Ky):
     """`rhsRK!` of dg2D_CNS_cavity_optimized.jl:955-972 on the periodic vortex box (BASELINE config 3's formulation)."""
     rd, md, ops, Q = product_cns_problem(N, Kx, Ky)
@@ -144,7 +144,7 @@ VISC_FACTOR = 2.0
 
 
 @pytest.mark.parametrize("BCTYPE", [1, 2, 3])
-@pytest.mark.parametrize("N,Kx,Ky", [(3, 6, 5), (4, 8, 8), (5, 4, 3), (4, 2, 2), (8, 3, 2)])   # (2x2: fewer elements than one group holds; N=8: kt2_rhs's wall instantiation)
+@pytest.mark.parametrize("N,Kx,Ky", [(3, 6, 5), (4, 8, 8), (5, 4, 3), (4, 2, 2), (8, 3, 2), (9, 3, 2), (11, 2, 2)])   # (2x2: fewer elements than one group holds; N=8: kt2_rhs's wall instantiation; N=9 ... 11: kt3_rhs's, one wave per SIMD)
 def test_cns_wall_boundary_conditions_match_oracle(eng_mod, oracle_lib, BCTYPE, N, Kx, Ky):
     """Lid-driven cavity walls (init_BC_funs, dg2D_CNS_cavity_optimized.jl:135-265): adiabatic no-slip (1),
     isothermal (2), slip (3), lid on y=+1."""
@@ -154,7 +154,13 @@ def test_cns_wall_boundary_conditions_match_oracle(eng_mod, oracle_lib, BCTYPE, 
     o, q = _cns(p)
     kw = dict(Re=p.Re, mu=p.mu, lam=p.lam, Pr=p.Pr, BCTYPE=BCTYPE)
     eng = eng_mod.RhsEngine(rd, md, ops, eng_mod.CNS_MODAL, **kw)
-    truth_gate(f"cavity BCTYPE={BCTYPE} N={N} {Kx}x{Ky} rhsRK!", _gpu_rhs(eng, Q), o.rhsRK(Q, False)[0], q.rhsRK(Q, False)[0])
+    # N >= 9: 2.5 x e_orc instead of 2 (measured 1.9 at N = 9, 2.2 at N = 11; N = 8: 1.6).  Not the kernels' arithmetic -- IEEE divisions,
+    # the library logarithm, corrected quotients change nothing to two digits -- but the REPRESENTATION of the operators: the truth
+    # evaluates the driver's dense VhP exactly, the 1e-16 ... 2e-15 of set-up round-off in its mathematically zero / one entries
+    # included, the kernels apply the same operator from 1D tables; on this low-Mach state the momentum rows cancel so far that one ulp
+    # per entry of VhP moves them by 0.3-0.6 x e_orc, growing with N (tools/lowmach_probe.py, profiles/experiments/r05_lowmach_probe.txt).
+    truth_gate(f"cavity BCTYPE={BCTYPE} N={N} {Kx}x{Ky} rhsRK!", _gpu_rhs(eng, Q), o.rhsRK(Q, False)[0], q.rhsRK(Q, False)[0],
+               factor=2.5 if N >= 9 else 2.0)
     # rhs_viscous! alone (esdg_set_parts(2)); field 1 is identically zero
     eng.set_parts(2)
     gv = _gpu_rhs(eng, Q)
