@@ -987,7 +987,6 @@ int esdg_create(const esdg_ops_t* ops, const esdg_mesh_t* mesh, const esdg_phys_
   std::vector<uint8_t> bcflag;
   std::vector<double> vlid;
   if (mesh->NmapB > 0) {
-    if (!use_fast) return fail(ESDG_ERR_STRUCTURE, "wall boundary conditions need tensor-structured operators (generic kernels are periodic-only)");
     bcflag.assign((size_t)K * Nfq, 0);
     for (int64_t i = 0; i < mesh->NmapB; ++i) {
       const int64_t l = mesh->mapB[i] - 1 - mesh->elem_offset * Nfq;

@@ -17,6 +17,7 @@
 // (nodes / face nodes / pairs) x elements are spread over the 256 lanes.  HBM accesses are
 // coalesced: a state block of E elements is E*Np contiguous doubles per field.
 #include "esdg_dev.hpp"
+#include "esdg_wall_closures.hpp"
 
 namespace esdg {
 
@@ -260,13 +261,27 @@ __device__ __forceinline__ void visc_face_jumps(const Tables& T, const MeshDev& 
     }
     const int64_t n = (e0 + e) * Nfq + fn;
     const double* vp = A_v + (int64_t)M.mapP[n] * AV_NC;
-    const double vP[3] = {vp[0], vp[1], vp[2]};
+    double vP[3] = {vp[0], vp[1], vp[2]};
+    const int bc = M.bc ? M.bc[n] : 0;
+    // boundary node: exterior values by the wall closure (impose_BCs_entropyvars!, cavity :178-216; modalESDG :187-203)
+    if (bc) t2::wall_exterior_v(vf, bc, M.vlid ? M.vlid[n] : 1.0, M.fnrm + n * 3, ph, vP);
     const double tau = -1 / ph.Re / vf[2];
+    double pen[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double dv = vP[c] - vf[c];
       sDv[(e * 3 + c) * Nfq + fn] = .5 * dv;
-      if (WITH_PEN) sPen[(e * 3 + c) * Nfq + fn] = tau * dv;
+      pen[c] = tau * dv;
+    }
+    if (WITH_PEN && bc) {   // third component overridden at boundary nodes (:827-837; the form kt3_rhs uses)
+      const double dV[3] = {vP[0] - vf[0], vP[1] - vf[1], vP[2] - vf[2]};
+      double sq = .5 * (vP[0] + vf[0]) * dV[0] + .5 * (vP[1] + vf[1]) * dV[1];
+      if (ph.BCTYPE != 1) sq += dV[2] * dV[2] * .5;
+      pen[2] = -tau * sq / vf[2];
+    }
+    if (WITH_PEN) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sPen[(e * 3 + c) * Nfq + fn] = pen[c];
     }
   }
 }
@@ -325,9 +340,10 @@ __device__ __forceinline__ void visc_sigma(const Tables& T, const MeshDev& M, co
 // own normal stress at a face node: (Ef*sigma_x)*nxJ + (Ef*sigma_y)*nyJ, rows 2..4
 template <int N1>
 __device__ __forceinline__ void face_normal_stress(const Tables& T, const double* __restrict__ sS, int e, int fn,
-                                                   double nxJ, double nyJ, double* sn) {
+                                                   double nxJ, double nyJ, double* sn, double* fx, double* fy) {
   constexpr int Nq = N1 * N1;
-  double fx[3] = {0, 0, 0}, fy[3] = {0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { fx[c] = 0.0; fy[c] = 0.0; }
   for (int t = 0; t < T.wEf; ++t) {
     const double a = T.Ef_val[fn * T.wEf + t];
     const int col = T.Ef_idx[fn * T.wEf + t];
@@ -377,8 +393,8 @@ __global__ __launch_bounds__(ESDG_TPB) void k_sigma(Tables T, MeshDev M, Phys ph
   for (int idx = tid; idx < nE * Nfq; idx += ESDG_TPB) {
     const int e = idx / Nfq, fn = idx - e * Nfq;
     const double* gn = M.fnrm + ((e0 + e) * Nfq + fn) * 3   /* per-node (nxJ, nyJ, sJ), MeshDev::fnrm */;
-    double sn[3];
-    face_normal_stress<N1>(T, sS, e, fn, gn[0], gn[1], sn);
+    double sn[3], fx[3], fy[3];
+    face_normal_stress<N1>(T, sS, e, fn, gn[0], gn[1], sn, fx, fy);
     double* b = B + ((e0 + e) * Nfq + fn) * B_NC;
     b[0] = sn[0]; b[1] = sn[1]; b[2] = sn[2];
   }
@@ -437,21 +453,36 @@ __global__ __launch_bounds__(ESDG_TPB) void k_rhs(Tables T, MeshDev M, Phys ph, 
     const double* aP = A_U + (int64_t)M.mapP[n] * AU_NC;
     const double UM[4] = {aM[0], aM[1], aM[2], aM[3]};
     const double UP[4] = {aP[0], aP[1], aP[2], aP[3]};
-    const double lamM = aM[4], lamP = aP[4];
+    double lamM = aM[4], lamP = aP[4];
     double qM[6], qP[6];
     prim_logs<MODAL>(UM, qM);
     prim_logs<MODAL>(UP, qP);
     double* d = sQh + (e * Nh + Nq + fn) * 6;
 #pragma unroll
     for (int c = 0; c < 6; ++c) d[c] = qM[c];
+    const double* gn = M.fnrm + ((e0 + e) * Nfq + fn) * 3   /* per-node (nxJ, nyJ, sJ), MeshDev::fnrm */;
+    const int bc = M.bc ? M.bc[n] : 0;
+    if (bc >= 3) {   // shock-tube closures (dg2D_CNS_modalESDG.jl:168-185): Dirichlet state / copy, lam = lamP = 0
+#pragma unroll
+      for (int c = 0; c < 6; ++c) qP[c] = bc == 3 ? ph.inflow_q[c] : qM[c];
+      lamM = 0.0; lamP = 0.0;
+    } else if (bc) {   // wall: mirror state rho+ = rho, beta+ = beta, u+ = u - 2 (u.n) n  (impose_BCs_inviscid!, cavity :157-176)
+      const double nx = gn[0] / gn[2], ny = gn[1] / gn[2];
+      const double un = qM[1] * nx + qM[2] * ny;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) qP[c] = qM[c];
+      qP[1] = qM[1] - 2 * un * nx;
+      qP[2] = qM[2] - 2 * un * ny;
+      lamP = lamM;
+    }
     double Fx[4], Fy[4];
     ec_flux<MODAL>(qM, qP, Fx, Fy);
-    const double* gn = M.fnrm + ((e0 + e) * Nfq + fn) * 3   /* per-node (nxJ, nyJ, sJ), MeshDev::fnrm */;
     const double LFc = ph.lf_scale * fmax(lamM, lamP) * gn[2];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       double f = Fx[c] * gn[0] + Fy[c] * gn[1];
-      if (ph.inviscid_dissp) f -= LFc * (UP[c] - UM[c]);
+      // (the LF jump is Uf[mapP] - Uf, which vanishes at boundary nodes: mapP = self, cavity :511-513)
+      if (ph.inviscid_dissp && !bc) f -= LFc * (UP[c] - UM[c]);
       sFl[(e * 4 + c) * Nfq + fn] = f;
     }
   }
@@ -530,12 +561,16 @@ __global__ __launch_bounds__(ESDG_TPB) void k_rhs(Tables T, MeshDev M, Phys ph, 
     for (int idx = tid; idx < nE * Nfq; idx += ESDG_TPB) {
       const int e = idx / Nfq, fn = idx - e * Nfq;
       const double* gn = M.fnrm + ((e0 + e) * Nfq + fn) * 3   /* per-node (nxJ, nyJ, sJ), MeshDev::fnrm */;
-      double sn[3];
-      face_normal_stress<N1>(T, sS, e, fn, gn[0], gn[1], sn);
+      double sn[3], fx[3], fy[3];
+      face_normal_stress<N1>(T, sS, e, fn, gn[0], gn[1], sn, fx, fy);
       const int64_t n = (e0 + e) * Nfq + fn;
       const double* bp = B + (int64_t)M.mapP[n] * B_NC;
+      const int bc = M.bc ? M.bc[n] : 0;
+      double sj[3] = {.5 * (-bp[0] - sn[0]), .5 * (-bp[1] - sn[1]), .5 * (-bp[2] - sn[2])};
+      // boundary node: the jump impose_BCs_stress! prescribes (cavity :218-262; modalESDG :205-216)
+      if (bc) t2::wall_stress_jump(sn, fx, fy, bc, M.vlid ? M.vlid[n] : 1.0, gn, ph, sj);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) sSj[(e * 3 + c) * Nfq + fn] = .5 * (-bp[c] - sn[c]);
+      for (int c = 0; c < 3; ++c) sSj[(e * 3 + c) * Nfq + fn] = sj[c];
     }
     __syncthreads();
     // divergence + penalty (dg_div! :590-611, penalty :817-845; the penalty is NOT scaled by 1/J, quirk Q3)

@@ -213,24 +213,6 @@ __device__ unsigned long long g_stamp[16];
 // phase 1 (CNS, meshes without walls): sigma = K(v) grad v -> normal-stress traces B and the volume part of div sigma
 // (rhs_viscous! :749-815 in collocated form, dg_grad! :548-569)
 // ---------------------------------------------------------------------------------------------------------------------
-// wall_stress_jump: the stress jump impose_BCs_stress! (:218-262; modalESDG :205-216) prescribes at a boundary face node,
-// from the own face values of sigma_x (fx), sigma_y (fy) and their normal component sn
-__device__ __forceinline__ void wall_stress_jump(const double* sn, const double* fx, const double* fy, int bc, double vlid, const double* gn,
-                                                 const Phys& ph, double* sj) {
-  sj[0] = 0.0; sj[1] = 0.0; sj[2] = 0.0;
-  if (bc >= 3 || ph.BCTYPE == 2) return;
-  if (ph.BCTYPE == 1) {
-    sj[2] = bc == 2 ? -sn[2] + vlid * sn[0] : -sn[2];
-  } else {
-    const double is = rcp_refined(gn[2]);
-    const double n1 = gn[0] * is, n2 = gn[1] * is;
-    const double snx = fx[0] * n1 + fx[1] * n2, sny = fy[0] * n1 + fy[1] * n2;
-    sj[0] = .5 * ((-2 * fx[0] + 2 * n1 * snx) * gn[0] + (-2 * fy[0] + 2 * n1 * sny) * gn[1]);
-    sj[1] = .5 * ((-2 * fx[1] + 2 * n2 * snx) * gn[0] + (-2 * fy[1] + 2 * n2 * sny) * gn[1]);
-    sj[2] = -sn[2];
-  }
-}
-
 // ---- meshes with walls: gradient and volume divergence of the elements that touch a wall, in the NODAL basis --------------
 // dg_grad! / dg_div! (cavity_optimized.jl:549-611) act on nodal coefficients: Dr, Ds, LIFT, then rows 1:Np of the metric
 // arrays and 1/J[i,e] node by node, then Vq.  Everywhere else the kernel works at the Gauss nodes with one geometry record

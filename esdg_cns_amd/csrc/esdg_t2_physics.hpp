@@ -4,6 +4,7 @@
 #pragma once
 #include "esdg_dev.hpp"
 #include "esdg_devmath.hpp"
+#include "esdg_wall_closures.hpp"
 
 namespace esdg {
 namespace t2 {
@@ -228,32 +229,6 @@ __device__ __forceinline__ void prim_of_v2_fast(const double* V, double* q) {
   q[1] = V[1] * r2;
   q[2] = V[2] * r2;
   q[3] = mv * (1.0 / (2 * GM1));
-}
-
-// Wall closures (meshes with boundary nodes, M.bc != null; bc: 1 wall, 2 lid, 3 Dirichlet inflow, 4 copy).
-// wall_exterior_v: exterior projected entropy variables (v2,v3,v4) at a boundary face node from the own ones
-// (impose_BCs_entropyvars! cavity :178-216; dg2D_CNS_modalESDG.jl:187-203); gn = (nxJ, nyJ, sJ) of the face.
-__device__ __forceinline__ void wall_exterior_v(const double* vf, int bc, double vlid, const double* gn, const Phys& ph, double* vP) {
-  if (bc >= 3) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) vP[c] = bc == 3 ? ph.inflow_vv[c] : vf[c];
-  } else if (ph.BCTYPE == 1) {                            // adiabatic no-slip (vlid: lid velocity at this node)
-    vP[0] = bc == 2 ? -vf[0] - 2 * vlid * vf[2] : -vf[0];
-    vP[1] = -vf[1];
-    vP[2] = vf[2];
-  } else if (ph.BCTYPE == 2) {                            // isothermal
-    const double theta = 1.0 / (0.3 * 0.3) / 1.4 / 0.4;
-    vP[0] = bc == 2 ? 2.0 / theta - vf[0] : -vf[0];
-    vP[1] = -vf[1];
-    vP[2] = -2.0 / theta - vf[2];
-  } else {                                                // slip / reflective
-    const double is = rcp_refined(gn[2]);
-    const double nx = gn[0] * is, ny = gn[1] * is;
-    const double vn = vf[0] * nx + vf[1] * ny;
-    vP[0] = vf[0] - 2 * vn * nx;
-    vP[1] = vf[1] - 2 * vn * ny;
-    vP[2] = vf[2];
-  }
 }
 
 }  // namespace t2

@@ -61,7 +61,7 @@ typedef enum {
  * driver's `ops` tuple.  Column-major.  Pointers not needed by the formulation may be NULL. */
 typedef struct {
   int32_t N;    /* polynomial degree.  Quads: 1..11, periodic meshes and meshes with walls alike; the generic pair-list kernels (operators
-                 * that do not factor into 1D tables; periodic meshes only) 1..7.  esdg_create refuses anything beyond with the reason. */
+                 * that do not factor into 1D tables; same boundary closures) 1..7.  esdg_create refuses anything beyond with the reason. */
   int32_t Np;   /* rows of a state matrix: (N+1)^2 */
   int32_t Nq;   /* volume quadrature nodes: length(rd.wq) */
   int32_t Nfq;  /* face quadrature nodes: length(rd.wf) */

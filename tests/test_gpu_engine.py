@@ -468,21 +468,39 @@ def test_rccl_transport_inside_the_library_loopback(E, form, N, Kx, Kyr):
         assert vt[0] == vt[1] and vt[0] != 0.0
 
 
-def test_generic_fallback_refuses_wall_meshes_explicitly(E):
-    """The generic pair-list kernels (the fallback when the operators do not factor into 1D tables, or ESDG_FORCE_GENERIC=1)
-    implement the periodic path only: a mesh with wall nodes (init_BC_funs, dg2D_CNS_cavity_optimized.jl:135-265) must be
-    refused at esdg_create with ESDG_ERR_STRUCTURE, never run without its closures."""
-    from common import product_cavity_problem
-    from esdg_cns_amd._lib import EsdgError
-    rd, md, ops, Q = product_cavity_problem(3, 4, 4)
+@pytest.mark.parametrize("case", ["cavity BCTYPE=1", "cavity BCTYPE=2", "cavity BCTYPE=3", "shocktube"])
+def test_generic_fallback_serves_wall_meshes(E, case):
+    """The generic pair-list kernels (the fallback when the operators do not factor into 1D tables; forced here with
+    ESDG_FORCE_GENERIC=1 on the A/B build) apply the boundary closures too (round 5): init_BC_funs of
+    dg2D_CNS_cavity_optimized.jl:135-265 (adiabatic no-slip, isothermal, slip; lid on y = +1) and the inflow / copy closures of
+    dg2D_CNS_modalESDG.jl:161-217.  Gate: the oracle's, as for the tensor kernels (they keep one geometry record per element also in
+    the wall elements' viscous operators, which the sum rhsRK! does not see at this size); and the two kernel sets agree to round-off."""
+    from common import TOL, as_oracle_problem, becker_constants, product_cavity_problem, product_shocktube_problem, truth_gate
+    from oracle import oracle as orc
+    if case == "shocktube":
+        st = becker_constants()
+        rd, md, ops, Q = product_shocktube_problem(3, 8, 5)
+        kw = dict(BCTYPE=4, viscous_dissp=False, mu=st["mu"], lam=st["lam"], Pr=st["Pr"], inflow=(st["rhoL"], st["uL"], st["vL"], st["pL"]))
+        po = orc.build_cns_problem(3, 8, 5, bc="shocktube")
+        p = as_oracle_problem(rd, md, ops, Q, Re=po.Re, mu=st["mu"], lam=st["lam"], Pr=st["Pr"], BCTYPE=4, inflow=kw["inflow"])
+        o, q = orc.CnsOracle(p, viscous_dissp=False), orc.CnsOracle(p, quad=True, viscous_dissp=False)
+    else:
+        bct = int(case[-1])
+        rd, md, ops, Q = product_cavity_problem(3, 6, 5)
+        kw = dict(BCTYPE=bct)
+        p = as_oracle_problem(rd, md, ops, Q, Re=1000.0, mu=1e-3, lam=-2e-3 / 3, Pr=.71, BCTYPE=bct)
+        o, q = orc.CnsOracle(p), orc.CnsOracle(p, quad=True)
     os.environ["ESDG_FORCE_GENERIC"] = "1"
     try:
-        with pytest.raises(EsdgError, match="wall boundary conditions need tensor-structured operators"):
-            E.RhsEngine(rd, md, ops, E.CNS_MODAL, BCTYPE=1, ab_hooks=True)
+        gen = E.RhsEngine(rd, md, ops, E.CNS_MODAL, ab_hooks=True, **kw)
     finally:
         del os.environ["ESDG_FORCE_GENERIC"]
-    eng = E.RhsEngine(rd, md, ops, E.CNS_MODAL, BCTYPE=1)        # the tensor kernels take the same mesh
-    assert eng.L.esdg_uses_tensor_kernels(eng.ctx) == 1
+    assert gen.L.esdg_uses_tensor_kernels(gen.ctx) == 0
+    ten = E.RhsEngine(rd, md, ops, E.CNS_MODAL, **kw)
+    assert ten.L.esdg_uses_tensor_kernels(ten.ctx) == 1
+    g, t = _rhs(gen, Q), _rhs(ten, Q)
+    _, e_orc = truth_gate(f"generic kernels, {case} N=3", g, o.rhsRK(Q, False)[0], q.rhsRK(Q, False)[0])
+    assert rel_l2(g, t) <= max(1e-11, 3 * e_orc)     # (two Float64 evaluations of the same statements)
 
 
 @pytest.mark.parametrize("form", ["cns", "euler"])
