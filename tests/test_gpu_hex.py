@@ -279,6 +279,24 @@ def test_cfg5_rank0_slab_of_the_8_rank_box_over_the_library_rccl_transport(eng_m
         one.rhs_lsrk_fused(q2, r2, -0.4 * k, 0.3, 1e-3)
     torch.cuda.synchronize()
     assert torch.equal(q1, q2)
+    # one DOPRI45 attempt (round 5: the stage combinations and the error norm in kh_rhs_l's node rounds) through the sharded
+    # schedule -- the last phase in up to three launches, each with its own run of partials, the norm reduced over the
+    # communicator -- against the stand-alone slab: same state bits, the estimate to summation order
+    import ctypes as C
+    from esdg_cns_amd.engine import check
+    outs = []
+    for eng in (sh, one):
+        k = [torch.zeros_like(Qd) for _ in range(7)]
+        eng.rhs_into(Qd, k[0])
+        Qtmp = torch.empty_like(Qd)
+        ptrs = (C.c_void_p * 7)(*[t.data_ptr() for t in k])
+        err = C.c_double(0.0)
+        check(eng.L.esdg_dopri45_attempt(eng.ctx, C.c_void_p(Qd.data_ptr()), C.c_void_p(Qtmp.data_ptr()), ptrs, 2e-3, 1e-5, C.byref(err),
+                                         eng._stream()))
+        torch.cuda.synchronize()
+        outs.append((Qtmp, [t.clone() for t in k], err.value))
+    assert torch.equal(outs[0][0], outs[1][0]) and all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+    assert outs[0][2] > 0 and abs(outs[0][2] - outs[1][2]) <= 1e-12 * outs[1][2]
 
 
 @pytest.mark.parametrize("K", [16])
