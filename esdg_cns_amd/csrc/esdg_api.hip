@@ -2121,7 +2121,7 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
   // (wall meshes whose last phase is kt2_rhs -- CNS at N = 5 ... 8, the inviscid formulations at N = 7, 8 -- take the unfused attempt)
   const bool fuse2 = ctx->dopri_fusion && ctx->dim == 2 && ctx->use_fast && (ctx->nphases == 3 || ctx->nphases == 2) &&
                      !ctx->bf && !(ctx->ph.dbg & ~32) && !(ctx->v2 & 2) && ctx->T.N1 >= 2 && ctx->T.N1 <= ESDG_MAX_N1 &&
-                     (!ctx->M.bc || ctx->T.N1 < (ctx->ph.formulation == 1 ? 6 : 8) || ctx->T.N1 == 10);
+                     (!ctx->M.bc || ctx->T.N1 < (ctx->ph.formulation == 1 ? 6 : 8) || ctx->T.N1 >= 10);
   const bool fuse3 = ctx->dopri_fusion && ctx->dim == 3 && !ctx->bf && rhs_hex_blocks(ctx->T.N1, ctx->K) > 0;   // (kh_rhs_l)
   const bool fuse = fuse2 || fuse3;
   if (fuse) {
