@@ -1,7 +1,7 @@
 """rhs_viscous! ALONE (esdg_set_parts(2)) on the lid-driven cavity: where does the GPU's error against the binary128 truth sit?
 Per field: relative L2 errors of the GPU and of the Float64 oracle, the share of the squared GPU error carried by elements that
 touch a wall / the lid / a corner, and the worst elements.  Kernel sets: v2 (default: nodal-basis viscous operators in the elements with a boundary node), v2 with one geometry record
-per element everywhere (ESDG_WALL_GEOMETRY=element), round-1 (ESDG_V1=walls).
+per element everywhere (ESDG_WALL_GEOMETRY=element).  (The round-1 kernels it also probed until round 4 are gone.)
   python tools/cavity_visc_probe.py [N Kx Ky [BCTYPE [nopen] [vlid0]]]     nopen: viscous_dissp = false; vlid0: lid velocity 0"""
 import os
 os.environ.setdefault("ESDG_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "esdg_cns_amd", "libesdg_hip_ab.so"))   # the A/B build reads the ESDG_* switches; the shipped library reads none

@@ -1,6 +1,6 @@
 """How e_gpu and e_orc (against the binary128 truth) grow with refinement, and where the GPU's excess lives.
 Round 3: at Euler N=4 256x256 the GPU was 4.5 x e_orc (64x64: 1.39, 12x8: 1.00).  For K = 32 ... 256 (vortex state):
-e_gpu / e_orc for the production kernels, the round-1 tensor kernels (ESDG_V1=1) and the generic pair-list kernels
+e_gpu / e_orc for the production kernels and the generic pair-list kernels (the round-1 tensor kernels it also ran are gone)
 (ESDG_FORCE_GENERIC=1); the split of both errors into the vortex core (r < 3) and the far field; the free-stream residual
 of GPU and oracle.    python tools/parity_scaling.py [cns] [Kmax]"""
 import os
