@@ -1,6 +1,6 @@
-"""Soak of the fused DOPRI45 attempt at cfg3's size: `n` attempts of the fused path and of the building blocks in lockstep (same step
+"""Soak of the fused DOPRI45 attempt at cfg3's size (or: euler = cfg2's size, hex = a 64 x 64 x 16 slab): `n` attempts of the fused path and of the building blocks in lockstep (same step
 sizes), states compared bit for bit every 50 attempts -- a race in the in-place stage update would show as a difference.
-    python tools/dopri_soak.py [n]"""
+    python tools/dopri_soak.py [n [cns|euler|hex]]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,10 +9,21 @@ import bench
 from esdg_cns_amd import engine as E, timestep as TS
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-rd, md, ops, Q = bench.build_problem(4, 512, 512, 0, 512 * 512, "cns")
-eng = E.RhsEngine(rd, md, ops, E.CNS_MODAL)
-a = TS.Dopri45(eng, eng.upload(bench.rough_state(Q)), 2e-4, err_tol=1e-5, swap=True)
-b = TS.Dopri45(eng, eng.upload(bench.rough_state(Q)), 2e-4, err_tol=1e-5, pieces=True, swap=True)
+form = sys.argv[2] if len(sys.argv) > 2 else "cns"      # cns | euler (cfg2's size) | hex (64 x 64 x 16 elements, N = 3)
+if form == "hex":
+    rd, md, ops, Q = bench.build_hex_problem(3, 64, 64, 16, 0, 64 * 64 * 16)
+    eng = E.RhsEngine(rd, md, ops, E.EULER_HEX_COLLOCATED, lf_scale=0.0)   # (the reference's 0*.25; a non-zero factor is anti-dissipative on its J < 0 meshes and blows up by t = 0.02: docs/history.md section 9)
+    Q0, dt0 = Q, 2e-4
+elif form == "euler":
+    rd, md, ops, Q = bench.build_problem(4, 256, 256, 0, 256 * 256, "euler")
+    eng = E.RhsEngine(rd, md, ops, E.EULER_COLLOCATED)
+    Q0, dt0 = bench.rough_state(Q), 2e-4
+else:
+    rd, md, ops, Q = bench.build_problem(4, 512, 512, 0, 512 * 512, "cns")
+    eng = E.RhsEngine(rd, md, ops, E.CNS_MODAL)
+    Q0, dt0 = bench.rough_state(Q), 2e-4
+a = TS.Dopri45(eng, eng.upload(Q0), dt0, err_tol=1e-5, swap=True)
+b = TS.Dopri45(eng, eng.upload(Q0), dt0, err_tol=1e-5, pieces=True, swap=True)
 acc = 0
 for i in range(1, n + 1):
     dt, prev = a.dt, a.prev_err
