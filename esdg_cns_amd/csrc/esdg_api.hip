@@ -1139,7 +1139,7 @@ int esdg_create_hex(const esdg_hex_ops_t* ops, const esdg_hex_mesh_t* mesh, cons
   *out = nullptr;
   ab_apply_tuning();
   const int N1 = ops->N + 1, NN = N1 * N1, Nq = ops->Nq, Nfq = ops->Nfq, Nh = Nq + Nfq;
-  if (!hex_supported_degree(N1)) return fail(ESDG_ERR_ARG, "unsupported hex degree N=%d (need 1..9)", ops->N);
+  if (!hex_supported_degree(N1)) return fail(ESDG_ERR_ARG, "unsupported hex degree N=%d (need 1..10)", ops->N);
   if (Nq != NN * N1 || Nfq != 6 * NN)
     return fail(ESDG_ERR_STRUCTURE, "need tensor hex sizes Nq=(N+1)^3, Nfq=6(N+1)^2; got Nq=%d Nfq=%d", Nq, Nfq);
   if (phys->formulation != ESDG_EULER_HEX_COLLOCATED) return fail(ESDG_ERR_ARG, "esdg_create_hex needs formulation ESDG_EULER_HEX_COLLOCATED");

@@ -1374,7 +1374,7 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
 }  // namespace hdev
 
 // N1 = 2 ... 4: one wavefront per element (kh_project / kh_rhs); N1 = 5 ... 8: one workgroup per element (kh_*_g)
-bool hex_supported_degree(int N1) { return N1 >= 2 && N1 <= 10; }
+bool hex_supported_degree(int N1) { return N1 >= 2 && N1 <= 11; }
 
 #define ESDG_HEX_DISPATCH(N1v, STMT)   \
   switch (N1v) {                        \
@@ -1401,6 +1401,7 @@ bool hex_supported_degree(int N1) { return N1 >= 2 && N1 <= 10; }
     case 8: { constexpr int N1 = 8; STMT; } break; \
     case 9: { constexpr int N1 = 9; STMT; } break; \
     case 10: { constexpr int N1 = 10; STMT; } break; \
+    case 11: { constexpr int N1 = 11; STMT; } break; \
     default: return (int)hipErrorInvalidValue;     \
   }
 
@@ -1430,7 +1431,7 @@ int rhs_hex_blocks(int N1v, int64_t e_count) {
   if (g_hex_line == 0) return -1;
   switch (N1v) {
 #define ESDG_HEXL_BLOCKS(N1c) case N1c: return (int)((e_count + hdev::LCfg<N1c>::E - 1) / hdev::LCfg<N1c>::E);
-    ESDG_HEXL_BLOCKS(2) ESDG_HEXL_BLOCKS(3) ESDG_HEXL_BLOCKS(4) ESDG_HEXL_BLOCKS(5) ESDG_HEXL_BLOCKS(6) ESDG_HEXL_BLOCKS(7) ESDG_HEXL_BLOCKS(8) ESDG_HEXL_BLOCKS(9) ESDG_HEXL_BLOCKS(10)
+    ESDG_HEXL_BLOCKS(2) ESDG_HEXL_BLOCKS(3) ESDG_HEXL_BLOCKS(4) ESDG_HEXL_BLOCKS(5) ESDG_HEXL_BLOCKS(6) ESDG_HEXL_BLOCKS(7) ESDG_HEXL_BLOCKS(8) ESDG_HEXL_BLOCKS(9) ESDG_HEXL_BLOCKS(10) ESDG_HEXL_BLOCKS(11)
 #undef ESDG_HEXL_BLOCKS
     default: return -1;
   }
@@ -1459,7 +1460,7 @@ int launch_rhs_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phys& p
     else hipLaunchKernelGGL((hdev::kh_rhs_l<N1c, 0>), grid, blk, 0, s, HT, M, ph, Q, A_U, rhs, lf, sf0);                      \
   } break;
       switch (N1v) {
-        ESDG_HEXL_LAUNCH(2) ESDG_HEXL_LAUNCH(3) ESDG_HEXL_LAUNCH(4) ESDG_HEXL_LAUNCH(5) ESDG_HEXL_LAUNCH(6) ESDG_HEXL_LAUNCH(7) ESDG_HEXL_LAUNCH(8) ESDG_HEXL_LAUNCH(9) ESDG_HEXL_LAUNCH(10)
+        ESDG_HEXL_LAUNCH(2) ESDG_HEXL_LAUNCH(3) ESDG_HEXL_LAUNCH(4) ESDG_HEXL_LAUNCH(5) ESDG_HEXL_LAUNCH(6) ESDG_HEXL_LAUNCH(7) ESDG_HEXL_LAUNCH(8) ESDG_HEXL_LAUNCH(9) ESDG_HEXL_LAUNCH(10) ESDG_HEXL_LAUNCH(11)
         default: return (int)hipErrorInvalidValue;
       }
 #undef ESDG_HEXL_LAUNCH

@@ -128,7 +128,7 @@ typedef struct {
 /* Hexahedral path: operators of examples/dg3D_euler_hex.jl:34-98 (quadrature basis) and the 3D MeshData
  * fields the driver holds when it calls `rhs` (:167).  Same conventions as above. */
 typedef struct {
-  int32_t N;    /* polynomial degree: hexahedra 1..9 (one element per workgroup from N = 7 on; affine and curved meshes) */
+  int32_t N;    /* polynomial degree: hexahedra 1..10 (one element per workgroup from N = 7 on; affine and curved meshes) */
   int32_t Nq;   /* (N+1)^3 */
   int32_t Nfq;  /* 6 (N+1)^2 */
   const double *Qrhskew, *Qshskew, *Qthskew; /* (Nh x Nh), dg3D_euler_hex.jl:49-51 */

@@ -300,7 +300,7 @@ def test_two_gloo_ranks_sharing_the_gpu_match_the_single_engine(formulation):
 
 @pytest.mark.parametrize("case", ["cns N=4 13x9", "cns N=2 10x7", "cns N=6 5x4", "cns N=7 4x3", "cavity N=4 9x8 BCTYPE=1", "cavity N=3 8x7 BCTYPE=2",
                                   "cavity N=1 7x6 BCTYPE=1", "cns N=4 256x256", "cns N=9 3x2", "euler N=4 12x9", "euler N=3 16x16", "euler N=7 4x3",
-                                  "inviscid N=4 9x8", "cavity N=9 3x2 BCTYPE=1", "cavity N=10 2x2 BCTYPE=3", "cavity N=6 4x3 BCTYPE=1", "hex N=3 5x4x3", "hex N=1 6x5x4", "hex N=4 3x2x2", "hex N=7 2x2x1", "hexcurved N=2 4x3x3"])
+                                  "inviscid N=4 9x8", "cavity N=9 3x2 BCTYPE=1", "cavity N=10 2x2 BCTYPE=3", "cavity N=6 4x3 BCTYPE=1", "hex N=3 5x4x3", "hex N=1 6x5x4", "hex N=4 3x2x2", "hex N=7 2x2x1", "hex N=10 2x2x1", "hexcurved N=2 4x3x3"])
 def test_fused_dopri45_attempt_is_bitwise_the_attempt_from_building_blocks(case):
     """esdg_dopri45_attempt on an unsharded 2D context (CNS; round 5: collocated Euler and the inviscid modal formulation too): the last phase of every stage also forms the next stage's state from the
     k_s it holds in registers, stage 6 leaves the error combination so far in k[6]'s array and stage 7 reduces the norm

@@ -23,7 +23,7 @@ def _gpu_rhs(eng, Q):
 
 # (N >= 4: more than one wavefront of Gauss nodes per element -> the degree-generic kernels kh_project_g / kh_rhs_g)
 @pytest.mark.parametrize("N,K3", [(3, (4, 4, 4)), (3, (5, 3, 2)), (2, (3, 4, 5)), (1, (4, 3, 3)), (4, (3, 2, 2)), (5, (2, 2, 3)), (6, (2, 2, 2)), (7, (2, 2, 2)),
-                                  (8, (2, 2, 2)), (9, (2, 2, 2))])   # (N = 8, 9: round 5, kh_project_g + kh_rhs_l; one element per workgroup)
+                                  (8, (2, 2, 2)), (9, (2, 2, 2)), (10, (2, 2, 1))])   # (N = 8 ... 10: round 5, kh_project_g + kh_rhs_l; one element per workgroup)
 @pytest.mark.parametrize("lf", [0.0, 0.25])
 def test_hex_matches_oracle(eng_mod, oracle_lib, N, K3, lf):
     from oracle import oracle as orc
@@ -165,7 +165,7 @@ def test_hex_sheared_parallelepiped_mesh_matches_oracle(eng_mod, oracle_lib):
     assert min(np.abs(getattr(po.md, n)).min() for n in ("sxJ", "txJ", "ryJ", "tyJ", "rzJ", "szJ")) > 1e-4
     rd, md, ops, Q = product_hex_problem(N, *K3, A3=A3)
     for n in ("rxJ", "tyJ", "szJ", "J", "nxJ", "nzJ", "sJ"):
-        assert np.abs(getattr(md, n) - getattr(po.md, n)).max() < 1e-12, n
+        assert np.abs(getattr(md, n) - getattr(po.md, n)).max() < (1e-12 if N <= 8 else 1e-11), n   # (two set-ups; conditioning grows with N)
     p = as_oracle_problem(rd, md, ops, Q)
     for lf in (0.0, 0.25):
         ho, hq = orc.HexOracle(p, lf), orc.HexOracle(p, lf, quad=True)
@@ -190,7 +190,7 @@ def test_hex_graded_mesh_every_element_its_own_geometry(eng_mod, oracle_lib):
         truth_gate(f"graded hex mesh lf={lf}", _gpu_rhs(eng, Q), ho.rhs(Q)[0], hq.rhs(Q)[0])
 
 
-@pytest.mark.parametrize("N,K3", [(3, (4, 4, 4)), (2, (3, 3, 4)), (4, (2, 2, 3)), (5, (2, 2, 2))])   # N >= 4: kh_rhs_g<N1, 1>
+@pytest.mark.parametrize("N,K3", [(3, (4, 4, 4)), (2, (3, 3, 4)), (4, (2, 2, 3)), (5, (2, 2, 2)), (8, (2, 2, 1)), (10, (2, 1, 1))])   # (kh_rhs_l<N1, 1>; N = 10: 40 spilled registers, one wave per SIMD)
 def test_hex_curved_mesh_matches_oracle(eng_mod, oracle_lib, N, K3):
     """The script's curved mapping x,y,z += a (x^2-1)(y^2-1)(z^2-1) (dg3D_euler_hex.jl:67-73; a = 0 in the script
     itself): per-node metric terms at the hybrid nodes, per-pair metric averages (:145-151), per-node normals and J.
@@ -201,7 +201,7 @@ def test_hex_curved_mesh_matches_oracle(eng_mod, oracle_lib, N, K3):
     assert np.abs(po.md.rxJ - po.md.rxJ[0]).max() > 1e-3                      # really non-affine
     rd, md, ops, Q = product_hex_problem(N, *K3, a=a)
     for n in ("rxJ", "tyJ", "szJ", "J", "nxJ", "nzJ", "sJ"):
-        assert np.abs(getattr(md, n) - getattr(po.md, n)).max() < 1e-12, n
+        assert np.abs(getattr(md, n) - getattr(po.md, n)).max() < (1e-12 if N <= 8 else 1e-11), n   # (two set-ups; conditioning grows with N)
     p = as_oracle_problem(rd, md, ops, Q)
     for lf in (0.0, 0.25):
         ho, hq = orc.HexOracle(p, lf), orc.HexOracle(p, lf, quad=True)
