@@ -612,10 +612,9 @@ struct esdg_ctx {
   size_t ws_bytes = 0;
   char* ws = nullptr;
   size_t off_AU = 0, off_Av = 0, off_B = 0, off_S = 0;
-  int64_t stage_cursor = 0;                // partials handed out so far in the current stage
   const StageFuse* stage_fuse = nullptr;   // set by esdg_dopri45_attempt around a last-phase launch (kt3_rhs's STG instantiation)
   bool dopri_fusion = true;    // ESDG_DOPRI_FUSION=0 at esdg_create: the unfused attempt (A/B partner, and the bitwise test's)
-  DevBuf d_stage_partial;      // one double per kt3_rhs workgroup (error norm of the fused attempt), allocated at the first attempt
+  DevBuf d_stage_partial;      // the error norm's terms of the fused attempt, one per state entry, + the chunk sums; allocated at the first attempt
   int64_t int_lo = 0, int_hi = 0;   // longest run of elements [int_lo, int_hi) that touch no ghost slot
   // nested interiors: nest_lo/hi[0] = [int_lo, int_hi); nest[p] = the longest run inside nest[p-1] all of whose face
   // neighbours lie in nest[p-1] -- what phase p can compute from data the same stream produced in phase p-1
@@ -1388,14 +1387,7 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
       rc = launch_project_hex(ctx->T.N1, ctx->HT, ctx->M, ctx->ph, Q, A_U, s);
     } else {
       if (!rhs && !lf.Qw) return fail(ESDG_ERR_ARG, "rhs output is null");
-      StageFuse sfl;
-      const StageFuse* sfp = ctx->stage_fuse;
-      if (sfp && sfp->err) {   // (as for kt3_rhs below: every launch of the stage gets its own run of partials)
-        sfl = *sfp;
-        sfl.partial += ctx->stage_cursor;
-        ctx->stage_cursor += rhs_hex_blocks(ctx->T.N1, ranged ? e_count : ctx->K);
-        sfp = &sfl;
-      }
+      const StageFuse* sfp = ctx->stage_fuse;   // (the norm's terms land at their entries' own indices: nothing per launch)
       rc = launch_rhs_hex(ctx->T.N1, ctx->HT, ctx->M, ctx->ph, Q, A_U, rhs, lf, s, sfp);
       if (rc == -1) return fail(ESDG_ERR_STATE, "DOPRI45 stage fusion asked of a hexahedral context whose last phase is not kh_rhs_l");
     }
@@ -1417,15 +1409,8 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
     // (ESDG_DBG bit 32: kt3_rhs takes every logarithm whatever the state -- the partner of the bitwise test of its data-dependent
     // short cut, tests/test_gpu_engine.py)
     if (ctx->use_fast && !(ctx->v2 & 2)) {
-      StageFuse sfl;
-      const StageFuse* sfp = ctx->stage_fuse;
-      if (sfp && sfp->err) {   // every launch of the stage (the pieces of a sharded schedule) gets its own run of partials
-        sfl = *sfp;
-        sfl.partial += ctx->stage_cursor;
-        ctx->stage_cursor += rhs_tensor3_blocks(ctx->T.N1, ranged ? e_count : ctx->K);
-        sfp = &sfl;
-      }
-      rc = launch_rhs_tensor3(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s, sfp);
+      const StageFuse* sfp = ctx->stage_fuse;   // (the norm's terms land at their entries' own indices, whatever pieces a sharded
+      rc = launch_rhs_tensor3(ctx->T.N1, ctx->TT, ctx->M, ctx->ph, Q, A_U, SG, B, rhs, lf, s, sfp);   // schedule cuts the phase into)
       if (rc == -1 && ctx->stage_fuse) return fail(ESDG_ERR_STATE, "DOPRI45 stage fusion asked of a context the v3 last-phase kernel does not serve");
     }
     if (rc == -1 && ctx->stage_fuse) return fail(ESDG_ERR_STATE, "DOPRI45 stage fusion asked of a context the v3 last-phase kernel does not serve");
@@ -2042,17 +2027,18 @@ int esdg_dopri_error(const double* Q, const double* const* k, const double* coef
                      double* result, void* stream) {
   if (!Q || !k || !coefE || !result || ns < 1 || ns > 8) return fail(ESDG_ERR_ARG, "bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int nb = 4096;   // (512 until late in round 4: two workgroups per CU left the eight input streams at 2.2 TB/s -- 0.77 ms at cfg3)
-  double* partial = nullptr;
-  HIP_TRY(hipMalloc(&partial, sizeof(double) * nb));
-  int rc = launch_dopri_err(Q, k, coefE, ns, tol, n, partial, nb, s);
-  std::vector<double> h(nb);
-  hipError_t e = hipMemcpyAsync(h.data(), partial, sizeof(double) * nb, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(partial);
-  if (rc || e != hipSuccess) return fail(ESDG_ERR_NO_DEVICE, "dopri error kernel failed");
+  // (one workgroup per run of ESDG_ERR_CHUNK entries -- 1600 at cfg3 -- then the runs' sums in k_sum's order: the fused attempt adds
+  // the same terms in the same order, esdg_kernels.hip)
+  const int64_t nc = err_chunks(n);
+  double* chunk = nullptr;
+  HIP_TRY(hipMalloc(&chunk, sizeof(double) * (size_t)(nc + 1)));
+  int rc = launch_dopri_err(Q, k, coefE, ns, tol, n, chunk, s);
+  if (!rc) rc = launch_sum(chunk, nc, chunk + nc, s);
   double t = 0.0;
-  for (double v : h) t += v;
+  hipError_t e = hipMemcpyAsync(&t, chunk + nc, sizeof(double), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(chunk);
+  if (rc || e != hipSuccess) return fail(ESDG_ERR_NO_DEVICE, "dopri error kernel failed");
   *result = t;
   return ESDG_OK;
 }
@@ -2114,8 +2100,8 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
   // Fused attempt (round 4: CNS; round 5: every 2D context whose last phase is kt3_rhs, sharded ones included; ESDG_DOPRI_FUSION=0: off): the last phase of stage
   // s holds k_s in registers and also writes the NEXT stage's state Q + dt sum_j a_{s+1,j} k_j, so the separate combination pass
   // (read Q, k_0 ... k_s, write Qtmp) shrinks to the reads of Q, k_0 ... k_{s-1} inside the launch; stage 6 (the b row) also leaves
-  // the error combination of k_0 ... k_5 in k[6]'s array, which stage 7's launch reads back, completes with k_6 and reduces to
-  // one partial per workgroup.  Stages with a zero coefficient in both rows are not read.  Per node the same fma chains as the
+  // the error combination of k_0 ... k_5 in k[6]'s array, which stage 7's launch reads back, completes with k_6 and turns into
+  // the norm's term of every entry (added below in k_dopri_err's order: the estimate's bits are those of the unfused attempt).  Stages with a zero coefficient in both rows are not read.  Per node the same fma chains as the
   // unfused attempt (same bits: tests/test_gpu_drivers.py); 30 instead of 43 state-sized sweeps per attempt on top of six
   // right-hand sides.
   // (wall meshes whose last phase is kt2_rhs -- CNS at N = 5 ... 8, the inviscid formulations at N = 7, 8 -- take the unfused attempt)
@@ -2125,9 +2111,9 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
   const bool fuse3 = ctx->dopri_fusion && ctx->dim == 3 && !ctx->bf && rhs_hex_blocks(ctx->T.N1, ctx->K) > 0;   // (kh_rhs_l)
   const bool fuse = fuse2 || fuse3;
   if (fuse) {
-    if (!ctx->d_stage_partial.p) {   // (a sharded schedule launches the last phase in up to three pieces, each rounding up)
-      const int nblk = fuse3 ? rhs_hex_blocks(ctx->T.N1, ctx->K) : rhs_tensor3_blocks(ctx->T.N1, ctx->K);
-      int rc = ctx->d_stage_partial.alloc(sizeof(double) * (size_t)(nblk + 9));
+    const int64_t nc = err_chunks(n);
+    if (!ctx->d_stage_partial.p) {   // n terms, nc chunk sums, the total
+      int rc = ctx->d_stage_partial.alloc(sizeof(double) * (size_t)(n + nc + 1));
       if (rc) return rc;
     }
     const LsrkFuse none{nullptr, nullptr, 0.0, 0.0, 0.0};
@@ -2148,15 +2134,16 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
         sf.err = 1; sf.ce_last = E[6]; sf.tol = err_tol; sf.partial = static_cast<double*>(ctx->d_stage_partial.p);
       }
       ctx->stage_fuse = &sf;     // (read by the last-phase launches only)
-      ctx->stage_cursor = 0;
       if (ctx->nghost) rc = rhs_sharded_impl(ctx, Qtmp, k[s], none, stream);
       else
         for (int p = 0; p < ctx->nphases && !rc; ++p) rc = esdg_rhs_phase(ctx, p, Qtmp, k[s], stream);
       ctx->stage_fuse = nullptr;
     }
     if (rc) return rc;
-    double acc = 0.0;
-    rc = esdg_sum_device(static_cast<double*>(ctx->d_stage_partial.p), ctx->stage_cursor, &acc, stream);
+    double acc = 0.0;   // the terms in k_dopri_err's order (runs of ESDG_ERR_CHUNK entries, then the runs): the unfused attempt's bits
+    double* terms = static_cast<double*>(ctx->d_stage_partial.p);
+    if (launch_chunk_sum(terms, n, terms + n, static_cast<hipStream_t>(stream))) return fail(ESDG_ERR_NO_DEVICE, "chunk sum launch failed");
+    rc = esdg_sum_device(terms + n, nc, &acc, stream);
     if (rc) return rc;
     double tot[2] = {acc, (double)n};
     if (ctx->nghost && (rc = esdg_comm_allreduce(ctx, tot, 2, 0, stream)) != 0) return rc;   // every rank gets the same estimate

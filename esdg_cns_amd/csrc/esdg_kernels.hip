@@ -685,17 +685,51 @@ __device__ __forceinline__ double block_sum(double v) {
   return s;
 }
 
-__global__ __launch_bounds__(ESDG_TPB) void k_dopri_err(const double* __restrict__ Q, StagePtrs sp, int ns, double tol,
-                                                        int64_t n, double* __restrict__ partial) {
-  double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double e = 0.0;
-    for (int s = 0; s < ns; ++s) e = __builtin_fma(sp.c[s], sp.k[s][i], e);
-    const double sc = fabs(e) / (tol * (1 + fabs(Q[i])));
-    acc += sc * sc;
+// The Hairer norm's numerator in ONE summation order, whoever forms the terms (round 5; the order used to follow the launch that
+// produced the partials).  The n entries i of the field-major state carry t_i = (|e_i| / (tol (1 + |x_i|)))^2; consecutive runs
+// of ESDG_ERR_CHUNK entries are summed by one workgroup -- thread t adds entries t, t + 256, ... of its run in that order, then
+// the 256 thread sums meet in a fixed tree -- and k_sum adds the runs' sums in its own fixed order.  The order is a function of n
+// alone: the fused attempt (kt3_rhs / kh_rhs_l store t_i, k_chunk_sum adds them), the attempt from the building blocks
+// (k_dopri_err forms t_i and adds them in flight) and a sharded context's pieces give the same bits.
+__device__ __forceinline__ double chunk_tree(double a) {
+  __shared__ double red[ESDG_TPB];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int w = ESDG_TPB / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
   }
-  const double s = block_sum(acc);
-  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  return red[0];
+}
+
+__global__ __launch_bounds__(ESDG_TPB) void k_dopri_err(const double* __restrict__ Q, StagePtrs sp, int ns, double tol,
+                                                        int64_t n, double* __restrict__ chunk) {
+  double acc = 0.0;
+  const int64_t base = (int64_t)blockIdx.x * ESDG_ERR_CHUNK;
+  for (int j = 0; j < ESDG_ERR_CHUNK / ESDG_TPB; ++j) {
+    const int64_t i = base + (int64_t)j * ESDG_TPB + threadIdx.x;
+    if (i < n) {
+      double e = 0.0;
+      for (int s = 0; s < ns; ++s) e = __builtin_fma(sp.c[s], sp.k[s][i], e);
+      const double sc = fabs(e) / (tol * (1 + fabs(Q[i])));
+      double t = sc * sc;
+      asm volatile("" : "+v"(t));   // (a rounded product, as the fused kernels store it: no fma with the running sum)
+      acc += t;
+    }
+  }
+  const double s = chunk_tree(acc);
+  if (threadIdx.x == 0) chunk[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(ESDG_TPB) void k_chunk_sum(const double* __restrict__ x, int64_t n, double* __restrict__ chunk) {
+  double acc = 0.0;
+  const int64_t base = (int64_t)blockIdx.x * ESDG_ERR_CHUNK;
+  for (int j = 0; j < ESDG_ERR_CHUNK / ESDG_TPB; ++j) {
+    const int64_t i = base + (int64_t)j * ESDG_TPB + threadIdx.x;
+    if (i < n) acc += x[i];
+  }
+  const double s = chunk_tree(acc);
+  if (threadIdx.x == 0) chunk[blockIdx.x] = s;
 }
 
 // rhstest = sum(wJq .* v(Uq) .* (Vq*rhs))  (euler_quad.jl:186-191; cavity_optimized.jl:958-966 with
@@ -903,11 +937,16 @@ int launch_sum(const double* x, int64_t n, double* out, hipStream_t s) {
 }
 
 int launch_dopri_err(const double* Q, const double* const* k, const double* coefE, int ns, double tol, int64_t n,
-                     double* partial, int nblocks, hipStream_t s) {
+                     double* chunk, hipStream_t s) {
   if (ns > 8) return (int)hipErrorInvalidValue;
   StagePtrs sp;
   for (int i = 0; i < ns; ++i) { sp.k[i] = k[i]; sp.c[i] = coefE[i]; }
-  hipLaunchKernelGGL(k_dopri_err, dim3(nblocks), dim3(ESDG_TPB), 0, s, Q, sp, ns, tol, n, partial);
+  hipLaunchKernelGGL(k_dopri_err, dim3((unsigned)err_chunks(n)), dim3(ESDG_TPB), 0, s, Q, sp, ns, tol, n, chunk);
+  return (int)hipGetLastError();
+}
+
+int launch_chunk_sum(const double* x, int64_t n, double* chunk, hipStream_t s) {
+  hipLaunchKernelGGL(k_chunk_sum, dim3((unsigned)err_chunks(n)), dim3(ESDG_TPB), 0, s, x, n, chunk);
   return (int)hipGetLastError();
 }
 

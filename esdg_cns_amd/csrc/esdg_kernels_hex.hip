@@ -1292,7 +1292,6 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
   }
   // ---- node rounds: -(.)/J, store or fused low-storage RK stage (:198-212) ------------------------------------------------
   asm volatile("" ::: "memory");   // (no load of the state sinks below this point: the fused updates may overwrite it in place)
-  double stg_acc = 0.0;            // STG: this lane's part of the error norm
 #pragma unroll
   for (int r = 0; r < NRN; ++r) {
     const int n = tid + r * T;
@@ -1335,7 +1334,7 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
             rhs[c * KN + i0] = out[c];
             const double e = __builtin_fma(sf.ce_last, out[c], ei[c]);
             const double sc = fabs(e) / (sf.tol * (1 + fabs(xo[c])));
-            stg_acc += sc * sc;
+            sf.partial[c * KN + i0] = sc * sc;   // every entry's term at its own index: the host adds them in ONE order (k_chunk_sum)
           }
         }
         continue;
@@ -1355,18 +1354,6 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
 #pragma unroll
         for (int c = 0; c < HEX_NFLD; ++c) rhs[(int64_t)c * KN + e0 * Nq + n] = sR[c * NV + sl] * miJ;
       }
-    }
-  }
-  if (STG && sf.err) {   // (uniform) one partial per workgroup: lanes of a wave, then the workgroup's waves in order
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) stg_acc += __shfl_xor(stg_acc, off, 64);
-    __syncthreads();     // (the tables' space: every lane left the line stage several barriers ago)
-    if ((tid & 63) == 0) sTab[tid >> 6] = stg_acc;
-    __syncthreads();
-    if (tid == 0) {
-      double t = 0.0;
-      for (int w = 0; w < T / 64; ++w) t += sTab[w];
-      sf.partial[blockIdx.x] = t;
     }
   }
 }
@@ -1426,7 +1413,7 @@ int launch_project_hex(int N1v, const HexTables& HT, const MeshDev& M, const Phy
 static int g_hex_line = 1;   // kh_rhs_l; 0 = kh_rhs / kh_rhs_g (A/B builds: esdg_api.hip under -DESDG_AB_HOOKS, ESDG_HEX_LINE=0)
 void ab_tuning_hex(int line) { g_hex_line = line; }
 
-// workgroups of a last-phase launch over e_count elements (StageFuse::partial has one entry each); -1: the line kernel is off
+// workgroups of a last-phase launch over e_count elements; -1: the line kernel is off
 int rhs_hex_blocks(int N1v, int64_t e_count) {
   if (g_hex_line == 0) return -1;
   switch (N1v) {

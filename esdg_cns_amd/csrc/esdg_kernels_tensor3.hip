@@ -601,7 +601,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
     for (int r = 0; r < NR; ++r) T3_PIN4(out[r]);
   }
   // ---- store, or fused low-storage RK stage (dg2D_euler_quad.jl:204-205) -------------------------------------------------------
-  double stg_acc = 0.0;          // STG: this lane's part of the error norm
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const unsigned n = tid + r * TW;
@@ -636,11 +635,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
 #pragma unroll
           for (int f = 0; f < 4; ++f) { xo[f] = sf.x0[f * KN + i0]; ei[f] = sf.err ? rhs[f * KN + i0] : 0.0; }
 #pragma unroll
-          for (int f = 0; f < 4; ++f) {
-            rhs[f * KN + i0] = out[r][f];
+          for (int f = 0; f < 4; ++f) {   // the norm's term of every entry at the entry's own index: the host adds them in ONE order
+            rhs[f * KN + i0] = out[r][f];   // (k_chunk_sum), whatever launches the phase was cut into
             const double e = __builtin_fma(sf.ce_last, out[r][f], ei[f]);
             const double sc = fabs(e) / (sf.tol * (1 + fabs(xo[f])));
-            stg_acc += sc * sc;
+            sf.partial[f * KN + i0] = sc * sc;
           }
         }
       }
@@ -663,11 +662,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
         for (int f = 0; f < 4; ++f) rhs[f * KN + e0 * Nq + n] = out[r][f];
       }
     }
-  }
-  if (STG && sf.err) {   // (uniform) one partial per workgroup = per wave
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) stg_acc += __shfl_xor(stg_acc, off, 64);
-    if (tid == 0) sf.partial[blockIdx.x] = stg_acc;
   }
 }
 

@@ -359,12 +359,14 @@ int esdg_dopri_error(const double* Q_dev, const double* const* k_dev, const doub
  * On contexts whose last phase is the line-per-lane kernel -- every 2D formulation on the tensor kernels (CNS wall meshes up to
  * N = 4, inviscid ones up to N = 6) and hexahedra; unsharded, or sharded with a communicator attached -- the stage combinations
  * and the error norm are computed inside the last-phase launch of each stage from the k_s it holds in registers (no separate
- * passes over the state; esdg_axpy_stages / esdg_dopri_error above are then not used): per node the same bits, the estimate to
- * summation order, 4.3 instead of 5.1 ms per attempt for CNS at N=4 on 512x512.
- * Reproducibility of the estimate: it is a sum of one partial per workgroup of the last-phase launches, so its last bits depend on
- * how a context cuts that phase into launches (stand-alone, or interior + boundary strips of a sharded schedule) and on whether
- * the fused or the separate-pass form runs.  An adaptive run (step sizes follow the estimate) is bitwise reproducible for a FIXED
- * sharding and library build; the states, all k_s and the accept / reject decisions of one attempt do not depend on either.
+ * passes over the state; esdg_axpy_stages / esdg_dopri_error above are then not used): the same bits per node and in the estimate,
+ * 4.3 instead of 5.1 ms per attempt for CNS at N=4 on 512x512.
+ * Reproducibility of the estimate: the norm's terms are added in ONE order that depends on the number of state entries alone
+ * (runs of 4096 consecutive entries of the field-major state, a fixed tree inside a run, then the runs in a fixed order) -- by
+ * esdg_dopri_error, by the fused attempt, and whatever launches a sharded schedule cuts the last phase into.  On one rank an
+ * adaptive run is therefore bitwise reproducible across the fused / separate-pass forms and across stand-alone / sharded
+ * contexts; across DIFFERENT numbers of ranks the per-rank sums meet in the all-reduce, so the estimate (and with it the step
+ * sizes) agrees to rounding, not bit for bit.
  * (The accept copy Q <- Qtmp may be a pointer swap on the caller's side: the library keeps no reference to either array.) */
 int esdg_lsrk45_step(esdg_ctx* ctx, double* Q_dev, double* resQ_dev, double dt, void* stream);
 int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q_dev, double* Qtmp_dev, double* const* k_dev, double dt, double err_tol,
