@@ -9,6 +9,6 @@ for v in main "$@"; do
   timeout -k 10 300 python bench.py --no-cpu-baseline 2>/dev/null | python3 -c "
 import sys, json
 r = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('ms_per_step %.4f  phases %s' % (r['ms_per_step'], ' '.join('%.4f' % p for p in r['roofline']['phase_ms'])))"
+print('ms_per_step %.4f  phases %s  rough %s' % (r['ms_per_step'], ' '.join('%.4f' % p for p in r['roofline']['phase_ms']), '%.4f' % r['ms_per_step_rough_state'] if r.get('ms_per_step_rough_state') else '-'))"
 done
 done
