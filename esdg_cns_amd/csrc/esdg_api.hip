@@ -1426,6 +1426,9 @@ static int rhs_phase_impl(esdg_ctx* ctx, int phase, const double* Q, double* rhs
       if (!rc && x.after_phase == phase)
         rc = launch_pack(reinterpret_cast<const double*>(ctx->ws + x.buf_off), x.ncomp, sl, ctx->nsend,
                          reinterpret_cast<double*>(ctx->ws + x.send_off), s);
+  if (rc == (int)hipErrorInvalidValue && ctx->dim == 3 && phase == 1)   // (the launcher's dispatch found no instantiation: only the A/B
+    return fail(ESDG_ERR_STATE, "no hexahedral last-phase kernel for N=%d in this kernel selection (the A/B partners kh_rhs / kh_rhs_g, "
+                                "which ESDG_HEX_LINE=0 selects, stop at N=7; kh_rhs_l serves N = 1 ... 10)", ctx->T.N1 - 1);   // partners)
   if (rc) return fail(ESDG_ERR_NO_DEVICE, "kernel launch failed in phase %d: %s", phase, hipGetErrorString((hipError_t)rc));
   return ESDG_OK;
 }
