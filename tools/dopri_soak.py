@@ -1,6 +1,6 @@
 """Soak of the fused DOPRI45 attempt at cfg3's size (or: euler = cfg2's size, hex = a 64 x 64 x 16 slab): `n` attempts of the fused path and of the building blocks in lockstep (same step
 sizes), states compared bit for bit every 50 attempts -- a race in the in-place stage update would show as a difference.
-    python tools/dopri_soak.py [n [cns|euler|hex [free]]]
+    python tools/dopri_soak.py [n [cns|euler|hex|cavity [free]]]
 `free` (late round 5): NO lockstep -- each run follows its own error estimates through the controller.  Since the norm's terms are
 added in one order (esdg_kernels.hip: k_dopri_err / k_chunk_sum) the estimates, hence the step sizes, hence the states must stay
 equal bit for bit without any help; every attempt's estimate and step size are compared."""
@@ -18,6 +18,12 @@ if form == "hex":
     rd, md, ops, Q = bench.build_hex_problem(3, 64, 64, 16, 0, 64 * 64 * 16)
     eng = E.RhsEngine(rd, md, ops, E.EULER_HEX_COLLOCATED, lf_scale=0.0)   # (the reference's 0*.25; a non-zero factor is anti-dissipative on its J < 0 meshes and blows up by t = 0.02: docs/history.md section 9)
     Q0, dt0 = Q, 2e-4
+elif form == "cavity":   # the reference driver's own case: lid-driven cavity, adiabatic no-slip walls, N = 4 on 128 x 128 (kt3_rhs's wall form)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from common import product_cavity_problem
+    rd, md, ops, Q0 = product_cavity_problem(4, 128, 128)
+    eng = E.RhsEngine(rd, md, ops, E.CNS_MODAL, BCTYPE=1)
+    dt0 = 1e-4
 elif form == "euler":
     rd, md, ops, Q = bench.build_problem(4, 256, 256, 0, 256 * 256, "euler")
     eng = E.RhsEngine(rd, md, ops, E.EULER_COLLOCATED)
