@@ -106,6 +106,7 @@ SYMBOLS = {
     "esdg_lsrk_update": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_int64, _vp]),
     "esdg_axpy_stages": (C.c_int, [_vp, _vp, C.POINTER(_vp), c_double_p, C.c_int, C.c_double, C.c_int64, _vp]),
     "esdg_dopri_error": (C.c_int, [_vp, C.POINTER(_vp), c_double_p, C.c_int, C.c_double, C.c_int64, c_double_p, _vp]),
+    "esdg_dopri_error_fields": (C.c_int, [_vp, C.POINTER(_vp), c_double_p, C.c_int, C.c_double, C.c_int64, C.c_int, c_double_p, _vp]),
     "esdg_lsrk45_step": (C.c_int, [_vp, _vp, _vp, C.c_double, _vp]),
     "esdg_dopri45_attempt": (C.c_int, [_vp, _vp, _vp, C.POINTER(_vp), C.c_double, C.c_double, c_double_p, _vp]),
     "esdg_dopri45_next_dt": (C.c_double, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64]),

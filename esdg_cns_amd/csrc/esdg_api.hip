@@ -614,7 +614,7 @@ struct esdg_ctx {
   size_t off_AU = 0, off_Av = 0, off_B = 0, off_S = 0;
   const StageFuse* stage_fuse = nullptr;   // set by esdg_dopri45_attempt around a last-phase launch (kt3_rhs's STG instantiation)
   bool dopri_fusion = true;    // ESDG_DOPRI_FUSION=0 at esdg_create: the unfused attempt (A/B partner, and the bitwise test's)
-  DevBuf d_stage_partial;      // the error norm's terms of the fused attempt, one per state entry, + the chunk sums; allocated at the first attempt
+  DevBuf d_stage_partial;      // the error norm's terms of the fused attempt, one per node, + the chunk sums; allocated at the first attempt
   int64_t int_lo = 0, int_hi = 0;   // longest run of elements [int_lo, int_hi) that touch no ghost slot
   // nested interiors: nest_lo/hi[0] = [int_lo, int_hi); nest[p] = the longest run inside nest[p-1] all of whose face
   // neighbours lie in nest[p-1] -- what phase p can compute from data the same stream produced in phase p-1
@@ -2026,16 +2026,16 @@ int esdg_axpy_stages(double* y, const double* x0, const double* const* k, const 
   return ESDG_OK;
 }
 
-int esdg_dopri_error(const double* Q, const double* const* k, const double* coefE, int ns, double tol, int64_t n,
-                     double* result, void* stream) {
-  if (!Q || !k || !coefE || !result || ns < 1 || ns > 8) return fail(ESDG_ERR_ARG, "bad argument");
+int esdg_dopri_error_fields(const double* Q, const double* const* k, const double* coefE, int ns, double tol, int64_t nodes,
+                            int nfld, double* result, void* stream) {
+  if (!Q || !k || !coefE || !result || ns < 1 || ns > 8 || nodes < 0 || nfld < 1) return fail(ESDG_ERR_ARG, "bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // (one workgroup per run of ESDG_ERR_CHUNK entries -- 1600 at cfg3 -- then the runs' sums in k_sum's order: the fused attempt adds
-  // the same terms in the same order, esdg_kernels.hip)
-  const int64_t nc = err_chunks(n);
+  // (one term per node -- its fields in one fma chain --, one workgroup per run of ESDG_ERR_CHUNK nodes -- 1600 at cfg3 --, then the
+  // runs' sums in k_sum's order: the fused attempt adds the same terms in the same order, esdg_kernels.hip)
+  const int64_t nc = err_chunks(nodes);
   double* chunk = nullptr;
   HIP_TRY(hipMalloc(&chunk, sizeof(double) * (size_t)(nc + 1)));
-  int rc = launch_dopri_err(Q, k, coefE, ns, tol, n, chunk, s);
+  int rc = launch_dopri_err(Q, k, coefE, ns, tol, nodes, nfld, chunk, s);
   if (!rc) rc = launch_sum(chunk, nc, chunk + nc, s);
   double t = 0.0;
   hipError_t e = hipMemcpyAsync(&t, chunk + nc, sizeof(double), hipMemcpyDeviceToHost, s);
@@ -2044,6 +2044,11 @@ int esdg_dopri_error(const double* Q, const double* const* k, const double* coef
   if (rc || e != hipSuccess) return fail(ESDG_ERR_NO_DEVICE, "dopri error kernel failed");
   *result = t;
   return ESDG_OK;
+}
+
+int esdg_dopri_error(const double* Q, const double* const* k, const double* coefE, int ns, double tol, int64_t n,
+                     double* result, void* stream) {
+  return esdg_dopri_error_fields(Q, k, coefE, ns, tol, n, 1, result, stream);   // (every entry a node of its own)
 }
 
 // sum of n doubles on the device (one block, fixed order) into x[n] (a spare slot of the caller's), result on the host
@@ -2104,7 +2109,7 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
   // s holds k_s in registers and also writes the NEXT stage's state Q + dt sum_j a_{s+1,j} k_j, so the separate combination pass
   // (read Q, k_0 ... k_s, write Qtmp) shrinks to the reads of Q, k_0 ... k_{s-1} inside the launch; stage 6 (the b row) also leaves
   // the error combination of k_0 ... k_5 in k[6]'s array, which stage 7's launch reads back, completes with k_6 and turns into
-  // the norm's term of every entry (added below in k_dopri_err's order: the estimate's bits are those of the unfused attempt).  Stages with a zero coefficient in both rows are not read.  Per node the same fma chains as the
+  // the norm's term of every node (added below in k_dopri_err's order: the estimate's bits are those of the unfused attempt).  Stages with a zero coefficient in both rows are not read.  Per node the same fma chains as the
   // unfused attempt (same bits: tests/test_gpu_drivers.py); 30 instead of 43 state-sized sweeps per attempt on top of six
   // right-hand sides.
   // (wall meshes whose last phase is kt2_rhs -- CNS at N = 5 ... 8, the inviscid formulations at N = 7, 8 -- take the unfused attempt)
@@ -2114,9 +2119,9 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
   const bool fuse3 = ctx->dopri_fusion && ctx->dim == 3 && !ctx->bf && rhs_hex_blocks(ctx->T.N1, ctx->K) > 0;   // (kh_rhs_l)
   const bool fuse = fuse2 || fuse3;
   if (fuse) {
-    const int64_t nc = err_chunks(n);
-    if (!ctx->d_stage_partial.p) {   // n terms, nc chunk sums, the total
-      int rc = ctx->d_stage_partial.alloc(sizeof(double) * (size_t)(n + nc + 1));
+    const int64_t nodes = n / ctx->nfld, nc = err_chunks(nodes);
+    if (!ctx->d_stage_partial.p) {   // one term per node, nc chunk sums, the total
+      int rc = ctx->d_stage_partial.alloc(sizeof(double) * (size_t)(nodes + nc + 1));
       if (rc) return rc;
     }
     const LsrkFuse none{nullptr, nullptr, 0.0, 0.0, 0.0};
@@ -2145,8 +2150,8 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
     if (rc) return rc;
     double acc = 0.0;   // the terms in k_dopri_err's order (runs of ESDG_ERR_CHUNK entries, then the runs): the unfused attempt's bits
     double* terms = static_cast<double*>(ctx->d_stage_partial.p);
-    if (launch_chunk_sum(terms, n, terms + n, static_cast<hipStream_t>(stream))) return fail(ESDG_ERR_NO_DEVICE, "chunk sum launch failed");
-    rc = esdg_sum_device(terms + n, nc, &acc, stream);
+    if (launch_chunk_sum(terms, nodes, terms + nodes, static_cast<hipStream_t>(stream))) return fail(ESDG_ERR_NO_DEVICE, "chunk sum launch failed");
+    rc = esdg_sum_device(terms + nodes, nc, &acc, stream);
     if (rc) return rc;
     double tot[2] = {acc, (double)n};
     if (ctx->nghost && (rc = esdg_comm_allreduce(ctx, tot, 2, 0, stream)) != 0) return rc;   // every rank gets the same estimate
@@ -2159,7 +2164,7 @@ int esdg_dopri45_attempt(esdg_ctx* ctx, const double* Q, double* Qtmp, double* c
     if (rc) return rc;
   }
   double acc = 0.0;
-  int rc = esdg_dopri_error(Q, k, E, 7, err_tol, n, &acc, stream);
+  int rc = esdg_dopri_error_fields(Q, k, E, 7, err_tol, n / ctx->nfld, ctx->nfld, &acc, stream);
   if (rc) return rc;
   double tot[2] = {acc, (double)n};
   if (ctx->nghost && (rc = esdg_comm_allreduce(ctx, tot, 2, 0, stream)) != 0) return rc;   // every rank gets the same estimate

@@ -165,8 +165,8 @@ struct LsrkFuse {
 //               a workgroup reads its elements' state at entry only), and with e_out != null also
 //               e_out = sum_{j<ns} ce[j] k[j] + ce_last k_s, the error combination so far;
 //   err != 0  : e = (what the rhs array held at the node: the error combination so far) + ce_last k_s, and
-//               partial[entry] = (|e| / (tol (1 + |x0|)))^2 at the entry's own index of the field-major state
-//               (dg2D_CNS_cavity_optimized.jl:1014-1021); the host adds them with k_chunk_sum + k_sum.
+//               partial[node] = sum over the node's fields (field order, one fma chain) of (|e| / (tol (1 + |x0|)))^2 at the
+//               node's own index (dg2D_CNS_cavity_optimized.jl:1014-1021); the host adds them with k_chunk_sum + k_sum.
 // The chains are the fma chains of k_axpy_stages / k_dopri_err (esdg_kernels.hip) in the same order, and the norm's terms meet in
 // k_dopri_err's order: same bits as the unfused attempt per node AND in the estimate, however the last phase is cut into launches.
 struct StageFuse {
@@ -208,11 +208,12 @@ int launch_lsrk(double* Q, double* resQ, const double* rhs, double a, double b, 
 int launch_axpy_stages(double* y, const double* x0, const double* const* k, const double* coef, int ns, double dt,
                        int64_t n, hipStream_t s);
 int launch_sum(const double* x, int64_t n, double* out, hipStream_t s);
-// Hairer norm (k_dopri_err / k_chunk_sum, esdg_kernels.hip): runs of ESDG_ERR_CHUNK consecutive entries, one sum each into
-// chunk[0 .. err_chunks(n)); launch_sum over those gives the numerator in an order that depends on n alone
+// Hairer norm (k_dopri_err / k_chunk_sum, esdg_kernels.hip): one term per node (its nfld fields in one fma chain), runs of
+// ESDG_ERR_CHUNK consecutive nodes, one sum each into chunk[0 .. err_chunks(nodes)); launch_sum over those gives the numerator in
+// an order that depends on (nodes, nfld) alone
 #define ESDG_ERR_CHUNK 4096
 static inline int64_t err_chunks(int64_t n) { return (n + ESDG_ERR_CHUNK - 1) / ESDG_ERR_CHUNK; }
-int launch_dopri_err(const double* Q, const double* const* k, const double* coefE, int ns, double tol, int64_t n,
+int launch_dopri_err(const double* Q, const double* const* k, const double* coefE, int ns, double tol, int64_t nodes, int nfld,
                      double* chunk, hipStream_t s);
 int launch_chunk_sum(const double* x, int64_t n, double* chunk, hipStream_t s);
 // error functionals (esdg_kernels_err.hip); all arrays on the device

@@ -686,11 +686,12 @@ __device__ __forceinline__ double block_sum(double v) {
 }
 
 // The Hairer norm's numerator in ONE summation order, whoever forms the terms (round 5; the order used to follow the launch that
-// produced the partials).  The n entries i of the field-major state carry t_i = (|e_i| / (tol (1 + |x_i|)))^2; consecutive runs
-// of ESDG_ERR_CHUNK entries are summed by one workgroup -- thread t adds entries t, t + 256, ... of its run in that order, then
-// the 256 thread sums meet in a fixed tree -- and k_sum adds the runs' sums in its own fixed order.  The order is a function of n
-// alone: the fused attempt (kt3_rhs / kh_rhs_l store t_i, k_chunk_sum adds them), the attempt from the building blocks
-// (k_dopri_err forms t_i and adds them in flight) and a sharded context's pieces give the same bits.
+// produced the partials).  Node i of the `nodes` per field carries t_i = sum over its nfld fields, in field order and as one fma
+// chain, of (|e| / (tol (1 + |x|)))^2; consecutive runs of ESDG_ERR_CHUNK nodes are summed by one workgroup -- thread t adds
+// nodes t, t + 256, ... of its run in that order, then the 256 thread sums meet in a fixed tree -- and k_sum adds the runs' sums
+// in its own fixed order.  The order is a function of (nodes, nfld) alone: the fused attempt (kt3_rhs / kh_rhs_l store t_i,
+// k_chunk_sum adds them), the attempt from the building blocks (k_dopri_err forms t_i and adds them in flight) and a sharded
+// context's pieces give the same bits.
 __device__ __forceinline__ double chunk_tree(double a) {
   __shared__ double red[ESDG_TPB];
   red[threadIdx.x] = a;
@@ -703,17 +704,21 @@ __device__ __forceinline__ double chunk_tree(double a) {
 }
 
 __global__ __launch_bounds__(ESDG_TPB) void k_dopri_err(const double* __restrict__ Q, StagePtrs sp, int ns, double tol,
-                                                        int64_t n, double* __restrict__ chunk) {
+                                                        int64_t nodes, int nfld, double* __restrict__ chunk) {
   double acc = 0.0;
   const int64_t base = (int64_t)blockIdx.x * ESDG_ERR_CHUNK;
   for (int j = 0; j < ESDG_ERR_CHUNK / ESDG_TPB; ++j) {
     const int64_t i = base + (int64_t)j * ESDG_TPB + threadIdx.x;
-    if (i < n) {
-      double e = 0.0;
-      for (int s = 0; s < ns; ++s) e = __builtin_fma(sp.c[s], sp.k[s][i], e);
-      const double sc = fabs(e) / (tol * (1 + fabs(Q[i])));
-      double t = sc * sc;
-      asm volatile("" : "+v"(t));   // (a rounded product, as the fused kernels store it: no fma with the running sum)
+    if (i < nodes) {
+      double t = 0.0;
+      for (int f = 0; f < nfld; ++f) {
+        const int64_t idx = (int64_t)f * nodes + i;
+        double e = 0.0;
+        for (int s = 0; s < ns; ++s) e = __builtin_fma(sp.c[s], sp.k[s][idx], e);
+        const double sc = fabs(e) / (tol * (1 + fabs(Q[idx])));
+        t = __builtin_fma(sc, sc, t);   // (the chain the fused kernels run per node: kt3_rhs / kh_rhs_l STG epilogues)
+      }
+      asm volatile("" : "+v"(t));       // (a finished term, as the fused kernels store it: no contraction with the running sum)
       acc += t;
     }
   }
@@ -936,12 +941,12 @@ int launch_sum(const double* x, int64_t n, double* out, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-int launch_dopri_err(const double* Q, const double* const* k, const double* coefE, int ns, double tol, int64_t n,
+int launch_dopri_err(const double* Q, const double* const* k, const double* coefE, int ns, double tol, int64_t nodes, int nfld,
                      double* chunk, hipStream_t s) {
-  if (ns > 8) return (int)hipErrorInvalidValue;
+  if (ns > 8 || nfld < 1) return (int)hipErrorInvalidValue;
   StagePtrs sp;
   for (int i = 0; i < ns; ++i) { sp.k[i] = k[i]; sp.c[i] = coefE[i]; }
-  hipLaunchKernelGGL(k_dopri_err, dim3((unsigned)err_chunks(n)), dim3(ESDG_TPB), 0, s, Q, sp, ns, tol, n, chunk);
+  hipLaunchKernelGGL(k_dopri_err, dim3((unsigned)err_chunks(nodes)), dim3(ESDG_TPB), 0, s, Q, sp, ns, tol, nodes, nfld, chunk);
   return (int)hipGetLastError();
 }
 

@@ -1329,13 +1329,15 @@ __global__ __launch_bounds__(LCfg<N1>::T) void kh_rhs_l(HexTables HT, MeshDev M,
           double xo[HEX_NFLD], ei[HEX_NFLD];
 #pragma unroll
           for (int c = 0; c < HEX_NFLD; ++c) { xo[c] = sf.x0[c * KN + i0]; ei[c] = sf.err ? rhs[c * KN + i0] : 0.0; }
+          double t = 0.0;   // this node's term (k_dopri_err's chain) at the node's own index: the host adds them in ONE order (k_chunk_sum)
 #pragma unroll
           for (int c = 0; c < HEX_NFLD; ++c) {
             rhs[c * KN + i0] = out[c];
             const double e = __builtin_fma(sf.ce_last, out[c], ei[c]);
             const double sc = fabs(e) / (sf.tol * (1 + fabs(xo[c])));
-            sf.partial[c * KN + i0] = sc * sc;   // every entry's term at its own index: the host adds them in ONE order (k_chunk_sum)
+            t = __builtin_fma(sc, sc, t);
           }
+          if (sf.err) sf.partial[i0] = t;   // (uniform)
         }
         continue;
       }

@@ -634,13 +634,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wpe3(N1, WAL
           double xo[4], ei[4];
 #pragma unroll
           for (int f = 0; f < 4; ++f) { xo[f] = sf.x0[f * KN + i0]; ei[f] = sf.err ? rhs[f * KN + i0] : 0.0; }
+          double t = 0.0;                 // the norm's term of this node (k_dopri_err's chain) at the node's own index: the host adds
 #pragma unroll
-          for (int f = 0; f < 4; ++f) {   // the norm's term of every entry at the entry's own index: the host adds them in ONE order
-            rhs[f * KN + i0] = out[r][f];   // (k_chunk_sum), whatever launches the phase was cut into
+          for (int f = 0; f < 4; ++f) {   // the terms in ONE order (k_chunk_sum), whatever launches the phase was cut into
+            rhs[f * KN + i0] = out[r][f];
             const double e = __builtin_fma(sf.ce_last, out[r][f], ei[f]);
             const double sc = fabs(e) / (sf.tol * (1 + fabs(xo[f])));
-            sf.partial[f * KN + i0] = sc * sc;
+            t = __builtin_fma(sc, sc, t);
           }
+          if (sf.err) sf.partial[i0] = t;   // (uniform)
         }
       }
       continue;

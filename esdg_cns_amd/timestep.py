@@ -5,7 +5,7 @@
                  (tableau :919-934, Hairer error norm :1014-1021, P/PI step-size controller :1027-1037)
 
 The state never leaves the GPU: stage combinations and the error norm run in libesdg_hip
-(esdg_lsrk_update / esdg_axpy_stages / esdg_dopri_error).
+(esdg_lsrk_update / esdg_axpy_stages / esdg_dopri_error_fields).
 """
 import ctypes as C
 import math
@@ -75,7 +75,7 @@ class Dopri45:
         """swap=True: an accepted step exchanges the roles of the state and the candidate buffer instead of copying the candidate
         over the state (two state-sized sweeps less per accepted step); the current state is then `self.Q`, and the tensor passed
         in is scratch from the first accepted step on.  Default: the tensor passed in is updated in place.
-        pieces=True: every attempt from the library's building blocks (esdg_axpy_stages, the RHS, esdg_dopri_error) instead of
+        pieces=True: every attempt from the library's building blocks (esdg_axpy_stages, the RHS, esdg_dopri_error_fields) instead of
         esdg_dopri45_attempt -- what a sharded engine on the torch transport always does, and the partner of the fused attempt
         in the tests."""
         self.eng, self.Q, self.dt, self.dt0, self.tol = eng, Qd, float(dt0), float(dt0), float(err_tol)
@@ -114,7 +114,9 @@ class Dopri45:
             self.n_rhs += 1
         coefE = (C.c_double * 7)(*[float(x) for x in self.rkE])
         acc = C.c_double(0.0)
-        _chk(L, L.esdg_dopri_error(C.c_void_p(self.Q.data_ptr()), self._ptrs(self.k), coefE, 7, self.tol, n, C.byref(acc), s))
+        nfld = int(self.Q.shape[0])                     # (the fused attempt's order: a node's fields first, then the nodes)
+        _chk(L, L.esdg_dopri_error_fields(C.c_void_p(self.Q.data_ptr()), self._ptrs(self.k), coefE, 7, self.tol, n // nfld, nfld,
+                                          C.byref(acc), s))
         if self.eng.nranks > 1:
             import torch.distributed as dist
             t = torch.tensor([acc.value], dtype=torch.float64, device=self.Q.device)

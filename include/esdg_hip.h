@@ -350,6 +350,12 @@ int esdg_axpy_stages(double* y_dev, const double* x0_dev, const double* const* k
 /* Hairer error norm numerator sum((|sum_s E[s] k[s]| / (tol*(1+|Q|)))^2) (cavity_optimized.jl:1014-1021) */
 int esdg_dopri_error(const double* Q_dev, const double* const* k_dev, const double* coefE, int nstages,
                      double tol, int64_t n, double* result_host, void* stream);
+/* The same sum for a state of nfld fields of `nodes` entries each (n = nfld * nodes), in the order esdg_dopri45_attempt uses:
+ * a node's nfld terms first (field order, one fma chain), then the nodes' sums in an order that depends on `nodes` alone (runs of
+ * 4096 consecutive nodes, a fixed tree inside a run, the runs in a fixed order).  esdg_dopri_error(n) is the nfld = 1 case.  A host
+ * that drives the stages itself gets the bits of esdg_dopri45_attempt's estimate from this entry point. */
+int esdg_dopri_error_fields(const double* Q_dev, const double* const* k_dev, const double* coefE, int nstages,
+                            double tol, int64_t nodes, int nfld, double* result_host, void* stream);
 
 /* Whole steps (unsharded meshes).  esdg_lsrk45_step = the five stages of dg2D_euler_quad.jl:200-206 on the fused
  * RHS+stage kernels.  esdg_dopri45_attempt = stages 2..7 and the Hairer error estimate of one DOPRI45 attempt
@@ -361,9 +367,9 @@ int esdg_dopri_error(const double* Q_dev, const double* const* k_dev, const doub
  * and the error norm are computed inside the last-phase launch of each stage from the k_s it holds in registers (no separate
  * passes over the state; esdg_axpy_stages / esdg_dopri_error above are then not used): the same bits per node and in the estimate,
  * 4.3 instead of 5.1 ms per attempt for CNS at N=4 on 512x512.
- * Reproducibility of the estimate: the norm's terms are added in ONE order that depends on the number of state entries alone
- * (runs of 4096 consecutive entries of the field-major state, a fixed tree inside a run, then the runs in a fixed order) -- by
- * esdg_dopri_error, by the fused attempt, and whatever launches a sharded schedule cuts the last phase into.  On one rank an
+ * Reproducibility of the estimate: the norm's terms are added in ONE order that depends on the state's shape alone (a node's
+ * fields first, then runs of 4096 consecutive nodes, a fixed tree inside a run, the runs in a fixed order) -- by
+ * esdg_dopri_error_fields, by the fused attempt, and whatever launches a sharded schedule cuts the last phase into.  On one rank an
  * adaptive run is therefore bitwise reproducible across the fused / separate-pass forms and across stand-alone / sharded
  * contexts; across DIFFERENT numbers of ranks the per-rank sums meet in the all-reduce, so the estimate (and with it the step
  * sizes) agrees to rounding, not bit for bit.

@@ -133,7 +133,7 @@ def test_julia_shim_mirrors_the_header():
         # diagnostics / introspection
         "esdg_version", "esdg_uses_tensor_kernels", "esdg_check_state", "esdg_debug_log", "esdg_device_synchronize",
         # building blocks of entry points the shim binds whole (esdg_dopri45_attempt)
-        "esdg_axpy_stages", "esdg_dopri_error",
+        "esdg_axpy_stages", "esdg_dopri_error", "esdg_dopri_error_fields",
     }
     unbound = declared - called
     assert unbound <= not_needed, sorted(unbound - not_needed)
